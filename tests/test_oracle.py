@@ -1,0 +1,192 @@
+"""CPU tests pinning the oracle (oracle/*.c) against every known answer the
+reference publishes (README sizes), the survey's independent hashes and the
+reference's own round-trip tests (lzss_test.go:25-47, cli_test.go:33-40)."""
+import hashlib
+import random
+
+import pytest
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+HELLO = b"Hello world!\n"
+ABC = b"abc" * 8 + b"\n"
+
+
+def test_fixture_is_the_references(samiam, known):
+    assert len(samiam) == 3461
+    assert sha(samiam) == known["survey"]["samiam_sha256"]
+
+
+def test_readme_known_answer_sizes(oracle, known):
+    ref = known["reference"]
+    assert len(oracle.huffman_compress(HELLO)) == ref["huffman_hello_size"]       # README.md:157
+    assert len(oracle.huffman_compress(ABC)) == ref["huffman_abc_size"]           # README.md:167
+    assert len(oracle.lzss_compress(HELLO)) == ref["lzss_hello_size"]             # README.md:153
+    assert len(oracle.lzss_compress_legacy(ABC)) == ref["lzss_legacy_abc_size"]   # README.md:165
+
+
+def test_survey_cross_check_huffman(oracle, known, samiam):
+    s = known["survey"]
+    c = oracle.huffman_compress(samiam)
+    hs = s["huffman_samiam"]
+    sep = c.index(b"\\\n")
+    assert (len(c), sep, c[sep + 2], len(c) - sep - 3) == (hs["size"], hs["header"], hs["pad"], hs["payload"])
+    assert sha(c[sep + 2:]) == hs["pad_payload_sha256"]
+    assert sha(c) == hs["file_sha256_ascending_header"]
+    t = oracle.huffman_table(samiam)
+    assert len(t) == hs["symbols"] and max(x[3] for x in t) == hs["maxlen"]
+    tiled = (samiam * 20)[:65536]
+    ct = oracle.huffman_compress(tiled)
+    assert (len(ct), sha(ct)) == (s["huffman_samiam_tiled_65536"]["size"], s["huffman_samiam_tiled_65536"]["sha256"])
+    assert oracle.huffman_compress(b"ab").hex() == s["huffman_ab_hex"]
+    assert oracle.huffman_compress(b"aaaa").hex() == s["huffman_aaaa_hex"]
+    c = oracle.huffman_compress(b"a\nb\\")
+    assert c.endswith(bytes.fromhex(s["huffman_a_nl_b_bs_payload_hex"]))
+    assert {(r, l, code) for r, f, code, l in oracle.huffman_table(b"a\nb\\")} == {
+        (10, 2, 0), (ord("b"), 2, 1), (ord("a"), 2, 2), (0x5C, 2, 3)}
+
+
+def test_survey_cross_check_lzss(oracle, known, samiam):
+    s = known["survey"]
+    c = oracle.lzss_compress(samiam)
+    assert (len(c), sha(c)) == (s["lzss_samiam"]["size"], s["lzss_samiam"]["sha256"])
+    assert c == oracle.lzss_compress(samiam, 8192) == oracle.lzss_compress_allpos(samiam)
+    g = oracle.lzss_compress_legacy(samiam)
+    assert (len(g), sha(g)) == (s["lzss_legacy_samiam"]["size"], s["lzss_legacy_samiam"]["sha256"])
+    lh = oracle.huffman_compress(c)
+    assert (len(lh), sha(lh)) == (s["lzss_huffman_samiam"]["size"], s["lzss_huffman_samiam"]["sha256"])
+    assert oracle.lzss_compress(ABC).decode() == s["lzss_abc"]
+    assert oracle.lzss_compress_legacy(ABC).decode() == s["lzss_legacy_abc"]
+    a, b = s["lzss_tiebreak"]
+    assert oracle.lzss_compress(a.encode()).decode() == b
+    for a, b in s["lzss_threshold"]:
+        assert oracle.lzss_compress(a.encode()).decode() == b
+
+
+def test_oracle_regression_pins(oracle, known, samiam):
+    o = known["oracle"]
+    assert oracle.huffman_compress(HELLO).hex() == o["huffman_hello_hex"]
+    assert oracle.huffman_compress(ABC).hex() == o["huffman_abc_hex"]
+    tiled = (samiam * 20)[:65536]
+    assert sha(oracle.lzss_compress(tiled)) == o["lzss_tiled_sha256"]
+    assert sha(oracle.huffman_compress(tiled)) == o["huffman_tiled_sha256"]
+
+
+def test_reference_round_trips(oracle, samiam):
+    # lzss_test.go:25-47 (window 8192) and cli_test.go:33-40 (huffman, lzss lossless on samIAm)
+    assert oracle.lzss_decompress(oracle.lzss_compress(samiam, 8192)) == samiam
+    assert oracle.lzss_decompress(oracle.lzss_compress_legacy(samiam, 8192)) == samiam
+    assert oracle.huffman_decompress(oracle.huffman_compress(samiam)) == samiam
+    # layered, engine.go:443-479: lzss then huffman; decode in reverse
+    layered = oracle.huffman_compress(oracle.lzss_compress(samiam))
+    assert oracle.lzss_decompress(oracle.huffman_decompress(layered)) == samiam
+
+
+def go_runes(b):
+    """Third, pure-Python statement of Go's range-over-string decoding."""
+    out, i, n = [], 0, len(b)
+    while i < n:
+        b0 = b[i]
+        if b0 < 0x80:
+            out.append(b0); i += 1; continue
+        lo, hi = 0x80, 0xBF
+        if 0xC2 <= b0 <= 0xDF: need = 2
+        elif b0 == 0xE0: need, lo = 3, 0xA0
+        elif b0 == 0xED: need, hi = 3, 0x9F
+        elif 0xE1 <= b0 <= 0xEF: need = 3
+        elif b0 == 0xF0: need, lo = 4, 0x90
+        elif b0 == 0xF4: need, hi = 4, 0x8F
+        elif 0xF1 <= b0 <= 0xF3: need = 4
+        else:
+            out.append(0xFFFD); i += 1; continue
+        seq = b[i:i + need]
+        ok = len(seq) == need and lo <= seq[1] <= hi and all(0x80 <= c <= 0xBF for c in seq[2:])
+        if not ok:
+            out.append(0xFFFD); i += 1; continue
+        out.append(ord(bytes(seq).decode("utf-8"))); i += need
+    return out
+
+
+def test_go_utf8_semantics(oracle, known):
+    assert list(oracle.utf8_runes(bytes([0xE1, 0x80, 0xC2, 0x80]))) == known["survey"]["go_utf8_e180c280"]
+    rng = random.Random(7)
+    for _ in range(300):
+        n = rng.randrange(1, 40)
+        b = bytes(rng.choice([rng.randrange(256), rng.randrange(0x80, 0x100), rng.randrange(0xC0, 0xF8)]) for _ in range(n))
+        assert list(oracle.utf8_runes(b)) == go_runes(b)
+    txt = "héllo wörld ✓ 𝄞 \n".encode()
+    assert list(oracle.utf8_runes(txt)) == [ord(c) for c in txt.decode()]
+
+
+def test_huffman_lossy_on_invalid_utf8(oracle):
+    # huffman.go:306-311: invalid bytes become U+FFFD; round trip = []byte(string([]rune(string(in))))
+    rng = random.Random(11)
+    b = bytes(rng.randrange(256) for _ in range(5000))
+    expect = "".join(chr(r) for r in go_runes(b)).encode("utf-8")
+    assert oracle.huffman_decompress(oracle.huffman_compress(b)) == expect
+
+
+def test_huffman_edge_cases(oracle):
+    with pytest.raises(oracle.OracleError):
+        oracle.huffman_compress(b"")                       # heap.Pop on empty heap, huffman.go:102
+    assert oracle.huffman_decompress(oracle.huffman_compress(b"aaaa")) == b"a"  # bare leaf emits once, huffman.go:137-142
+    # '\\' must never be the last header entry (huffman.go:210 panics)
+    c = oracle.huffman_compress(b"AB\\\\A")
+    hdr = c[:c.index(b"\\\n")]
+    assert hdr.startswith(b"2|\\") and oracle.huffman_decompress(c) == b"AB\\\\A"
+    with pytest.raises(oracle.OracleError):
+        oracle.huffman_decompress(b"2|\\\\\n\x00")          # single '\\' symbol: only order is the fatal one
+    with pytest.raises(oracle.OracleError):
+        oracle.huffman_decompress(b"no separator")
+    # digits and '|' as symbols, newline escaped (huffman.go:313-317)
+    s = b"1|2||33|\n\n7"
+    assert oracle.huffman_decompress(oracle.huffman_compress(s)) == s
+    # 900000-bit reference limit is opt-in
+    rng = random.Random(3)
+    big = bytes(rng.randrange(32, 127) for _ in range(200000))
+    c = oracle.huffman_compress(big)
+    assert oracle.huffman_decompress(c) == big
+    with pytest.raises(oracle.OracleError):
+        oracle.huffman_decompress(c, strict_ref_limit=True)
+
+
+def test_header_multiset_helper(oracle, samiam):
+    c = oracle.huffman_compress(samiam)
+    ents, rest = oracle.header_entries(c)
+    assert len(ents) == 46 and sum(int(f) for f, _ in ents) == len(samiam)
+    assert (b"145", b"\\n") in ents
+
+
+@pytest.mark.parametrize("alphabet,n", [(b"ab", 300), (b"abc<\\\xff", 400), (bytes(range(256)), 600), (b"a", 200)])
+def test_lzss_lazy_equals_literal_form(oracle, alphabet, n):
+    rng = random.Random(len(alphabet) * 1000 + n)
+    for w in (4096, 16, 0):
+        for _ in range(6):
+            b = bytes(rng.choice(alphabet) for _ in range(rng.randrange(0, n)))
+            c = oracle.lzss_compress(b, w)
+            assert c == oracle.lzss_compress_allpos(b, w)
+            assert oracle.lzss_decompress(c) == b
+
+
+def test_lzss_escape(oracle):
+    assert oracle.lzss_escape(b"a<b\xffc\\d") == b"a\xffb\\\xffc\\\\d"
+    assert oracle.lzss_unescape(b"a\xffb\\\xffc\\\\d") == b"a<b\xffc\\d"
+    assert oracle.lzss_compress(b"") == b"" and oracle.lzss_decompress(b"") == b""
+    with pytest.raises(oracle.OracleError):
+        oracle.lzss_decompress(b"ab<5,2>")
+
+
+def test_lzss_window_binds(oracle):
+    rng = random.Random(5)
+    blk = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(5000))
+    b = blk + blk
+    c = oracle.lzss_compress(b, 4096)      # distance 5000 > window: no long match
+    assert b"<5000," not in c and oracle.lzss_decompress(c) == b
+    c0 = oracle.lzss_compress(b, 0)        # unbounded (lzss.go:125)
+    assert b"<5000," in c0 and oracle.lzss_decompress(c0) == b
+    blk = blk[:4096]
+    c = oracle.lzss_compress(blk * 3, 4096)
+    assert c.endswith(b"<4096,4096><4096,4096>")
