@@ -157,7 +157,7 @@ def test_header_multiset_helper(oracle, samiam):
     c = oracle.huffman_compress(samiam)
     ents, rest = oracle.header_entries(c)
     assert len(ents) == 46 and sum(int(f) for f, _ in ents) == len(samiam)
-    assert (b"145", b"\\n") in ents
+    assert (str(samiam.count(b"\n")).encode(), b"\\n") in ents
 
 
 @pytest.mark.parametrize("alphabet,n", [(b"ab", 300), (b"abc<\\\xff", 400), (bytes(range(256)), 600), (b"a", 200)])
