@@ -1,0 +1,109 @@
+/*
+ * rsn.h -- C ABI of librsn: the MI355X (gfx950) implementation of raisin's
+ * Huffman and LZSS codecs (go-compression/raisin compressor/huffman,
+ * compressor/lz).  This is the drop-in boundary: a Go host binds these entry
+ * points with cgo in place of the per-package Compress/Decompress functions
+ * (binding shown in INTEGRATION.md).  Plain pointers and sizes only.
+ *
+ * All compute runs in hand-written HIP kernels; there is NO CPU fallback.  If
+ * no HIP device can be initialised every codec call fails with RSN_ERR_DEVICE.
+ *
+ * Threading: every entry point is re-entrant and may be called concurrently
+ * from any number of host threads (the reference engine runs codecs from
+ * concurrent goroutines, engine/engine.go:235-244).  State is per calling
+ * thread; nothing is process-global (unlike huffman.go:56,129,193-194).
+ *
+ * Errors: the reference panics (check(e), index out of range); this library
+ * returns a negative code and a thread-local message instead and never aborts.
+ * The cgo shim turns a non-zero code back into panic() to keep engine behaviour
+ * (engine.go:315-328 recovers it into a "failed" row).
+ */
+#ifndef RSN_H
+#define RSN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSN_OK 0
+#define RSN_ERR_ARG (-1)      /* bad argument (e.g. negative level, lzss.go:43-45) */
+#define RSN_ERR_EMPTY (-2)    /* huffman of empty input: reference panics in heap.Pop (huffman.go:102) */
+#define RSN_ERR_FORMAT (-3)   /* malformed compressed stream: reference panics (index/slice out of range) */
+#define RSN_ERR_DEVICE (-4)   /* HIP runtime / device failure */
+#define RSN_ERR_NOMEM (-5)
+#define RSN_ERR_LIMIT (-6)    /* outside implementation limits (documented in DESIGN.md) */
+#define RSN_ERR_CAPACITY (-7) /* caller-provided device output buffer too small */
+
+#define RSN_LZSS_DEFAULT_WINDOW 4096 /* lzss.go:35 DefaultWindowSize */
+
+/* ---- library / device ------------------------------------------------- */
+/* Select the HIP device used by the calling thread (default 0). */
+int rsn_device_set(int device);
+/* Number of visible HIP devices, or a negative error. */
+int rsn_device_count(void);
+const char *rsn_last_error(void); /* thread-local, valid until the next call on this thread */
+const char *rsn_version(void);
+void rsn_free(void *p);           /* releases buffers returned through `out` below */
+
+/* ---- host-buffer entry points (what the cgo shim binds) ----------------
+ * Input is borrowed for the duration of the call and never modified.  Output
+ * is allocated by the library and released with rsn_free().                */
+
+/* replaces huffman.Compress([]byte) []byte            huffman.go:299 */
+int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+/* replaces huffman.Decompress([]byte) []byte          huffman.go:327 */
+int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+/* replaces lz.CompressAsync([]byte, bool, int) []byte lzss.go:109
+ * (the engine path: Writer.Write lzss.go:53-57).  window <= 0 = unbounded
+ * search buffer (lzss.go:125).  The progress-bar argument has no equivalent. */
+int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
+/* replaces lz.Decompress([]byte, bool) []byte         lzss.go:323 */
+int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+
+/* Batch form for independent chunks (one .rsn segment per chunk, as
+ * engine.CompressFiles produces one file per input, engine.go:150-154). */
+int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
+                               uint8_t **outs, size_t *out_lens);
+
+/* ---- device-resident entry points --------------------------------------
+ * d_in / d_out are HIP device pointers on the calling thread's device; stream
+ * is a hipStream_t (NULL = the thread's own stream).  The call returns after
+ * the result size is known on the host; d_out is complete once `stream` has
+ * been synchronised (the calls below synchronise it before returning).
+ * d_out must be 16-byte aligned and hold rsn_*_bound() bytes.              */
+size_t rsn_huffman_compress_bound(size_t n);
+size_t rsn_lzss_compress_bound(size_t n);
+int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+/* Output size is only known after the header is parsed: call with d_out=NULL
+ * to get the exact size in *out_n, or pass a buffer with out_cap >= that.   */
+int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+
+/* ---- measurement --------------------------------------------------------
+ * When enabled, every kernel launch of the calling thread is bracketed by HIP
+ * events on the launch stream; rsn_prof_get() reports per-kernel totals since
+ * the last rsn_prof_reset().                                               */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} rsn_prof_entry;
+void rsn_prof_enable(int on);
+void rsn_prof_reset(void);
+int rsn_prof_get(rsn_prof_entry *entries, int cap); /* returns the number of entries */
+
+/* Introspection used by the parity tests: the code table the encoder builds for
+ * `in` (device buffer not needed; runs the histogram on the device, the tree on
+ * the host).  Arrays hold `cap` entries in printCodes DFS order (huffman.go:110);
+ * returns the symbol count or a negative error. */
+int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs,
+                          uint64_t *codes, uint8_t *lens, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,21 @@
+// codecs.h -- device-resident codec entry points shared between translation units.
+#pragma once
+
+#include "huff_host.h"
+#include "rsn_common.h"
+
+namespace rsn {
+
+size_t huff_compress_bound(size_t n);
+size_t lzss_compress_bound(size_t n);
+
+// All four: buffers are device pointers (16-byte aligned), the call synchronises
+// `s` before returning, *out_n is the exact result size; on RSN_ERR_CAPACITY it
+// is the capacity that would have sufficed.
+int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n,
+                    HuffTree *tree_out, HuffCodes *codes_out);
+int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
+int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
+int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
+
+}  // namespace rsn

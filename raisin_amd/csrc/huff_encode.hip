@@ -1,0 +1,570 @@
+// huff_encode.hip -- Huffman encode for gfx950 (MI355X).
+//
+// Replaces the inner loops of huffman.Compress (compressor/huffman/huffman.go:
+// histogram :306-311, encode :229-256, bitString.AsByteSlice :174-191).
+//
+// Pipeline (all on one stream):
+//   K1  k_byte_hist      N bytes -> per-tile (64 KiB) 256-bin histograms + global histogram
+//                        (LDS sub-histograms, 16 B/lane coalesced loads)          HBM-bound: N read
+//   --  D2H 2 KiB, host builds the Go-exact tree and code table (<= 256 leaves: microseconds)
+//   K2  k_tile_bits      per-tile bit totals from the tile histograms (no second input read)
+//   K3  k_scan_u64       exclusive scan -> bit offset of every tile
+//   K4  k_emit_init      zero the 16-byte units shared by neighbouring blocks
+//   K5  k_emit<MODE>     N bytes -> code words, bit-packed through LDS, 16 B/lane stores
+//                                                                  HBM-bound: N read + C written
+// Inputs with bytes >= 0x80 take the rune path (Go UTF-8 semantics, huffman.go:309):
+//   K1r k_rune_hist, K2r k_tile_bits_rune, K5 k_emit<MODE_RUNE> (one extra read of the input).
+//
+// Bit layout (huffman.go:245-255): out = header || "\\\n" || byte(pad) || bytes(0^pad || S),
+// S MSB-first.  The kernels treat `out` as one big-endian bit string whose first
+// code bit sits at bit 8*(hdr+3)+pad; tile t starts at that plus tile_off[t].
+#include "huff_host.h"
+#include "rsn_common.h"
+
+namespace rsn {
+
+constexpr int TILE = 65536;        // input bytes per tile
+constexpr int HB = 256;            // threads per block (4 wavefronts)
+constexpr int ROUND = HB * 16;     // input bytes per block round (16 B per lane)
+
+enum { MODE_ASCII = 0, MODE_ASCII_WIDE = 1, MODE_RUNE = 2 };
+
+// ---------------------------------------------------------------- K1: byte histogram
+// R replicated sub-histograms, bin-major (h[bin*R + copy]) so that copies of one
+// bin sit in different LDS banks; copy = lane % R.
+template <int R>
+__global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in, size_t n, uint32_t n_tiles,
+                                                  uint32_t *__restrict__ tile_hist,
+                                                  unsigned long long *__restrict__ ghist) {
+    __shared__ uint32_t h[256 * R];
+    const int tid = threadIdx.x;
+    const int copy = tid & (R - 1);
+    unsigned long long mine = 0;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        for (int i = tid; i < 256 * R; i += HB) h[i] = 0;
+        __syncthreads();
+        const size_t base = (size_t)t * TILE;
+#pragma unroll 4
+        for (int k = 0; k < TILE / ROUND; k++) {
+            const size_t off = base + (size_t)(k * HB + tid) * 16;
+            if (off + 16 <= n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(in + off);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    atomicAdd(&h[((w[j]) & 0xFF) * R + copy], 1u);
+                    atomicAdd(&h[((w[j] >> 8) & 0xFF) * R + copy], 1u);
+                    atomicAdd(&h[((w[j] >> 16) & 0xFF) * R + copy], 1u);
+                    atomicAdd(&h[(w[j] >> 24) * R + copy], 1u);
+                }
+            } else if (off < n) {
+                for (size_t p = off; p < n; p++) atomicAdd(&h[in[p] * R + copy], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t s = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) s += h[tid * R + ((r + tid) & (R - 1))];
+        tile_hist[(size_t)t * 256 + tid] = s;
+        mine += s;
+        __syncthreads();
+    }
+    if (mine) atomicAdd(&ghist[tid], mine);
+}
+
+// ---------------------------------------------------------------- Go UTF-8 classification (rune path)
+// Length of the valid sequence starting with b0 (1 ASCII, 2..4), 0 if invalid
+// (=> U+FFFD consuming one byte).  Accept ranges: go1.15 unicode/utf8.
+__device__ __forceinline__ int seq_len(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    if (b0 < 0x80) return 1;
+    if (b0 < 0xC2 || b0 > 0xF4) return 0;
+    uint32_t lo = 0x80, hi = 0xBF;
+    if (b0 == 0xE0) lo = 0xA0;
+    else if (b0 == 0xED) hi = 0x9F;
+    else if (b0 == 0xF0) lo = 0x90;
+    else if (b0 == 0xF4) hi = 0x8F;
+    if (b1 < lo || b1 > hi) return 0;
+    if (b0 < 0xE0) return 2;
+    if ((b2 & 0xC0) != 0x80) return 0;
+    if (b0 < 0xF0) return 3;
+    if ((b3 & 0xC0) != 0x80) return 0;
+    return 4;
+}
+
+__device__ __forceinline__ uint32_t load_word_clamped(const uint8_t *in, size_t n, long long off) {
+    // 4 bytes at `off` (multiple of 4); bytes outside [0,n) read as 0
+    if (off < 0 || (size_t)off >= n) return 0;
+    if ((size_t)off + 4 <= n) return *reinterpret_cast<const uint32_t *>(in + off);
+    uint32_t w = 0;
+    for (int k = 0; k < 4 && (size_t)off + k < n; k++) w |= (uint32_t)in[off + k] << (8 * k);
+    return w;
+}
+
+// Classifies the 16 positions [P, P+16).  A position is a rune start unless a
+// VALID multi-byte sequence begins 1..3 bytes before it (lead bytes are never
+// continuation bytes, so every valid sequence start is itself a rune start:
+// the decision is local, DESIGN.md "rune classification").  Returns the start
+// mask; rune[k] is meaningful where bit k is set.
+__device__ __forceinline__ uint32_t classify16(const uint8_t *__restrict__ in, size_t n, size_t P, uint32_t rune[16]) {
+    uint32_t w[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) w[j] = load_word_clamped(in, n, (long long)P - 4 + 4 * j);
+    const uint32_t valid = (P + 16 <= n) ? 0xFFFFu : (P < n ? ((1u << (n - P)) - 1u) : 0u);
+    if (((w[0] | w[1] | w[2] | w[3] | w[4] | w[5]) & 0x80808080u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) rune[k] = (w[1 + (k >> 2)] >> (8 * (k & 3))) & 0xFF;
+        return valid;
+    }
+    auto B = [&](int i) -> uint32_t { return (w[(i + 4) >> 2] >> (8 * ((i + 4) & 3))) & 0xFF; };   // i in [-4, 19]
+    int v[19];
+#pragma unroll
+    for (int q = -3; q < 16; q++) v[q + 3] = seq_len(B(q), B(q + 1), B(q + 2), B(q + 3));
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const bool consumed = v[k + 2] > 1 || v[k + 1] > 2 || v[k] > 3;
+        if (!consumed) mask |= 1u << k;
+        const int L = v[k + 3];
+        const uint32_t b0 = B(k), b1 = B(k + 1), b2 = B(k + 2), b3 = B(k + 3);
+        uint32_t r = b0;
+        if (L == 0) r = kRuneError;
+        else if (L == 2) r = ((b0 & 0x1F) << 6) | (b1 & 0x3F);
+        else if (L == 3) r = ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F);
+        else if (L == 4) r = ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
+        rune[k] = r;
+    }
+    return mask & valid;
+}
+
+// ---------------------------------------------------------------- K1r: rune histogram
+__global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in, size_t n,
+                                                  unsigned long long *__restrict__ ghist) {
+    __shared__ uint32_t h[2048];   // runes < 0x800; the rest go straight to global atomics
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2048; i += HB) h[i] = 0;
+    __syncthreads();
+    uint32_t n_err = 0;            // U+FFFD is the hot bin on binary data: count it in a register
+    const size_t rounds = (n + ROUND - 1) / ROUND;
+    for (size_t rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+        const size_t P = rd * ROUND + (size_t)tid * 16;
+        if (P >= n) continue;
+        uint32_t rune[16];
+        const uint32_t m = classify16(in, n, P, rune);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (!((m >> k) & 1)) continue;
+            const uint32_t r = rune[k];
+            if (r < 0x800) atomicAdd(&h[r], 1u);
+            else if (r == kRuneError) n_err++;
+            else atomicAdd(&ghist[r], 1ull);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2048; i += HB) if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+    for (int d = 32; d; d >>= 1) n_err += __shfl_down(n_err, d);
+    if ((tid & 63) == 0 && n_err) atomicAdd(&ghist[kRuneError], (unsigned long long)n_err);
+}
+
+// ---------------------------------------------------------------- K2: tile bit totals
+// one wavefront per tile: sum_s hist[t][s] * len[s]
+__global__ __launch_bounds__(HB) void k_tile_bits(const uint32_t *__restrict__ tile_hist, const uint8_t *__restrict__ lens,
+                                                  uint32_t n_tiles, unsigned long long *__restrict__ tile_bits) {
+    const uint32_t t = blockIdx.x * (HB / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const uint32_t *h = tile_hist + (size_t)t * 256;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s += (unsigned long long)h[lane + 64 * k] * lens[lane + 64 * k];
+    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) tile_bits[t] = s;
+}
+
+// K2r: rune path -- re-reads the tile, sums len[rune] over rune starts
+__global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict__ in, size_t n, const uint8_t *__restrict__ rlen,
+                                                       uint32_t n_tiles, unsigned long long *__restrict__ tile_bits) {
+    __shared__ unsigned long long part[HB / 64];
+    const int tid = threadIdx.x;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        unsigned long long s = 0;
+        for (int k = 0; k < TILE / ROUND; k++) {
+            const size_t P = (size_t)t * TILE + (size_t)(k * HB + tid) * 16;
+            if (P >= n) break;
+            uint32_t rune[16];
+            const uint32_t m = classify16(in, n, P, rune);
+#pragma unroll
+            for (int j = 0; j < 16; j++) if ((m >> j) & 1) s += rlen[rune[j]];
+        }
+        for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
+        if ((tid & 63) == 0) part[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) tile_bits[t] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- K3: exclusive scan (single block)
+__global__ __launch_bounds__(1024) void k_scan_u64(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+                                                   uint32_t n, unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const unsigned long long x = i < n ? in[i] : 0;
+        unsigned long long s = x;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d); if (lane >= d) s += y; }
+        if (lane == 63) wsum[wv] = s;
+        __syncthreads();
+        unsigned long long pre = carry_s;
+        for (int k = 0; k < wv; k++) pre += wsum[k];
+        if (i < n) out[i] = pre + s - x;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + s;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry_s;
+}
+
+// ---------------------------------------------------------------- K4: boundary units
+// Zero the 16-byte unit that holds the first bit of every emit block's range and
+// the unit that holds the end of the stream: those are the only units written
+// with atomicOr (they are shared by two neighbouring blocks / the header).
+__global__ void k_emit_init(uint32_t *__restrict__ out_words, const unsigned long long *__restrict__ tile_off,
+                            unsigned long long base_bits, uint32_t tiles_per_block, uint32_t n_tiles, uint32_t n_blocks,
+                            unsigned long long end_bit) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long unit;
+    if (b < n_blocks) {
+        const unsigned long long t0 = (unsigned long long)b * tiles_per_block;
+        if (t0 >= n_tiles) return;
+        unit = (base_bits + tile_off[t0]) >> 7;
+    } else if (b == n_blocks) {
+        unit = end_bit >> 7;
+    } else return;
+    uint4 z = {0, 0, 0, 0};
+    *reinterpret_cast<uint4 *>(out_words + unit * 4) = z;
+}
+
+// ---------------------------------------------------------------- K5: emit
+template <int MODE> struct EmitCfg;
+template <> struct EmitCfg<MODE_ASCII> { static constexpr int MAXLEN = 26; };
+template <> struct EmitCfg<MODE_ASCII_WIDE> { static constexpr int MAXLEN = 64; };
+template <> struct EmitCfg<MODE_RUNE> { static constexpr int MAXLEN = 64; };
+
+struct EmitArgs {
+    const uint8_t *in; size_t n;
+    const uint32_t *tab32;               // MODE_ASCII: 256 x (len<<26 | code)
+    const unsigned long long *code64;    // WIDE: [256]; RUNE: [kMaxRune]
+    const uint8_t *len8;                 // WIDE: [256]; RUNE: [kMaxRune]
+    const unsigned long long *tile_off;
+    unsigned long long base_bits;
+    uint32_t tiles_per_block, n_tiles;
+    uint32_t *out_words;
+};
+
+// Per-lane bit packer into the block's LDS window (big-endian 32-bit words:
+// bit 31 of word w is stream bit 32*w).  The first word a lane touches and its
+// trailing partial word may be shared with neighbours -> ds_or; words in between
+// are wholly owned -> plain ds_write.
+struct Packer {
+    uint32_t *win; unsigned long long acc; uint32_t nb, w; bool first;
+    __device__ __forceinline__ void start(uint32_t *window, uint32_t bit_off) { win = window; acc = 0; nb = bit_off & 31; w = bit_off >> 5; first = true; }
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {   // len <= 26
+        acc = (acc << len) | code;
+        nb += len;
+        if (nb >= 32) {
+            nb -= 32;
+            const uint32_t word = (uint32_t)(acc >> nb);
+            if (first) { atomicOr(&win[w], word); first = false; } else win[w] = word;
+            w++;
+        }
+    }
+    __device__ __forceinline__ void put64(unsigned long long code, uint32_t len) {   // len <= 64
+        if (len > 52) { put((uint32_t)(code >> 52), len - 52); len = 52; }
+        if (len > 26) { put((uint32_t)(code >> 26) & 0x3FFFFFFu, len - 26); len = 26; }
+        put((uint32_t)code & ((1u << len) - 1u), len);
+    }
+    __device__ __forceinline__ void finish() {
+        if (nb) atomicOr(&win[w], (uint32_t)(acc << (32 - nb)));   // garbage above bit 31 falls off
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
+    constexpr int MAXLEN = EmitCfg<MODE>::MAXLEN;
+    constexpr int WIN_WORDS = ROUND * MAXLEN / 32 + 8;
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN_WORDS];
+    __shared__ uint32_t s_tab[MODE == MODE_ASCII ? 256 : 1];
+    __shared__ unsigned long long s_code[MODE == MODE_ASCII_WIDE ? 256 : 1];
+    __shared__ uint8_t s_len[MODE == MODE_ASCII_WIDE ? 256 : 1];
+    __shared__ uint32_t s_wsum[HB / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t t0 = blockIdx.x * a.tiles_per_block;
+    if (t0 >= a.n_tiles) return;
+    const uint32_t t1 = min(t0 + a.tiles_per_block, a.n_tiles);
+    const size_t in0 = (size_t)t0 * TILE;
+    const size_t in1 = min((size_t)t1 * TILE, a.n);
+
+    if (MODE == MODE_ASCII) s_tab[tid] = a.tab32[tid];
+    if (MODE == MODE_ASCII_WIDE) { s_code[tid] = a.code64[tid]; s_len[tid] = a.len8[tid]; }
+    for (int i = tid; i < WIN_WORDS; i += HB) s_win[i] = 0;
+
+    const unsigned long long bit0 = a.base_bits + a.tile_off[t0];
+    const unsigned long long unit0 = bit0 >> 7;   // first 16-byte unit this block touches (shared with block-1)
+    unsigned long long win_unit = unit0;          // global unit index of s_win[0]
+    uint32_t fill = (uint32_t)(bit0 & 127);       // bits of the window that precede this block's data
+    __syncthreads();
+
+    for (size_t pos = in0; pos < in1; pos += ROUND) {
+        const size_t P = pos + (size_t)tid * 16;
+        // ---- pass 1: look up, sum code lengths
+        uint32_t e[MODE == MODE_ASCII ? 16 : 1];
+        uint32_t rune[MODE == MODE_RUNE ? 16 : 1];
+        uint32_t smask = 0, w4[4] = {0, 0, 0, 0};
+        uint32_t mylen = 0;
+        if (MODE == MODE_RUNE) {
+            smask = P < in1 ? classify16(a.in, a.n, P, rune) : 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) if ((smask >> k) & 1) mylen += a.len8[rune[k]];
+        } else {
+            if (P + 16 <= in1) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(a.in + P);
+                w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
+                smask = 0xFFFF;
+            } else if (P < in1) {
+                const int cnt = (int)(in1 - P);
+                for (int k = 0; k < cnt; k++) w4[k >> 2] |= (uint32_t)a.in[P + k] << (8 * (k & 3));
+                smask = (1u << cnt) - 1;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                if (MODE == MODE_ASCII) {
+                    const uint32_t ent = ((smask >> k) & 1) ? s_tab[b] : 0;
+                    e[k] = ent;
+                    mylen += ent >> 26;
+                } else {
+                    if ((smask >> k) & 1) mylen += s_len[b];
+                }
+            }
+        }
+        // ---- block exclusive scan of mylen
+        uint32_t incl = mylen;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t wpre = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < HB / 64; k++) { const uint32_t x = s_wsum[k]; if (k < wv) wpre += x; total += x; }
+        // ---- pass 2: pack into the LDS window
+        Packer pk;
+        pk.start(s_win, fill + wpre + incl - mylen);
+        if (MODE == MODE_ASCII) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) pk.put(e[k] & 0x3FFFFFFu, e[k] >> 26);
+        } else if (MODE == MODE_ASCII_WIDE) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                if ((smask >> k) & 1) pk.put64(s_code[b], s_len[b]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) if ((smask >> k) & 1) pk.put64(a.code64[rune[k]], a.len8[rune[k]]);
+        }
+        if (mylen) pk.finish();
+        __syncthreads();
+        // ---- flush complete 16-byte units
+        const uint32_t tot_bits = fill + total;
+        const uint32_t n_units = tot_bits >> 7;
+        for (uint32_t u = tid; u < n_units; u += HB) {
+            uint4 v = *reinterpret_cast<const uint4 *>(&s_win[u * 4]);
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+            const unsigned long long g = win_unit + u;
+            uint32_t *dst = a.out_words + g * 4;
+            if (g == unit0) {
+                if (v.x) atomicOr(dst + 0, v.x);
+                if (v.y) atomicOr(dst + 1, v.y);
+                if (v.z) atomicOr(dst + 2, v.z);
+                if (v.w) atomicOr(dst + 3, v.w);
+            } else {
+                *reinterpret_cast<uint4 *>(dst) = v;
+            }
+        }
+        uint32_t carry = 0;
+        if (tid < 4) carry = s_win[n_units * 4 + tid];
+        __syncthreads();
+        const uint32_t used = n_units * 4 + 4;
+        for (uint32_t i = tid; i < used; i += HB) s_win[i] = i < 4 ? carry : 0;   // lanes 0..3 of wave 0 hold the carry words
+        win_unit += n_units;
+        fill = tot_bits & 127;
+        // the scan barrier of the next round orders these writes before the next pack
+    }
+    __syncthreads();
+    if (fill && tid < 4) {
+        const uint32_t v = __builtin_bswap32(s_win[tid]);
+        if (v) atomicOr(a.out_words + win_unit * 4 + tid, v);
+    }
+}
+
+// ======================================================================= host side
+namespace {
+
+struct EncodePlan {
+    std::string header;      // header || "\\\n" || pad byte
+    unsigned pad = 0;
+    uint64_t total_bits = 0;
+    size_t out_n = 0;
+    bool ascii = true;
+    bool single = false;     // one distinct symbol: empty payload
+    unsigned max_len = 0;
+};
+
+int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t *d_tile_hist,
+                       std::vector<HuffSym> &syms, bool &ascii) {
+    void *p;
+    int rc = dev_buf(c, 1, 256 * 8, &p); if (rc) return rc;
+    unsigned long long *d_gh = (unsigned long long *)p;
+    RSN_HIP(hipMemsetAsync(d_gh, 0, 256 * 8, s));
+    static int R = [] { const char *e = getenv("RSN_HIST_R"); return e ? atoi(e) : 8; }();
+    const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 2048);
+    switch (R) {
+        case 1: RSN_LAUNCH("huff_byte_hist", k_byte_hist<1>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
+        case 4: RSN_LAUNCH("huff_byte_hist", k_byte_hist<4>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
+        case 16: RSN_LAUNCH("huff_byte_hist", k_byte_hist<16>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
+        case 32: RSN_LAUNCH("huff_byte_hist", k_byte_hist<32>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
+        default: RSN_LAUNCH("huff_byte_hist", k_byte_hist<8>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
+    }
+    void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 8, &hp); if (rc) return rc;
+    unsigned long long *h = (unsigned long long *)hp;
+    RSN_HIP(hipMemcpyAsync(h, d_gh, 256 * 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    ascii = true;
+    for (int b = 128; b < 256; b++) if (h[b]) ascii = false;
+    syms.clear();
+    if (ascii) {
+        for (uint32_t b = 0; b < 128; b++) if (h[b]) syms.push_back({b, h[b]});
+        return RSN_OK;
+    }
+    // rune path: Go UTF-8 semantics (huffman.go:309)
+    rc = dev_buf(c, 2, (size_t)kMaxRune * 8, &p); if (rc) return rc;
+    unsigned long long *d_rh = (unsigned long long *)p;
+    RSN_HIP(hipMemsetAsync(d_rh, 0, (size_t)kMaxRune * 8, s));
+    const size_t rounds = ceil_div(n, ROUND);
+    RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh);
+    RSN_HIP(hipMemcpyAsync(h, d_rh, (size_t)kMaxRune * 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    for (uint32_t r = 0; r < kMaxRune; r++) if (h[r]) syms.push_back({r, h[r]});
+    return RSN_OK;
+}
+
+}  // namespace
+
+size_t huff_compress_bound(size_t n) {
+    // an optimal prefix code never costs more than the fixed-length code: <= 21 bits per rune
+    const size_t syms = std::min<size_t>(n, kMaxRune);
+    return n * 21 / 8 + syms * 26 + 96;
+}
+
+// Encodes d_in[0..n) into d_out.  On RSN_ERR_CAPACITY *out_n holds the needed capacity.
+int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n,
+                    HuffTree *tree_out, HuffCodes *codes_out) {
+    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
+    const uint32_t n_tiles = (uint32_t)ceil_div(n, TILE);
+    void *p;
+    int rc = dev_buf(c, 0, (size_t)n_tiles * 256 * 4, &p); if (rc) return rc;
+    uint32_t *d_tile_hist = (uint32_t *)p;
+
+    std::vector<HuffSym> syms;
+    bool ascii;
+    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, d_tile_hist, syms, ascii); if (rc) return rc;
+
+    std::string hdr;
+    emit_header(syms, hdr);   // syms is ascending by rune here
+    HuffTree tree; HuffCodes codes; std::string msg;
+    if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
+    if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    if (tree_out) *tree_out = tree;
+    if (codes_out) *codes_out = codes;
+    if (!d_out) return RSN_OK;   // table introspection only
+
+    const unsigned pad = (unsigned)((8 - codes.total_bits % 8) % 8);            // huffman.go:245-249
+    hdr.append("\\\n");
+    hdr.push_back((char)pad);
+    const size_t H = hdr.size();
+    const size_t total = H + (size_t)((codes.total_bits + pad) / 8);
+    *out_n = total;
+    const size_t need = round_up(total, 16) + 32;
+    if (need > out_cap) { *out_n = need; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", need, out_cap); }
+
+    const unsigned long long base_bits = 8ull * H + pad;
+    if (codes.total_bits == 0) {   // one distinct symbol: code "" (huffman.go:110-116), no payload bytes
+        RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        return RSN_OK;
+    }
+
+    // ---- code tables
+    const int mode = !ascii ? MODE_RUNE : (codes.max_len <= 26 ? MODE_ASCII : MODE_ASCII_WIDE);
+    EmitArgs a{};
+    uint8_t *d_len8 = nullptr;
+    if (mode == MODE_RUNE) {
+        void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 9, &hp); if (rc) return rc;
+        unsigned long long *hc = (unsigned long long *)hp;
+        uint8_t *hl = (uint8_t *)hp + (size_t)kMaxRune * 8;
+        memset(hp, 0, (size_t)kMaxRune * 9);
+        for (uint32_t i = 0; i < tree.n_leaves; i++) { hc[tree.rune[i]] = codes.code[i]; hl[tree.rune[i]] = codes.len[i]; }
+        rc = dev_buf(c, 3, (size_t)kMaxRune * 9, &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, hp, (size_t)kMaxRune * 9, hipMemcpyHostToDevice, s));
+        a.code64 = (const unsigned long long *)p;
+        d_len8 = (uint8_t *)p + (size_t)kMaxRune * 8;
+    } else {
+        struct Tab { uint32_t t32[256]; unsigned long long c64[256]; uint8_t l8[256]; };
+        void *hp; rc = pinned_buf(c, sizeof(Tab), &hp); if (rc) return rc;
+        Tab *ht = (Tab *)hp;
+        memset(ht, 0, sizeof *ht);
+        for (uint32_t i = 0; i < tree.n_leaves; i++) {
+            const uint32_t r = tree.rune[i];
+            ht->c64[r] = codes.code[i]; ht->l8[r] = codes.len[i];
+            if (codes.max_len <= 26) ht->t32[r] = ((uint32_t)codes.len[i] << 26) | (uint32_t)codes.code[i];
+        }
+        rc = dev_buf(c, 3, sizeof(Tab), &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, ht, sizeof(Tab), hipMemcpyHostToDevice, s));
+        Tab *dt = (Tab *)p;
+        a.tab32 = dt->t32; a.code64 = dt->c64;
+        d_len8 = dt->l8;
+    }
+    a.len8 = d_len8;
+
+    // ---- tile bit offsets
+    rc = dev_buf(c, 4, ((size_t)n_tiles * 2 + 2) * 8, &p); if (rc) return rc;
+    unsigned long long *d_tile_bits = (unsigned long long *)p;
+    unsigned long long *d_tile_off = d_tile_bits + n_tiles;
+    if (mode == MODE_RUNE) {
+        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, d_tile_bits);
+    } else {
+        RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, d_tile_hist, d_len8, n_tiles, d_tile_bits);
+    }
+    RSN_LAUNCH("huff_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tile_bits, d_tile_off, n_tiles, d_tile_off + n_tiles);
+
+    // ---- emit
+    const uint32_t tiles_per_block = (uint32_t)std::max<size_t>(1, ceil_div(n_tiles, 2048));
+    const uint32_t n_blocks = (uint32_t)ceil_div(n_tiles, tiles_per_block);
+    a.in = d_in; a.n = n; a.tile_off = d_tile_off; a.base_bits = base_bits;
+    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out;
+    RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
+               (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + codes.total_bits);
+    RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+    if (mode == MODE_ASCII) RSN_LAUNCH("huff_emit", k_emit<MODE_ASCII>, dim3(n_blocks), dim3(HB), 0, s, a);
+    else if (mode == MODE_ASCII_WIDE) RSN_LAUNCH("huff_emit_wide", k_emit<MODE_ASCII_WIDE>, dim3(n_blocks), dim3(HB), 0, s, a);
+    else RSN_LAUNCH("huff_emit_rune", k_emit<MODE_RUNE>, dim3(n_blocks), dim3(HB), 0, s, a);
+    RSN_HIP(hipStreamSynchronize(s));   // hdr (host memory) must outlive the copy
+    return RSN_OK;
+}
+
+}  // namespace rsn

@@ -1,0 +1,256 @@
+// rsn_api.hip -- extern "C" surface of librsn (include/rsn.h) and the per-thread
+// context.  Host-buffer entry points stage through device memory and call the
+// device-resident codecs; there is no CPU compute path.
+#include "codecs.h"
+#include "rsn_common.h"
+
+namespace rsn {
+
+Ctx &ctx() {
+    static thread_local Ctx c;
+    return c;
+}
+
+int ctx_init(Ctx &c) {
+    if (c.inited) {
+        hipError_t e = hipSetDevice(c.device);
+        if (e != hipSuccess) return c.fail(RSN_ERR_DEVICE, "hipSetDevice(%d): %s", c.device, hipGetErrorString(e));
+        return RSN_OK;
+    }
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return c.fail(RSN_ERR_DEVICE, "no HIP device available (%s); librsn has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (c.device >= cnt) return c.fail(RSN_ERR_DEVICE, "device %d out of range (%d visible)", c.device, cnt);
+    RSN_HIP(hipSetDevice(c.device));
+    RSN_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.inited = true;
+    return RSN_OK;
+}
+
+int dev_buf(Ctx &c, int slot, size_t bytes, void **out) {
+    Ctx::Buf &b = c.bufs[slot];
+    if (bytes > b.cap) {
+        if (b.p) { RSN_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        const size_t want = round_up(bytes + bytes / 8, 4096);
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) { b.p = nullptr; return c.fail(RSN_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+        b.cap = want;
+    }
+    *out = b.p;
+    return RSN_OK;
+}
+
+int pinned_buf(Ctx &c, size_t bytes, void **out) {
+    if (bytes > c.pinned_cap) {
+        if (c.pinned) { RSN_HIP(hipHostFree(c.pinned)); c.pinned = nullptr; c.pinned_cap = 0; }
+        hipError_t e = hipHostMalloc(&c.pinned, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { c.pinned = nullptr; return c.fail(RSN_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        c.pinned_cap = bytes;
+    }
+    *out = c.pinned;
+    return RSN_OK;
+}
+
+void prof_collect(Ctx &c) {
+    for (auto &sl : c.slots) {
+        for (auto &pr : sl.pending) {
+            float ms = 0;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                sl.total_ms += ms;
+                sl.launches++;
+            }
+            c.free_events.push_back(pr.first);
+            c.free_events.push_back(pr.second);
+        }
+        sl.pending.clear();
+    }
+}
+
+namespace {
+
+// Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a malloc'ed result.
+template <class Fn>
+int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t bound, Fn fn) {
+    Ctx &c = ctx();
+    if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
+    *out = nullptr; *out_n = 0;
+    int rc = ctx_init(c); if (rc) return rc;
+    hipStream_t s = c.own_stream;
+    void *d_in, *d_out;
+    rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
+    RSN_HIP(hipMemsetAsync((uint8_t *)d_in + (n & ~(size_t)15), 0, 64, s));
+    if (n) RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+    size_t cap = bound, got = 0;
+    for (int attempt = 0;; attempt++) {
+        rc = dev_buf(c, 21, cap, &d_out); if (rc) return rc;
+        rc = fn(c, s, (const uint8_t *)d_in, (uint8_t *)d_out, cap, &got);
+        if (rc == RSN_ERR_CAPACITY && attempt == 0 && got > cap) { cap = got; continue; }
+        break;
+    }
+    if (rc) return rc;
+    uint8_t *res = (uint8_t *)malloc(got ? got : 1);
+    if (!res) return c.fail(RSN_ERR_NOMEM, "malloc(%zu) failed", got);
+    if (got) {
+        RSN_HIP(hipMemcpyAsync(res, d_out, got, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+    }
+    *out = res; *out_n = got;
+    return RSN_OK;
+}
+
+int dev_prologue(Ctx &c, void *stream, hipStream_t *s) {
+    int rc = ctx_init(c); if (rc) return rc;
+    *s = stream ? (hipStream_t)stream : c.own_stream;
+    return RSN_OK;
+}
+
+}  // namespace
+}  // namespace rsn
+
+using namespace rsn;
+
+extern "C" {
+
+int rsn_device_set(int device) {
+    Ctx &c = ctx();
+    if (device < 0) return c.fail(RSN_ERR_ARG, "negative device");
+    if (c.inited && c.device != device) {
+        // drop per-device resources; they are re-created lazily on the new device
+        (void)hipSetDevice(c.device);
+        for (auto &b : c.bufs) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+        c.own_stream = nullptr;
+        prof_collect(c);
+        for (auto e : c.free_events) (void)hipEventDestroy(e);
+        c.free_events.clear();
+        c.inited = false;
+    }
+    c.device = device;
+    return ctx_init(c);
+}
+
+int rsn_device_count(void) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess) return ctx().fail(RSN_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return cnt;
+}
+
+const char *rsn_last_error(void) { return ctx().err.c_str(); }
+const char *rsn_version(void) { return "librsn 0.1 (gfx950)"; }
+void rsn_free(void *p) { free(p); }
+
+size_t rsn_huffman_compress_bound(size_t n) { return huff_compress_bound(n); }
+size_t rsn_lzss_compress_bound(size_t n) { return lzss_compress_bound(n); }
+
+int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+    Ctx &c = ctx(); hipStream_t s;
+    if (!d_in || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    int rc = dev_prologue(c, stream, &s); if (rc) return rc;
+    return huff_encode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n, nullptr, nullptr);
+}
+
+int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+    Ctx &c = ctx(); hipStream_t s;
+    if (!d_in || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    int rc = dev_prologue(c, stream, &s); if (rc) return rc;
+    return huff_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
+}
+
+int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+    Ctx &c = ctx(); hipStream_t s;
+    if ((!d_in && n) || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    int rc = dev_prologue(c, stream, &s); if (rc) return rc;
+    return lzss_encode_dev(c, s, (const uint8_t *)d_in, n, window, (uint8_t *)d_out, out_cap, out_n);
+}
+
+int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+    Ctx &c = ctx(); hipStream_t s;
+    if ((!d_in && n) || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    int rc = dev_prologue(c, stream, &s); if (rc) return rc;
+    return lzss_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
+}
+
+int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    // typical outputs are < n; the exact need is reported back on RSN_ERR_CAPACITY
+    return host_call(in, n, out, out_n, n + n / 8 + (1 << 16),
+                     [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
+                         return huff_encode_dev(c, s, di, n, dout, cap, got, nullptr, nullptr);
+                     });
+}
+
+int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    return host_call(in, n, out, out_n, 4 * n + (1 << 16),
+                     [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
+                         return huff_decode_dev(c, s, di, n, dout, cap, got);
+                     });
+}
+
+int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+    return host_call(in, n, out, out_n, lzss_compress_bound(n),
+                     [n, window](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
+                         return lzss_encode_dev(c, s, di, n, window, dout, cap, got);
+                     });
+}
+
+int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    return host_call(in, n, out, out_n, 8 * n + (1 << 16),
+                     [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
+                         return lzss_decode_dev(c, s, di, n, dout, cap, got);
+                     });
+}
+
+int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+    Ctx &c = ctx();
+    if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
+    for (size_t i = 0; i < n_chunks; i++) {
+        int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
+        if (rc) { for (size_t k = 0; k < i; k++) { free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; } return rc; }
+    }
+    return RSN_OK;
+}
+
+void rsn_prof_enable(int on) { ctx().prof = on != 0; }
+void rsn_prof_reset(void) {
+    Ctx &c = ctx();
+    prof_collect(c);
+    for (auto &s : c.slots) { s.launches = 0; s.total_ms = 0; }
+}
+int rsn_prof_get(rsn_prof_entry *entries, int cap) {
+    Ctx &c = ctx();
+    prof_collect(c);
+    int k = 0;
+    for (auto &s : c.slots) {
+        if (!s.launches) continue;
+        if (k < cap && entries) {
+            snprintf(entries[k].name, sizeof entries[k].name, "%s", s.name.c_str());
+            entries[k].launches = s.launches;
+            entries[k].total_ms = s.total_ms;
+        }
+        k++;
+    }
+    return k;
+}
+
+int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs, uint64_t *codes, uint8_t *lens, size_t cap) {
+    Ctx &c = ctx();
+    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input");
+    int rc = ctx_init(c); if (rc) return rc;
+    hipStream_t s = c.own_stream;
+    void *d_in;
+    rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
+    RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+    HuffTree t; HuffCodes hc; size_t dummy = 0;
+    rc = huff_encode_dev(c, s, (const uint8_t *)d_in, n, nullptr, 0, &dummy, &t, &hc);
+    if (rc) return rc;
+    for (size_t k = 0; k < hc.dfs.size() && k < cap; k++) {
+        const uint32_t id = hc.dfs[k];
+        runes[k] = t.rune[id]; freqs[k] = t.freq[id]; codes[k] = hc.code[id]; lens[k] = hc.len[id];
+    }
+    return (int64_t)hc.dfs.size();
+}
+
+}  // extern "C"

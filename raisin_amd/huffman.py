@@ -1,0 +1,123 @@
+"""Mirror of /root/reference/compressor/huffman (huffman.go) over librsn."""
+import io
+
+from . import _lib
+
+
+def Compress(fileContents):
+    """huffman.go:299 Compress([]byte) []byte"""
+    return _lib.call_host(_lib.lib().rsn_huffman_compress, fileContents)
+
+
+def Decompress(fileContents):
+    """huffman.go:327 Decompress([]byte) []byte"""
+    return _lib.call_host(_lib.lib().rsn_huffman_decompress, fileContents)
+
+
+class Writer:
+    """huffman.go:368-386: Write compresses the whole buffer once and returns len(compressed)."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def Write(self, data):
+        compressed = Compress(data)
+        self.w.write(compressed)
+        return len(compressed)
+
+    write = Write
+
+    def Close(self):
+        return None
+
+    close = Close
+
+
+class Reader:
+    """huffman.go:388-422: the first Read drains the source and decompresses everything."""
+
+    def __init__(self, r):
+        self.r = r
+        self.decompressed = None
+        self.pos = 0
+
+    def Read(self, size=-1):
+        if self.decompressed is None:
+            self.decompressed = Decompress(self.r.read())
+        if size is None or size < 0:
+            size = len(self.decompressed) - self.pos
+        chunk = self.decompressed[self.pos:self.pos + size]
+        self.pos += len(chunk)
+        return chunk
+
+    read = Read
+
+
+def NewWriter(w):
+    """huffman.go:372 NewWriter(io.Writer) io.WriteCloser"""
+    return Writer(w)
+
+
+def NewReader(r):
+    """huffman.go:395 NewReader(io.Reader) io.Reader"""
+    if isinstance(r, (bytes, bytearray)):
+        r = io.BytesIO(r)
+    return Reader(r)
+
+
+def table(data):
+    """[(rune, freq, code, len)] in printCodes order (huffman.go:110) as built by the library."""
+    import ctypes
+
+    import numpy as np
+    L = _lib.lib()
+    data = bytes(data)
+    cap = 0x110000
+    runes = np.zeros(cap, dtype=np.uint32)
+    freqs = np.zeros(cap, dtype=np.uint64)
+    codes = np.zeros(cap, dtype=np.uint64)
+    lens = np.zeros(cap, dtype=np.uint8)
+    a = L.rsn_huffman_table(data, len(data), runes.ctypes.data, freqs.ctypes.data, codes.ctypes.data, lens.ctypes.data, cap)
+    if a < 0:
+        _lib.check(int(a))
+    return [(int(runes[i]), int(freqs[i]), int(codes[i]), int(lens[i])) for i in range(a)]
+
+
+# ---- device-resident form (torch tensors as plain device memory) -----------
+from ._lib import own_stream as _own_stream  # noqa: E402
+
+def compress_bound(n):
+    return int(_lib.lib().rsn_huffman_compress_bound(n))
+
+
+def compress_tensor(src, out=None, stream=None):
+    """src: uint8 CUDA tensor.  Returns a uint8 view of `out` holding the .rsn bytes."""
+    import torch
+    n = src.numel()
+    if out is None:
+        out = torch.empty(n + n // 8 + (1 << 16), dtype=torch.uint8, device=src.device)
+    st = _own_stream(src, stream)
+    try:
+        got = _lib.call_dev(_lib.lib().rsn_huffman_compress_dev, src.data_ptr(), n, out.data_ptr(), out.numel(), st)
+    except _lib.RsnError as e:
+        if e.code != _lib.RSN_ERR_CAPACITY:
+            raise
+        out = torch.empty(e.needed, dtype=torch.uint8, device=src.device)
+        got = _lib.call_dev(_lib.lib().rsn_huffman_compress_dev, src.data_ptr(), n, out.data_ptr(), out.numel(), st)
+    return out[:got]
+
+
+def decompress_tensor(src, out=None, stream=None):
+    import torch
+    n = src.numel()
+    st = _own_stream(src, stream)
+    if out is None:
+        out = torch.empty(8 * n + (1 << 16), dtype=torch.uint8, device=src.device)
+    try:
+        got = _lib.call_dev(_lib.lib().rsn_huffman_decompress_dev, src.data_ptr(), n, out.data_ptr(), out.numel(), st)
+    except _lib.RsnError as e:
+        if e.code != _lib.RSN_ERR_CAPACITY:
+            raise
+        out = torch.empty(e.needed, dtype=torch.uint8, device=src.device)
+        got = _lib.call_dev(_lib.lib().rsn_huffman_decompress_dev, src.data_ptr(), n, out.data_ptr(), out.numel(), st)
+    return out[:got]

@@ -1,0 +1,137 @@
+"""GPU parity: librsn Huffman decode (through the C ABI) vs the CPU oracle, bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from test_gpu_huffman_encode import fib_skewed, rnd_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def huff():
+    from raisin_amd import huffman
+    return huffman
+
+
+def test_fixtures(huff, oracle, samiam):
+    for data in (b"Hello world!\n", b"abc" * 8 + b"\n", samiam, (samiam * 20)[:65536], b"ab", b"a\nb\\", b"AB\\\\A", b"1|2||33|\n\n7"):
+        c = oracle.huffman_compress(data)
+        assert huff.Decompress(c) == oracle.huffman_decompress(c) == data
+    # reference round trip (cli_test.go:33-40) entirely on the device
+    assert huff.Decompress(huff.Compress(samiam)) == samiam
+
+
+def test_single_symbol_quirk(huff, oracle):
+    c = oracle.huffman_compress(b"aaaa")
+    assert huff.Decompress(c) == oracle.huffman_decompress(c) == b"a"   # huffman.go:136-143
+    c = oracle.huffman_compress("ééé".encode())
+    assert huff.Decompress(c) == "é".encode()
+
+
+@pytest.mark.parametrize("n", [2, 3, 15, 16, 17, 255, 4095, 4097, 8191, 8192, 8193, 65537, 1 << 20, (1 << 22) + 12345])
+def test_flat_alphabet_sizes(huff, oracle, n):
+    data = rnd_bytes(n, n, 0, 128)
+    c = oracle.huffman_compress(data)
+    assert huff.Decompress(c) == data
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_skewed_self_sync(huff, oracle, seed):
+    rng = np.random.default_rng(200 + seed)
+    k = int(rng.integers(2, 120))
+    p = rng.dirichlet(np.ones(k) * (0.05 + 0.2 * seed))
+    data = rng.choice(np.arange(8, 8 + k, dtype=np.uint8), size=400000 + seed * 9991, p=p).astype(np.uint8).tobytes()
+    c = oracle.huffman_compress(data)
+    assert huff.Decompress(c) == data
+
+
+def test_two_symbols_one_bit_codes(huff, oracle):
+    data = rnd_bytes(1, 700001, 0, 2)
+    c = oracle.huffman_compress(data)
+    assert huff.Decompress(c) == data
+
+
+def test_wide_codes_long_walk(huff, oracle):
+    data = fib_skewed(30)
+    c = oracle.huffman_compress(data)
+    assert huff.Decompress(c) == data
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 4096, 65537, 1 << 19])
+def test_binary_is_lossy_like_the_reference(huff, oracle, n):
+    data = rnd_bytes(7 * n + 1, n)
+    c = oracle.huffman_compress(data)
+    want = oracle.huffman_decompress(c)
+    assert huff.Decompress(c) == want
+    assert huff.Decompress(huff.Compress(data)) == want
+
+
+def test_utf8_text(huff, oracle):
+    rng = random.Random(9)
+    s = "".join(rng.choice("abc déf ✓ λ 𝄞 \n\\|0123") for _ in range(150000)).encode("utf-8")
+    c = oracle.huffman_compress(s)
+    assert huff.Decompress(c) == s
+
+
+def test_header_order_is_free(huff, oracle, samiam):
+    """Any entry order is a legal reference output (Go map order, huffman.go:312)."""
+    c = oracle.huffman_compress(samiam)
+    ents, rest = oracle.header_entries(c)
+    rng = random.Random(4)
+    for _ in range(5):
+        rng.shuffle(ents)
+        while ents[-1][1] == b"\\":
+            rng.shuffle(ents)
+        shuffled = b"".join(f + b"|" + s for f, s in ents) + b"\\\n" + rest
+        assert huff.Decompress(shuffled) == samiam == oracle.huffman_decompress(shuffled)
+
+
+def test_large_pad_byte(huff, oracle, samiam):
+    c = oracle.huffman_compress(samiam)
+    sep = c.index(b"\\\n")
+    pad = c[sep + 2]
+    weird = c[:sep + 2] + bytes([pad + 16]) + b"\x00\x00" + c[sep + 3:]
+    assert oracle.huffman_decompress(weird) == samiam
+    assert huff.Decompress(weird) == samiam
+
+
+def test_errors_where_the_reference_panics(huff, oracle, samiam):
+    from raisin_amd import RsnError
+    good = oracle.huffman_compress(samiam)
+    bad_inputs = [
+        b"no separator at all",
+        b"2|\\\\\n\x00",                      # '\\' is the last header entry (huffman.go:210)
+        b"3|a2|b\\\n\x09\x00",               # pad exceeds payload bits (huffman.go:294)
+        b"4|a\\\n\x00\xff",                  # single-leaf tree with payload (huffman.go:139-140)
+        b"3|a2|b1|c\\\n\x00",                # multi-symbol tree, empty payload (huffman.go:145)
+        b"\\\n\x00\x00",                     # empty header (huffman.go:102)
+        good[:-1] + bytes([good[-1] ^ 1]) if False else good[:-2],   # truncated: ends inside a codeword (usually)
+    ]
+    for b in bad_inputs:
+        try:
+            want = oracle.huffman_decompress(b)
+        except oracle.OracleError:
+            want = None
+        if want is None:
+            with pytest.raises(RsnError):
+                huff.Decompress(b)
+        else:
+            assert huff.Decompress(b) == want
+
+
+def test_device_resident_round_trip_256MiB(huff):
+    import torch
+    n = 1 << 28
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0002)
+    src = torch.randint(0, 128, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    c = huff.compress_tensor(src)
+    d = huff.decompress_tensor(c)
+    assert d.numel() == n and torch.equal(d, src)
+    # skewed (variable-length codes, real self-synchronisation) at size
+    w = torch.tensor([2.0 ** (-i / 3) for i in range(90)], device="cuda")
+    src2 = (torch.multinomial(w, 1 << 26, replacement=True).to(torch.uint8) + 32).contiguous()
+    c2 = huff.compress_tensor(src2)
+    d2 = huff.decompress_tensor(c2)
+    assert torch.equal(d2, src2)
