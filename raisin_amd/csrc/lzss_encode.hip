@@ -1,5 +1,386 @@
+// lzss_encode.hip -- LZSS encode for gfx950 (MI355X).
+//
+// Replaces lz.CompressAsync (compressor/lz/lzss.go:109): EncodeOpeningSymbols :369,
+// the per-position compressorWorker fan-out :119-130,:166-184 and the greedy
+// compaction :134-151.
+//
+//   E1 k_esc_count / k_esc_write   '<'->FF, FF->5C FF, 5C->5C 5C (lzss.go:369-389)
+//   E2 k_match     for EVERY escaped position i: the longest L such that fc[i:i+L]
+//                  occurs entirely inside the window fc[max(0,i-W):i], and the
+//                  distance to its LEFTMOST occurrence (bytes.Index, lzss.go:419).
+//                  key[i] = L<<16 | distance (0 => literal).
+//   E3 k_parse_exit / k_parse_chain / k_parse_mark   the greedy chain of lzss.go:136-151
+//                  (position i is visited iff no earlier visited reference covers it)
+//   E4 k_tok_emit  "<off,len>" if shorter than the match, else the raw bytes (lzss.go:143-149)
+//
+// E2 is the cost: W byte-compares per position is the reference's semantics
+// (leftmost-longest over the whole window), so it is VALU-bound, not HBM-bound.
+// Formulation (DESIGN.md "LZSS match search"): lane = position, step = diagonal.
+// On diagonal d (candidate start i-d) the match length obeys
+//     run_d(i) = fc[i]==fc[i-d] ? run_d(i+1)+1 : 0,
+// so a wavefront sweeps 64 consecutive positions against one candidate byte per
+// step (uniform LDS read), the run counters move one lane down per step (DPP
+// wave_shl:1) and every (i,d) pair costs O(1) regardless of the data -- runs of one
+// byte, periodic input and random input all take the same time.
 #include "codecs.h"
+
 namespace rsn {
-size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
-int lzss_encode_dev(Ctx &c, hipStream_t, const uint8_t *, size_t, int64_t, uint8_t *, size_t, size_t *) { return c.fail(RSN_ERR_LIMIT, "lzss encode: not built yet"); }
+
+__global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
+
+constexpr int LB = 256;                 // threads per block
+constexpr int ESC_TILE = LB * 16;       // input bytes per escape block
+constexpr int MATCH_STRIP = 16384;      // positions per match block
+constexpr int MATCH_WAVES = 4;          // each takes a quarter of the diagonals
+constexpr int PT = 8192;                // positions per parse tile
+constexpr uint32_t MAX_WINDOW = 8192;
+constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ E1: escape
+__device__ __forceinline__ uint32_t count_special16(const uint32_t w[4]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const uint32_t v = (w[j] >> (8 * b)) & 0xFF; c += (v == 0x5C || v == 0xFF); }
+    return c;
 }
+
+__device__ __forceinline__ void load16(const uint8_t *in, size_t n, size_t P, uint32_t w[4], int *cnt) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    if (P + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + P);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; *cnt = 16;
+    } else if (P < n) {
+        *cnt = (int)(n - P);
+        for (int k = 0; k < *cnt; k++) w[k >> 2] |= (uint32_t)in[P + k] << (8 * (k & 3));
+    } else *cnt = 0;
+}
+
+__global__ __launch_bounds__(LB) void k_esc_count(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_extra) {
+    __shared__ uint32_t part[LB / 64];
+    const size_t P = (size_t)blockIdx.x * ESC_TILE + threadIdx.x * 16;
+    uint32_t w[4]; int cnt;
+    load16(in, n, P, w, &cnt);
+    uint32_t c = 0;
+    if (cnt == 16) c = count_special16(w);
+    else for (int k = 0; k < cnt; k++) { const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; c += (v == 0x5C || v == 0xFF); }
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_extra[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
+                                                  uint8_t *__restrict__ fc) {
+    __shared__ uint32_t wsum[LB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t P = (size_t)blockIdx.x * ESC_TILE + tid * 16;
+    uint32_t w[4]; int cnt;
+    load16(in, n, P, w, &cnt);
+    uint32_t c = 0;
+    for (int k = 0; k < cnt; k++) { const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; c += (v == 0x5C || v == 0xFF); }
+    uint32_t incl = c;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < wv; k++) pre += wsum[k];
+    uint8_t *o = fc + P + blk_off[blockIdx.x] + pre + incl - c;
+    for (int k = 0; k < cnt; k++) {
+        uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (v == 0x3C) v = 0xFF;                       // '<' -> EncodedOpening (lzss.go:373-377)
+        else if (v == 0xFF || v == 0x5C) *o++ = 0x5C;  // escape byte first (lzss.go:378-379)
+        *o++ = (uint8_t)v;
+    }
+}
+
+// ------------------------------------------------------------------ E2: match search
+struct MatchArgs {
+    const uint8_t *fc; uint32_t E; uint32_t W; uint32_t DW;   // DW = diagonals per wave
+    uint32_t *keys;
+};
+
+#define RSN_DPP_WAVE_SHL1 0x130   // lane i <- lane i+1
+#define RSN_DPP_WAVE_SHR1 0x138   // lane i <- lane i-1
+
+template <bool MASKED>
+__device__ __forceinline__ void match_step(uint32_t X, uint32_t Y, uint32_t cin16, uint32_t &R16, uint32_t &Bd, uint32_t &best,
+                                           bool valid) {
+    // lanes 0..62 take the run of the lane above (position+1, same diagonal); lane 63 takes the carry
+    const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)cin16, (int)R16, RSN_DPP_WAVE_SHL1, 0xF, 0xF, false);
+    bool eq = X == Y;
+    if (MASKED) eq = eq && valid;
+    R16 = eq ? sh + 0x10000u : 0u;
+    Bd += 0x10001u;
+    const uint32_t key = min((Bd & 0xFFFFu) | R16, Bd);   // min(run,d)<<16 | d
+    best = max(best, key);
+}
+
+__global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t W4 = a.DW * MATCH_WAVES;                          // >= W
+    const uint32_t WUB = (a.W + 63) / 64 * 64;                       // warm-up positions above the strip
+    const uint32_t RLEN = MATCH_STRIP + WUB + W4;                    // staged positions
+    uint16_t *s_b = reinterpret_cast<uint16_t *>(smem);              // bytes (0x200 = outside the stream)
+    uint16_t *s_carry = s_b + RLEN;                                  // [MATCH_WAVES][DW] runs entering from the block above
+    uint32_t *s_comb = reinterpret_cast<uint32_t *>(s_carry + MATCH_WAVES * a.DW + (MATCH_WAVES * a.DW & 1));   // [2][MATCH_WAVES][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps the loop bounds in SGPRs
+    const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
+    const long long r0 = b0 - (long long)W4;
+    for (uint32_t i = tid; i < RLEN; i += LB) {
+        const long long p = r0 + i;
+        s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0x200;
+    }
+    for (uint32_t i = tid; i < MATCH_WAVES * a.DW; i += LB) s_carry[i] = 0;
+    __syncthreads();
+
+    const uint32_t Dk = wv * a.DW;                                    // this wave's diagonals: Dk+1 .. Dk+DWk
+    const uint32_t DWk = Dk >= a.W ? 0 : min(a.DW, a.W - Dk);
+    const uint32_t nsteps = DWk ? DWk + 63 : 0;
+    uint16_t *carry = s_carry + wv * a.DW;
+    const int nPB = (int)((MATCH_STRIP + WUB) / 64);
+
+    for (int pb = nPB - 1; pb >= 0; pb--) {
+        const long long P0 = b0 + 64ll * pb;
+        if (P0 >= (long long)a.E) continue;                           // nothing above the end of the stream: runs stay 0
+        const long long p = P0 + lane;
+        const uint32_t X = p < (long long)a.E ? (uint32_t)s_b[p - r0] : 0x300u;
+        uint32_t best = 0, R16 = 0;
+        // lane l meets diagonal Dk + (t - 62 + l) at step t; candidate index y = P0 + 62 - t - Dk for every lane
+        uint32_t Bd = (Dk + (uint32_t)lane - 63u) * 0x10001u;         // becomes (Dk + t - 62 + l)*0x10001 after the step's increment
+        const uint16_t *ybase = s_b + (P0 + 62 - (long long)Dk - r0);
+        for (uint32_t t0 = 0; t0 < nsteps; t0 += 64) {
+            const uint32_t ci = t0 + lane;
+            const uint32_t vCin = ci < DWk ? (uint32_t)carry[ci] << 16 : 0u;
+            uint32_t vCout = 0;
+            if (t0 >= 63 && t0 + 64 <= DWk) {
+#pragma unroll
+                for (int k = 0; k < 64; k++) {
+                    const uint32_t Y = ybase[-(int)(t0 + k)];
+                    const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
+                    match_step<false>(X, Y, cin, R16, Bd, best, true);
+                    // collect lane 0's run: shift the collector up one lane, lane 0 <- R16[0]
+                    vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 64; k++) {
+                    const uint32_t t = t0 + k;
+                    if (t < nsteps) {
+                        const uint32_t Y = ybase[-(int)t];
+                        const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
+                        const bool valid = (t + (uint32_t)lane - 63u) < DWk;   // local diagonal index in [0, DWk)
+                        match_step<true>(X, Y, cin, R16, Bd, best, valid);
+                    }
+                    vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
+                }
+            }
+            // lane 0 met local diagonal index t-63 at step t; after 64 shifts the value of step k sits in lane 63-k
+            const uint32_t co = t0 - (uint32_t)lane;
+            if (co < DWk) carry[co] = (uint16_t)(vCout >> 16);
+        }
+        uint32_t *comb = s_comb + (pb & 1) * (MATCH_WAVES * 64);
+        comb[wv * 64 + lane] = best;
+        __syncthreads();
+        if (wv == 0 && pb < MATCH_STRIP / 64 && p < (long long)a.E) {
+            uint32_t k = max(max(comb[lane], comb[64 + lane]), max(comb[128 + lane], comb[192 + lane]));
+            if ((k >> 16) == 0) k = 0;
+            a.keys[p] = k;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ E3: greedy chain
+__device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len) {   // len("<off,len>"), lzss.go:318-320
+    auto digits = [](uint32_t v) { return v < 10 ? 1u : v < 100 ? 2u : v < 1000 ? 3u : v < 10000 ? 4u : 5u; };
+    return 3 + digits(off) + digits(len);
+}
+
+// next(i) = i + max(1, L_i) (lzss.go:139-142); exit_rel[i] = overshoot past the tile end of the chain started at i
+__global__ __launch_bounds__(LB) void k_parse_exit(const uint32_t *__restrict__ keys, uint32_t E, uint16_t *__restrict__ exit_rel) {
+    __shared__ uint16_t nxt[PT];
+    const uint32_t base = blockIdx.x * PT;
+    for (int i = threadIdx.x; i < PT; i += LB) {
+        const uint32_t p = base + i;
+        uint32_t L = p < E ? keys[p] >> 16 : 1;
+        if (L == 0) L = 1;
+        nxt[i] = (uint16_t)(i + L);                                   // < PT + MAX_WINDOW <= 65535
+    }
+    __syncthreads();
+    for (int round = 0; round < 13; round++) {                        // 2^13 = PT: every chain has left the tile
+        for (int i = threadIdx.x; i < PT; i += LB) {
+            const uint32_t j = nxt[i];
+            if (j < PT) nxt[i] = nxt[j];
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < PT; i += LB) if (base + i < E) exit_rel[base + i] = (uint16_t)(nxt[i] - PT);
+}
+
+// serial over tiles: where does the chain that starts at position 0 enter each tile
+__global__ void k_parse_chain(const uint16_t *__restrict__ exit_rel, uint32_t n_tiles, uint32_t *__restrict__ entry) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long pos = 0;
+    for (uint32_t t = 0; t < n_tiles; t++) {
+        const unsigned long long hi = (unsigned long long)(t + 1) * PT;
+        if (pos >= hi) { entry[t] = NO_ENTRY; continue; }
+        entry[t] = (uint32_t)(pos - (unsigned long long)t * PT);
+        pos = hi + exit_rel[pos];
+    }
+}
+
+// walk the tile's part of the chain, flag the visited positions, count the output bytes
+__global__ __launch_bounds__(LB) void k_parse_mark(const uint32_t *__restrict__ keys, uint32_t E, const uint32_t *__restrict__ entry,
+                                                   uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+    __shared__ uint16_t nxt[PT];
+    __shared__ uint32_t fl[PT / 32];
+    __shared__ uint32_t part[LB / 64];
+    const uint32_t base = blockIdx.x * PT;
+    for (int i = threadIdx.x; i < PT; i += LB) {
+        const uint32_t p = base + i;
+        uint32_t L = p < E ? keys[p] >> 16 : 1;
+        if (L == 0) L = 1;
+        nxt[i] = (uint16_t)(i + L);
+    }
+    for (int i = threadIdx.x; i < PT / 32; i += LB) fl[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t i = entry[blockIdx.x];
+        const uint32_t lim = min((uint32_t)PT, E - base);
+        while (i < lim) { fl[i >> 5] |= 1u << (i & 31); i = nxt[i]; }
+    }
+    __syncthreads();
+    uint32_t bytes = 0;
+    for (int i = threadIdx.x; i < PT; i += LB) {
+        if (!((fl[i >> 5] >> (i & 31)) & 1)) continue;
+        const uint32_t k = keys[base + i], L = k >> 16;
+        if (L == 0) bytes += 1;
+        else { const uint32_t e = enc_len(k & 0xFFFF, L); bytes += e < L ? e : L; }   // lzss.go:143
+    }
+    for (int i = threadIdx.x; i < PT / 32; i += LB) flags[(size_t)blockIdx.x * (PT / 32) + i] = fl[i];
+    for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bytes;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_bytes[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+}
+
+// ------------------------------------------------------------------ E4: token emit
+__device__ __forceinline__ uint8_t *put_dec(uint8_t *o, uint32_t v) {
+    char tmp[6]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *o++ = (uint8_t)tmp[--k];
+    return o;
+}
+
+__global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc, const uint32_t *__restrict__ keys, uint32_t E,
+                                                 const uint32_t *__restrict__ flags, const unsigned long long *__restrict__ tile_off,
+                                                 uint8_t *__restrict__ out) {
+    __shared__ uint32_t wsum[LB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t base = blockIdx.x * PT;
+    unsigned long long run = tile_off[blockIdx.x];
+    for (int r = 0; r < PT / (LB * 16); r++) {
+        // 16 consecutive positions per lane = one half-word of the flag mask
+        const uint32_t i0 = r * (LB * 16) + tid * 16;
+        const uint32_t fw = (flags[(size_t)blockIdx.x * (PT / 32) + (i0 >> 5)] >> (i0 & 31)) & 0xFFFF;
+        uint32_t mine = 0;
+        for (uint32_t m = fw; m; m &= m - 1) {
+            const uint32_t p = base + i0 + __builtin_ctz(m);
+            const uint32_t k = keys[p], L = k >> 16;
+            if (L == 0) mine += 1;
+            else { const uint32_t e = enc_len(k & 0xFFFF, L); mine += e < L ? e : L; }
+        }
+        uint32_t incl = mine;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int k = 0; k < LB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
+        uint8_t *o = out + run + pre + incl - mine;
+        for (uint32_t m = fw; m; m &= m - 1) {
+            const uint32_t p = base + i0 + __builtin_ctz(m);
+            const uint32_t k = keys[p], L = k >> 16, off = k & 0xFFFF;
+            if (L == 0) { *o++ = fc[p]; continue; }
+            if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
+            else for (uint32_t j = 0; j < L; j++) *o++ = fc[p + j];
+        }
+        run += tot;
+        __syncthreads();
+    }
+}
+
+// ======================================================================= host side
+size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
+
+int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    *out_n = 0;
+    if (n == 0) return RSN_OK;                                        // CompressAsync(empty) == empty
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "lzss: device buffers must be 16-byte aligned");
+    if (n >= (1ull << 31)) return c.fail(RSN_ERR_LIMIT, "lzss: input of %zu bytes exceeds the 2 GiB per-call limit", n);
+    void *p; int rc;
+    // ---- E1
+    const uint32_t n_eb = (uint32_t)ceil_div(n, ESC_TILE);
+    rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
+    unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
+    RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
+    RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_extra, d_eoff, n_eb, d_etot);
+    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    unsigned long long *h64 = (unsigned long long *)hp;
+    RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    const size_t E64 = n + (size_t)h64[0];
+    if (E64 >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: escaped stream too large for one call");
+    const uint32_t E = (uint32_t)E64;
+    uint32_t W;
+    if (window <= 0) {                                                // unbounded search buffer (lzss.go:125)
+        if (E > MAX_WINDOW) return c.fail(RSN_ERR_LIMIT, "lzss: unbounded window on %u escaped bytes exceeds the %u-byte window limit", E, MAX_WINDOW);
+        W = E;
+    } else {
+        if ((uint64_t)window > MAX_WINDOW && E > MAX_WINDOW) return c.fail(RSN_ERR_LIMIT, "lzss: window %lld exceeds the %u-byte limit", (long long)window, MAX_WINDOW);
+        W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);        // a window longer than the stream never binds
+    }
+    if (W == 0) W = 1;
+    rc = dev_buf(c, 9, (size_t)E + 64, &p); if (rc) return rc;
+    uint8_t *d_fc = (uint8_t *)p;
+    RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+    // ---- E2
+    rc = dev_buf(c, 10, (size_t)E * 4 + 64, &p); if (rc) return rc;
+    uint32_t *d_keys = (uint32_t *)p;
+    MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys};
+    {
+        const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
+        const size_t shmem = (size_t)(MATCH_STRIP + WUB + W4) * 2 + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;
+        static thread_local size_t attr_set = 0;
+        if (shmem > attr_set) {
+            RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_set = shmem;
+        }
+        RSN_LAUNCH("lzss_match", k_match, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(LB), shmem, s, ma);
+    }
+    // ---- E3
+    const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
+    rc = dev_buf(c, 11, (size_t)E * 2 + 64, &p); if (rc) return rc;
+    uint16_t *d_exit = (uint16_t *)p;
+    rc = dev_buf(c, 12, (size_t)n_pt * 4 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 2) * 8 + 64, &p); if (rc) return rc;
+    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;
+    uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
+    uint32_t *d_flags = d_entry + n_pt;
+    RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
+    RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_exit, n_pt, d_entry);
+    RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_entry, d_flags, d_tbytes);
+    RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+    RSN_HIP(hipMemcpyAsync(h64, d_ttot, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    const size_t total = (size_t)h64[0];
+    *out_n = total;
+    if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
+    // ---- E4
+    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out);
+    RSN_HIP(hipStreamSynchronize(s));
+    return RSN_OK;
+}
+
+}  // namespace rsn

@@ -1,0 +1,137 @@
+"""GPU parity: librsn LZSS encode/decode (through the C ABI) vs the CPU oracle, bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lz():
+    from raisin_amd import lz
+    return lz
+
+
+def rnd(seed, n, alphabet):
+    rng = np.random.default_rng(seed)
+    a = np.frombuffer(bytes(alphabet), dtype=np.uint8)
+    return a[rng.integers(0, len(a), size=n)].tobytes()
+
+
+def text(seed, n):
+    rng = random.Random(seed)
+    words = [b"the", b"quick", b"brown", b"fox", b"jumps", b"over", b"lazy", b"dog", b"compression", b"raisin",
+             b"huffman", b"lzss", b"window", b"buffer", b"a", b"I", b"<tag>", b"back\\slash", b"\xff\xfe"]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words) + rng.choice([b" ", b" ", b"\n", b", "])
+    return bytes(out[:n])
+
+
+def test_fixtures_and_known_answers(lz, oracle, samiam, known):
+    s = known["survey"]
+    assert lz.CompressAsync(b"Hello world!\n") == b"Hello world!\n"
+    assert lz.CompressAsync(b"abc" * 8 + b"\n").decode() == s["lzss_abc"]
+    a, b = s["lzss_tiebreak"]
+    assert lz.CompressAsync(a.encode()).decode() == b          # leftmost (farthest) occurrence wins
+    for a, b in s["lzss_threshold"]:
+        assert lz.CompressAsync(a.encode()).decode() == b      # token only if strictly shorter (lzss.go:143)
+    c = lz.CompressAsync(samiam, False, 8192)                 # lzss_test.go:37-47
+    assert c == oracle.lzss_compress(samiam, 8192)
+    assert lz.Decompress(c, False) == samiam
+    assert lz.CompressAsync(samiam) == oracle.lzss_compress(samiam, 4096)
+    assert lz.CompressAsync(b"") == b"" and lz.Decompress(b"") == b""
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 4095, 4096, 4097, 8191, 8193, 16383, 16385, 40000])
+def test_sizes_small_alphabet(lz, oracle, n):
+    data = rnd(n, n, b"ab")
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
+
+
+@pytest.mark.parametrize("alphabet", [b"a", b"abc<\\\xff", bytes(range(256)), b"\\", b"<", b"\xff\\"])
+def test_alphabets_with_escapes(lz, oracle, alphabet):
+    for n in (300, 5000, 20011):
+        data = rnd(len(alphabet) * 7 + n, n, alphabet)
+        c = lz.CompressAsync(data)
+        assert c == oracle.lzss_compress(data)
+        assert lz.Decompress(c) == oracle.lzss_decompress(c) == data
+
+
+@pytest.mark.parametrize("w", [1, 5, 16, 63, 64, 65, 255, 1000, 4096, 8192])
+def test_windows(lz, oracle, w):
+    data = text(w, 30000)
+    c = lz.CompressAsync(data, False, w)
+    assert c == oracle.lzss_compress(data, w)
+    assert lz.Decompress(c) == data
+
+
+def test_unbounded_window_small(lz, oracle):
+    data = text(3, 6000)
+    assert lz.CompressAsync(data, False, 0) == oracle.lzss_compress(data, 0)   # lzss.go:125: <=0 means no limit
+    assert lz.CompressAsync(data, False, 100000) == oracle.lzss_compress(data, 100000)
+
+
+def test_text_and_period(lz, oracle):
+    data = text(11, 300000)
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
+    # config-3 shape: one 4096-byte block (no 5C / FF) repeated
+    rng = np.random.default_rng(0x5EED0003)
+    vals = np.array([v for v in range(256) if v not in (0x5C, 0xFF)], dtype=np.uint8)
+    blk = vals[rng.integers(0, len(vals), size=4096)].tobytes()
+    data = blk * 40
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert c.endswith(b"<4096,4096>" * 30)
+    assert lz.Decompress(c) == data
+
+
+def test_long_runs(lz, oracle):
+    for data in (b"a" * 100000, b"ab" * 30000, b"\\" * 20001, (b"x" * 5000 + b"y") * 8):
+        c = lz.CompressAsync(data)
+        assert c == oracle.lzss_compress(data)
+        assert lz.Decompress(c) == data
+
+
+def test_match_table_against_oracle(lz, oracle):
+    """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
+    data = text(21, 50000)
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress_allpos(data)
+
+
+def test_decode_errors(lz, oracle):
+    from raisin_amd import RsnError
+    for bad in (b"ab<5,2>", b"abcdef<3,4>", b"abc<1,", b"abc<x,1>", b"abc<1,1"):
+        try:
+            want = oracle.lzss_decompress(bad)
+        except oracle.OracleError:
+            want = None
+        if want is None:
+            with pytest.raises(RsnError):
+                lz.Decompress(bad)
+    with pytest.raises(ValueError):
+        lz.NewWriterLevel(None, -1)                            # lzss.go:43-45
+
+
+def test_layered_lzss_then_huffman(lz, oracle, samiam, known):
+    from raisin_amd import huffman
+    layered = huffman.Compress(lz.CompressAsync(samiam))      # engine.go:443-452
+    assert len(layered) == known["survey"]["lzss_huffman_samiam"]["size"]
+    assert layered == oracle.huffman_compress(oracle.lzss_compress(samiam))
+    assert lz.Decompress(huffman.Decompress(layered)) == samiam   # engine.go:454-479 (reverse order)
+
+
+def test_device_resident_16MiB(lz, oracle):
+    import torch
+    data = text(5, 16 << 20)
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    c = lz.compress_tensor(src)
+    d = lz.decompress_tensor(c)
+    assert torch.equal(d, src)
+    assert bytes(c.cpu().numpy()) == oracle.lzss_compress(data)
