@@ -103,6 +103,23 @@ int rsn_prof_get(rsn_prof_entry *entries, int cap); /* returns the number of ent
 int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs,
                           uint64_t *codes, uint8_t *lens, size_t cap);
 
+/* ---- host-side helpers (no device needed) --------------------------------
+ * The part of the Huffman codec that stays on the host by design: the Go-exact
+ * tree (buildTree huffman.go:58-103 with container/heap order), the codes
+ * (printCodes :110-127) and the textual header (:312-318 / decodeTree :196-227).
+ * Exposed so that the host logic can be checked on a machine without a GPU.   */
+
+/* (rune,count) pairs in any order -> codes in printCodes DFS order plus the
+ * header this library writes (ascending rune, '\\' never last).  Returns the
+ * symbol count, or a negative error.  header may be NULL.                      */
+int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms,
+                         uint32_t *out_runes, uint64_t *out_codes, uint8_t *out_lens,
+                         uint8_t *header, size_t header_cap, size_t *header_len);
+/* decodeTree's scan of a header (bytes before "\\\n").  Returns the number of
+ * distinct symbols (ascending rune), or a negative error where the reference
+ * would index out of range.                                                   */
+int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ SYMBOLS = [
     "rsn_huffman_compress_bound", "rsn_lzss_compress_bound",
     "rsn_huffman_compress_dev", "rsn_huffman_decompress_dev", "rsn_lzss_compress_dev", "rsn_lzss_decompress_dev",
     "rsn_prof_enable", "rsn_prof_reset", "rsn_prof_get", "rsn_huffman_table",
+    "rsn_huffman_plan", "rsn_huffman_parse_header",
 ]
 
 
@@ -77,6 +78,10 @@ def lib():
     L.rsn_prof_get.argtypes = [ctypes.POINTER(ProfEntry), ctypes.c_int]
     L.rsn_huffman_table.argtypes = [ctypes.c_char_p, sz, vp, vp, vp, vp, sz]
     L.rsn_huffman_table.restype = ctypes.c_int64
+    L.rsn_huffman_plan.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, szp]
+    L.rsn_huffman_plan.restype = ctypes.c_int64
+    L.rsn_huffman_parse_header.argtypes = [ctypes.c_char_p, sz, vp, vp, sz]
+    L.rsn_huffman_parse_header.restype = ctypes.c_int64
     L.rsn_huffman_compress_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), szp, ctypes.POINTER(u8p), szp]
     _lib = L
     return L

@@ -4,6 +4,8 @@
 #include "codecs.h"
 #include "rsn_common.h"
 
+#include <algorithm>
+
 namespace rsn {
 
 Ctx &ctx() {
@@ -251,6 +253,34 @@ int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t
         runes[k] = t.rune[id]; freqs[k] = t.freq[id]; codes[k] = hc.code[id]; lens[k] = hc.len[id];
     }
     return (int64_t)hc.dfs.size();
+}
+
+int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms, uint32_t *out_runes, uint64_t *out_codes,
+                         uint8_t *out_lens, uint8_t *header, size_t header_cap, size_t *header_len) {
+    Ctx &c = ctx();
+    std::vector<HuffSym> syms(n_syms);
+    for (size_t i = 0; i < n_syms; i++) syms[i] = {runes[i], counts[i]};
+    std::sort(syms.begin(), syms.end(), [](const HuffSym &a, const HuffSym &b) { return a.rune < b.rune; });
+    std::string hdr;
+    emit_header(syms, hdr);
+    if (header_len) *header_len = hdr.size();
+    if (header) { if (hdr.size() > header_cap) return c.fail(RSN_ERR_CAPACITY, "header needs %zu bytes", hdr.size()); memcpy(header, hdr.data(), hdr.size()); }
+    HuffTree t; HuffCodes hc; std::string msg;
+    if (!build_tree(syms, t, msg)) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
+    if (!assign_codes(t, hc, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    for (size_t k = 0; k < hc.dfs.size(); k++) {
+        const uint32_t id = hc.dfs[k];
+        out_runes[k] = t.rune[id]; out_codes[k] = hc.code[id]; out_lens[k] = hc.len[id];
+    }
+    return (int64_t)hc.dfs.size();
+}
+
+int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap) {
+    Ctx &c = ctx();
+    std::vector<HuffSym> syms; std::string msg;
+    if (!parse_header(header, n, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
+    for (size_t i = 0; i < syms.size() && i < cap; i++) { runes[i] = syms[i].rune; counts[i] = syms[i].freq; }
+    return (int64_t)syms.size();
 }
 
 }  // extern "C"

@@ -1,0 +1,209 @@
+"""Mirror of /root/reference/engine (engine.go, util.go) for the codecs on the
+accelerated path.  The engine is the CALLER of the hot path: layering, file
+I/O, ratio / lossless / entropy reporting stay on the host exactly as the
+reference does them; every byte of codec work goes through librsn."""
+import io
+import math
+import os
+import time
+from dataclasses import dataclass
+
+from . import huffman, lz
+
+# engine.go:32 lists 11 engines; the MI355X build carries the two this path names
+# (the others -- arithmetic, dmc, mcc, stdlib bindings -- are out of scope).
+Engines = ["lzss", "huffman"]
+Suites = {"all": list(Engines), "suite": list(Engines)}
+
+# engine.go:48-58 / :101-111
+Readers = {"lzss": lz.NewReader, "huffman": huffman.NewReader}
+Writers = {"lzss": lz.NewWriter, "huffman": huffman.NewWriter}
+
+
+class CompressedFile:
+    """engine.go:39-45,60-139"""
+
+    def __init__(self, CompressionEngine="", Compressed=b"", MaxSearchBufferLength=4096):
+        self.CompressionEngine = CompressionEngine
+        self.Compressed = bytes(Compressed)
+        self.Decompressed = None
+        self.pos = 0
+        self.MaxSearchBufferLength = MaxSearchBufferLength  # never read by the reference either (engine.go:445)
+
+    def Write(self, content):
+        newWriter = Writers[self.CompressionEngine]        # unknown engine: KeyError (reference: nil type assertion panics)
+        b = io.BytesIO()
+        w = newWriter(b)
+        w.Write(content)                                   # ONE write of the whole buffer (engine.go:133)
+        w.Close()
+        compressed = b.getvalue()
+        self.Compressed += compressed
+        return len(compressed)
+
+    def Read(self, size):
+        """engine.go:60-98: first call decompresses everything, then serves `size` bytes; returns (chunk, eof)."""
+        if self.Decompressed is None:
+            r = Readers[self.CompressionEngine](io.BytesIO(self.Compressed))
+            self.Decompressed = r.Read(-1)
+        chunk = self.Decompressed[self.pos:self.pos + size]
+        eof = len(self.Decompressed) - self.pos <= size
+        if not eof:
+            self.pos += size
+        return chunk, eof
+
+
+def compress(content, algorithms):
+    """engine.go:443-452: layers applied in order."""
+    for algorithm in algorithms:
+        f = CompressedFile(MaxSearchBufferLength=4096)
+        f.CompressionEngine = algorithm
+        f.Write(content)
+        content = f.Compressed
+    return content
+
+
+def decompress(content, algorithms):
+    """engine.go:454-479: layers undone in reverse order, read through a 512-byte buffer."""
+    for algorithm in reversed(algorithms):
+        f = CompressedFile(CompressionEngine=algorithm, Compressed=content)
+        while True:
+            _, eof = f.Read(512)
+            if eof:
+                break
+        content = f.Decompressed
+    return content
+
+
+def CompressFile(algorithms, path, output):
+    """engine.go:157-172"""
+    data = open(path, "rb").read()
+    print("Compressing...")
+    out = compress(data, algorithms)
+    open(output, "wb").write(out)
+    print("Original bytes: %d" % len(data))
+    print("Compressed bytes: %d" % len(out))
+    print("Compression ratio: %.2f%%" % (len(out) / len(data) * 100 if data else float("nan")))
+    return out
+
+
+def CompressFiles(algorithms, files, extension):
+    for f in files:
+        CompressFile(algorithms, f, f + extension)
+
+
+def DecompressFile(algorithms, path, output):
+    """engine.go:187-199"""
+    data = open(path, "rb").read()
+    print("Decompressing...")
+    out = decompress(data, algorithms)
+    open(output, "wb").write(out)
+    return out
+
+
+def DecompressFiles(algorithms, files, extension):
+    for f in files:
+        path = f + extension
+        if extension.strip() in ("", "."):
+            path = os.path.splitext(f)[0]
+        DecompressFile(algorithms, f, path)
+
+
+@dataclass
+class Result:
+    """engine.go:201-209"""
+    CompressionEngine: str
+    TimeTaken: str
+    Ratio: float
+    ActualEntropy: float
+    Entropy: float
+    Lossless: bool
+    Failed: bool
+
+
+def _entropy(counts, total):
+    """goent discrete.Entropy(p, math.Log): -sum p ln p (natural log, engine.go:410)."""
+    h = 0.0
+    for c in counts:
+        if c:
+            p = c / total
+            h -= p * math.log(p)
+    return h
+
+
+def _byte_counts(b):
+    import numpy as np
+    return np.bincount(np.frombuffer(b, dtype=np.uint8), minlength=256).tolist() if b else []
+
+
+def BenchmarkFile(algorithms, fileString, PrintStats=False):
+    """engine.go:357-441: ONE timer around compress+decompress, ratio%, lossless by
+    byte equality, and the entropy columns -- including the quirk at :412-423 that
+    the 'compressed' entropy is computed over the DECOMPRESSED bytes divided by the
+    compressed length."""
+    data = open(fileString, "rb").read()
+    name = ",".join(algorithms)
+    entropy = _entropy(_byte_counts(data), len(data)) if data else 0.0
+    start = time.perf_counter()
+    compressed = compress(data, algorithms)
+    decompressed = decompress(compressed, algorithms)
+    dur = time.perf_counter() - start
+    lossless = decompressed == data
+    ratio = len(compressed) / len(data) * 100 if data else float("nan")
+    actual = _entropy(_byte_counts(decompressed), len(compressed)) if compressed else 0.0
+    res = Result(name, "%.2fms" % (dur * 1e3), ratio, actual, entropy, lossless, False)
+    if PrintStats:
+        print("Lossless: %s" % str(lossless).lower())
+        print("Original bytes: %d" % len(data))
+        print("Compressed bytes: %d" % len(compressed))
+        if not lossless:
+            print("Decompressed bytes: %d" % len(decompressed))
+        print("Compression ratio: %.2f%%" % ratio)
+        print("Time taken: %s" % res.TimeTaken)
+    return res
+
+
+def AsyncBenchmarkFile(algorithms, fileString):
+    """engine.go:310-355: a panic in a codec becomes a 'failed' row."""
+    try:
+        return BenchmarkFile(algorithms, fileString)
+    except Exception:  # noqa: BLE001 -- mirrors recover()
+        return Result(",".join(algorithms), "failed", 0.0, 0.0, 0.0, False, True)
+
+
+def parseAlgorithms(s):
+    """cmd/cli.go:203-231: "a,[b,c]" -> [[a],[b,c]]"""
+    algorithms, buf, layer, in_layer = [], "", [], False
+    for ch in s:
+        if ch == ",":
+            if in_layer and buf:
+                layer.append(buf)
+            elif buf:
+                algorithms.append([buf])
+            buf = ""
+        elif ch == "[":
+            in_layer = True
+        elif ch == "]":
+            layer.append(buf)
+            buf = ""
+            in_layer = False
+            algorithms.append(layer)
+            layer = []
+        else:
+            buf += ch
+    if buf:
+        algorithms.append([buf])
+    return algorithms
+
+
+def ByteCountSI(b):
+    """engine/util.go:30-42"""
+    unit = 1000
+    if b < unit:
+        return "%d B" % b
+    div, exp = unit, 0
+    n = b // unit
+    while n >= unit:
+        div *= unit
+        exp += 1
+        n //= unit
+    return "%.1f %cB" % (b / div, "kMGTPE"[exp])

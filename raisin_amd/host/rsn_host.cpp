@@ -1,0 +1,173 @@
+// rsn_host.cpp -- C++ host mirroring the reference's engine + CLI for the
+// accelerated path (the reference host is Go: engine/engine.go, cmd/cli.go; no
+// Go toolchain exists in this image, so the host above the C ABI is C++).
+// It keeps what the reference keeps on the host: file I/O, the -algorithm layer
+// list, .rsn naming, ratio / lossless reporting.  All codec work is librsn.
+//
+//   rsn -compress   <file[,file..]> [-algorithm=lzss,huffman] [-out=F | -outext=rsn] [-delete]
+//   rsn -decompress <file[,file..]> [-algorithm=lzss,huffman] [-out=F | -outext=E]   [-delete=false]
+//   rsn -benchmark  <file[,file..]> [-algorithm=lzss,huffman,[lzss,huffman]]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rsn.h"
+
+using Bytes = std::vector<uint8_t>;
+
+static Bytes read_file(const std::string &p) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) throw std::runtime_error("Could not open file (likely does not exist): " + p);   // cli.go:95
+    return Bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void write_file(const std::string &p, const Bytes &b) {
+    std::ofstream f(p, std::ios::binary);
+    f.write((const char *)b.data(), (std::streamsize)b.size());
+}
+
+// check(e) -> panic in the reference; an exception here (caught per row in -benchmark, engine.go:315-328)
+template <class Call>
+static Bytes take(Call call) {
+    uint8_t *out = nullptr; size_t n = 0;
+    if (call(&out, &n) != RSN_OK) throw std::runtime_error(rsn_last_error());
+    Bytes b(out, out + n);
+    rsn_free(out);
+    return b;
+}
+
+namespace engine {
+// engine.go:101-111 Writers / :48-58 Readers, restricted to the engines on this path
+using Codec = std::function<Bytes(const Bytes &)>;
+static const std::map<std::string, Codec> Writers = {
+    {"lzss", [](const Bytes &in) { return take([&](uint8_t **o, size_t *n) { return rsn_lzss_compress(in.data(), in.size(), RSN_LZSS_DEFAULT_WINDOW, o, n); }); }},
+    {"huffman", [](const Bytes &in) { return take([&](uint8_t **o, size_t *n) { return rsn_huffman_compress(in.data(), in.size(), o, n); }); }},
+};
+static const std::map<std::string, Codec> Readers = {
+    {"lzss", [](const Bytes &in) { return take([&](uint8_t **o, size_t *n) { return rsn_lzss_decompress(in.data(), in.size(), o, n); }); }},
+    {"huffman", [](const Bytes &in) { return take([&](uint8_t **o, size_t *n) { return rsn_huffman_decompress(in.data(), in.size(), o, n); }); }},
+};
+static const Codec &lookup(const std::map<std::string, Codec> &m, const std::string &name) {
+    auto it = m.find(name);
+    if (it == m.end()) throw std::runtime_error("unknown compression engine '" + name + "' (this build carries: lzss, huffman)");
+    return it->second;
+}
+// engine.go:443-452
+static Bytes compress(Bytes content, const std::vector<std::string> &algorithms) {
+    for (auto &a : algorithms) content = lookup(Writers, a)(content);
+    return content;
+}
+// engine.go:454-479 (reverse order)
+static Bytes decompress(Bytes content, const std::vector<std::string> &algorithms) {
+    for (size_t i = algorithms.size(); i-- > 0;) content = lookup(Readers, algorithms[i])(content);
+    return content;
+}
+static double entropy(const Bytes &sym, size_t total) {   // goent Entropy(p, math.Log), engine.go:410,423
+    size_t cnt[256] = {0};
+    for (uint8_t c : sym) cnt[c]++;
+    double h = 0;
+    for (size_t c : cnt) if (c) { const double p = (double)c / (double)total; h -= p * std::log(p); }
+    return h;
+}
+struct Result { std::string engine, timeTaken; float ratio; float actualEntropy; double entropy; bool lossless, failed; };
+// engine.go:357-441
+static Result BenchmarkFile(const std::vector<std::string> &algorithms, const std::string &path) {
+    std::string name;
+    for (size_t i = 0; i < algorithms.size(); i++) name += (i ? "," : "") + algorithms[i];
+    const Bytes data = read_file(path);
+    const auto t0 = std::chrono::steady_clock::now();
+    const Bytes c = compress(data, algorithms);
+    const Bytes d = decompress(c, algorithms);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    char tt[32]; snprintf(tt, sizeof tt, "%.2fms", ms);
+    return {name, tt, (float)c.size() / (float)data.size() * 100.f, (float)entropy(d, c.size()), entropy(data, data.size()), d == data, false};
+}
+}  // namespace engine
+
+static std::vector<std::string> split(const std::string &s, char sep) {
+    std::vector<std::string> out; std::string cur;
+    for (char ch : s) { if (ch == sep) { out.push_back(cur); cur.clear(); } else if (ch != ' ') cur += ch; }
+    out.push_back(cur);
+    return out;
+}
+// cmd/cli.go:203-231
+static std::vector<std::vector<std::string>> parseAlgorithms(const std::string &s) {
+    std::vector<std::vector<std::string>> algs; std::vector<std::string> layer; std::string buf; bool in = false;
+    for (char ch : s) {
+        if (ch == ',') { if (in && !buf.empty()) layer.push_back(buf); else if (!buf.empty()) algs.push_back({buf}); buf.clear(); }
+        else if (ch == '[') in = true;
+        else if (ch == ']') { layer.push_back(buf); buf.clear(); in = false; algs.push_back(layer); layer.clear(); }
+        else buf += ch;
+    }
+    if (!buf.empty()) algs.push_back({buf});
+    return algs;
+}
+
+int main(int argc, char **argv) {
+    std::string app = argv[0], cmd, file, algorithm, out, outext; bool has_delete = false, del = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&](const char *k) -> const char * { const size_t n = strlen(k); if (a.compare(0, n, k) == 0 && a.size() > n && a[n] == '=') return argv[i] + n + 1; return nullptr; };
+        if (a == "-compress" || a == "-decompress" || a == "-benchmark" || a == "-help") cmd = a.substr(1);
+        else if (const char *v = val("-algorithm")) algorithm = v;
+        else if (const char *v = val("-out")) out = v;
+        else if (const char *v = val("-outext")) outext = v;
+        else if (a == "-delete") { has_delete = true; del = true; }
+        else if (const char *v = val("-delete")) { has_delete = true; del = strcmp(v, "false") != 0; }
+        else if (a[0] != '-' && file.empty()) file = a;
+    }
+    if (cmd.empty()) cmd = app.size() >= 5 && app.compare(app.size() - 5, 5, "grape") == 0 ? "decompress" : "compress";   // cli.go:54-58
+    if (cmd == "help" || file.empty()) {
+        fprintf(stderr, "Usage: %s -compress|-decompress|-benchmark <file[,file]> [-algorithm=lzss,huffman] [-out=F] [-outext=E] [-delete]\n", argv[0]);
+        return cmd == "help" ? 0 : 1;
+    }
+    try {
+        const auto files = split(file, ',');
+        if (cmd == "compress") {
+            if (algorithm.empty()) algorithm = "lzss,huffman";   // reference default "lzss,arithmetic" (cli.go:99); arithmetic is not on this path
+            const auto algs = split(algorithm, ',');
+            for (auto &f : files) {
+                const std::string o = files.size() == 1 ? (out.empty() ? f + ".rsn" : out) : f + "." + (outext.empty() ? "rsn" : outext);   // cli.go:108-112
+                const Bytes data = read_file(f);
+                printf("Compressing...\n");
+                const Bytes c = engine::compress(data, algs);
+                write_file(o, c);
+                printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", data.size(), c.size(), (float)c.size() / (float)data.size() * 100.f);   // engine.go:166-169
+            }
+            if (has_delete && del) for (auto &f : files) remove(f.c_str());
+        } else if (cmd == "decompress") {
+            if (algorithm.empty()) algorithm = "lzss,huffman";
+            const auto algs = split(algorithm, ',');
+            for (auto &f : files) {
+                std::string o = f.substr(0, f.find_last_of('.'));                                   // cli.go:141-143
+                if (files.size() == 1 && !out.empty()) o = out;
+                if (files.size() > 1 && !outext.empty()) o = f + "." + outext;
+                printf("Decompressing...\n");
+                write_file(o, engine::decompress(read_file(f), algs));
+            }
+            if (!has_delete || del) for (auto &f : files) remove(f.c_str());                       // -delete defaults to true (cli.go:150)
+        } else {
+            if (algorithm.empty()) algorithm = "lzss,huffman,[lzss,huffman]";
+            for (auto &f : files) {
+                printf("%-24s %-12s %10s %9s %9s %s\n", "engine", "time", "ratio", "entropy", "actual", "lossless");
+                for (auto &algs : parseAlgorithms(algorithm)) {
+                    engine::Result r;
+                    try { r = engine::BenchmarkFile(algs, f); }
+                    catch (const std::exception &e) { std::string n; for (auto &a : algs) n += (n.empty() ? "" : ",") + a; r = {n, "failed", 0, 0, 0, false, true}; }   // engine.go:315-328
+                    printf("%-24s %-12s %9.2f%% %9.2f %9.2f %s\n", r.engine.c_str(), r.timeTaken.c_str(), r.ratio, r.entropy, r.actualEntropy, r.failed ? "DNF" : r.lossless ? "true" : "false");
+                }
+            }
+        }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "panic: %s\n", e.what());
+        return 2;
+    }
+    return 0;
+}

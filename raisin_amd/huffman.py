@@ -83,6 +83,43 @@ def table(data):
     return [(int(runes[i]), int(freqs[i]), int(codes[i]), int(lens[i])) for i in range(a)]
 
 
+def plan(counts):
+    """Host-only: {rune: count} -> ([(rune, code, len)] in printCodes order, header bytes).
+    Runs the library's Go-exact tree builder without touching a device."""
+    import ctypes
+
+    import numpy as np
+    L = _lib.lib()
+    items = sorted(counts.items())
+    runes = np.array([r for r, _ in items], dtype=np.uint32)
+    cnts = np.array([c for _, c in items], dtype=np.uint64)
+    n = len(items)
+    o_r = np.zeros(max(n, 1), dtype=np.uint32)
+    o_c = np.zeros(max(n, 1), dtype=np.uint64)
+    o_l = np.zeros(max(n, 1), dtype=np.uint8)
+    hdr = np.zeros(32 * max(n, 1), dtype=np.uint8)
+    hl = ctypes.c_size_t(0)
+    a = L.rsn_huffman_plan(runes.ctypes.data, cnts.ctypes.data, n, o_r.ctypes.data, o_c.ctypes.data, o_l.ctypes.data,
+                           hdr.ctypes.data, hdr.size, ctypes.byref(hl))
+    if a < 0:
+        _lib.check(int(a))
+    return [(int(o_r[i]), int(o_c[i]), int(o_l[i])) for i in range(a)], bytes(hdr[:hl.value])
+
+
+def parse_header(header):
+    """Host-only: decodeTree's header scan (huffman.go:196-227) -> [(rune, count)] ascending."""
+    import numpy as np
+    L = _lib.lib()
+    header = bytes(header)
+    cap = max(len(header), 1)
+    runes = np.zeros(cap, dtype=np.uint32)
+    cnts = np.zeros(cap, dtype=np.uint64)
+    a = L.rsn_huffman_parse_header(header, len(header), runes.ctypes.data, cnts.ctypes.data, cap)
+    if a < 0:
+        _lib.check(int(a))
+    return [(int(runes[i]), int(cnts[i])) for i in range(a)]
+
+
 # ---- device-resident form (torch tensors as plain device memory) -----------
 from ._lib import own_stream as _own_stream  # noqa: E402
 

@@ -1,0 +1,108 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/rsn.h declares,
+fails loudly without a device, and its HOST logic (Go-exact tree, header) matches the oracle."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from raisin_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "rsn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rsn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = built.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(built.SYMBOLS)
+
+
+def test_no_cpu_fallback(built):
+    """Without a HIP device every codec entry point must fail loudly (never compute on the CPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from raisin_amd import RsnError, huffman, lz
+    for fn in (lambda: huffman.Compress(b"abc"), lambda: huffman.Decompress(b"1|a\\\n\x00"),
+               lambda: lz.CompressAsync(b"abc"), lambda: lz.Decompress(b"abc")):
+        with pytest.raises(RsnError) as e:
+            fn()
+        assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raisin_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in txt.replace("rsn_oracle", "oracle") or f == "__init__.py" and False, (dirpath, f)
+
+
+def _counts(data, oracle):
+    runes = oracle.utf8_runes(data)
+    vals, cnts = np.unique(runes, return_counts=True)
+    return {int(v): int(c) for v, c in zip(vals, cnts)}
+
+
+def test_host_tree_and_header_match_oracle(built, oracle, samiam):
+    from raisin_amd import huffman
+    rng = random.Random(12)
+    cases = [samiam, b"Hello world!\n", b"ab", b"a\nb\\", b"AB\\\\A", "héllo ✓ 𝄞\n".encode() * 7,
+             bytes(rng.randrange(256) for _ in range(20000)),
+             bytes(rng.choice(b"aaaaabbbc") for _ in range(5000)),
+             bytes(rng.randrange(128) for _ in range(100000))]
+    for data in cases:
+        table, header = huffman.plan(_counts(data, oracle))
+        want = oracle.huffman_table(data)
+        assert table == [(r, c, l) for r, f, c, l in want]
+        ref = oracle.huffman_compress(data)
+        assert header == ref[:ref.index(b"\\\n")]
+        assert huffman.parse_header(header) == sorted(_counts(data, oracle).items())
+
+
+def test_heap_tie_breaks_on_equal_frequencies(built, oracle):
+    """All-equal counts exercise nothing but Go's container/heap sift order."""
+    from raisin_amd import huffman
+    for k in (2, 3, 5, 6, 7, 12, 33, 100, 128):
+        data = bytes(range(k)) * 3
+        table, _ = huffman.plan({i: 3 for i in range(k)})
+        assert table == [(r, c, l) for r, f, c, l in oracle.huffman_table(data)]
+
+
+def test_header_parse_quirks(built):
+    from raisin_amd import RsnError, huffman
+    assert huffman.parse_header(b"3|\\n5||7|9") == [(10, 3), (0x39, 7), (0x7C, 5)]     # '\\n' escape, '|' and digit symbols
+    assert huffman.parse_header("2|é1|x".encode()) == [(ord("x"), 1), (ord("é"), 2)]  # continuation bytes are skipped (huffman.go:222)
+    assert huffman.parse_header(b"|a") == [(ord("a"), 0)]                             # Atoi("") == 0 (huffman.go:207)
+    assert huffman.parse_header(b"1|a5|a") == [(ord("a"), 5)]                         # later entry overwrites
+    for bad in (b"3|", b"3|\\"):                                                       # index out of range (huffman.go:210)
+        with pytest.raises(RsnError):
+            huffman.parse_header(bad)
+    with pytest.raises(RsnError):
+        huffman.plan({})                                                               # heap.Pop on an empty heap (huffman.go:102)
+
+
+def test_engine_mirror_host_side(built):
+    from raisin_amd import engine, lz
+    assert engine.ByteCountSI(1000) == "1.0 kB" and engine.ByteCountSI(10) == "10 B"   # engine/util_test.go:7-17
+    assert engine.ByteCountSI(1234567) == "1.2 MB"
+    assert engine.parseAlgorithms("lzss,arithmetic,huffman,[lzss,arithmetic],gzip") == [
+        ["lzss"], ["arithmetic"], ["huffman"], ["lzss", "arithmetic"], ["gzip"]]       # cmd/cli.go:169,203-231
+    assert set(engine.Writers) == set(engine.Readers) == {"lzss", "huffman"}
+    with pytest.raises(KeyError):
+        engine.CompressedFile(CompressionEngine="dmc").Write(b"x")
+    with pytest.raises(ValueError):
+        lz.NewWriterLevel(None, -1)                                                     # lzss.go:43-45
+    assert lz.DefaultWindowSize == 4096

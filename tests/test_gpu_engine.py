@@ -1,0 +1,50 @@
+"""GPU: the engine mirror (layering, benchmark semantics) and the C++ host CLI over librsn."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_layering_and_benchmark_semantics(tmp_path, oracle, samiam):
+    from raisin_amd import engine
+    p = tmp_path / "compression_test.txt"
+    p.write_bytes(samiam)                                   # cmd/cli_test.go:17-19
+    for algs in (["huffman"], ["lzss"], ["lzss", "huffman"], ["huffman", "lzss"]):
+        r = engine.BenchmarkFile(algs, str(p))
+        assert r.Lossless and not r.Failed                  # cli_test.go:33-40
+        comp = engine.compress(samiam, algs)
+        want = samiam
+        for a in algs:
+            want = oracle.huffman_compress(want) if a == "huffman" else oracle.lzss_compress(want)
+        assert comp == want
+        assert abs(r.Ratio - len(want) / len(samiam) * 100) < 1e-3
+        assert engine.decompress(comp, algs) == samiam
+    out = tmp_path / "x.rsn"
+    engine.CompressFile(["lzss", "huffman"], str(p), str(out))
+    assert engine.DecompressFile(["lzss", "huffman"], str(out), str(tmp_path / "y")) == samiam
+    # binary input through huffman is lossy in the reference too (huffman.go:309): reported, not hidden
+    b = tmp_path / "bin"
+    b.write_bytes(bytes(range(256)) * 40)
+    r = engine.BenchmarkFile(["huffman"], str(b))
+    assert r.Lossless is False and not r.Failed
+    r = engine.AsyncBenchmarkFile(["huffman"], str(tmp_path / "empty"))  # missing file -> failed row (engine.go:315-328)
+    assert r.Failed
+
+
+def test_cpp_host_cli(tmp_path, oracle, samiam):
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    src = tmp_path / "sam.txt"
+    src.write_bytes(samiam)
+    subprocess.check_call([exe, "-compress", str(src), "-algorithm=lzss,huffman"])
+    rsn = tmp_path / "sam.txt.rsn"                          # cli.go:109 default output name
+    assert rsn.read_bytes() == oracle.huffman_compress(oracle.lzss_compress(samiam))
+    src.unlink()
+    subprocess.check_call([exe, "-decompress", str(rsn), "-algorithm=lzss,huffman"])
+    assert src.read_bytes() == samiam and not rsn.exists()  # -delete defaults to true (cli.go:150)
+    out = subprocess.check_output([exe, "-benchmark", str(src), "-algorithm=huffman,[lzss,huffman],dmc"]).decode()
+    assert out.count("true") == 2 and "DNF" in out
