@@ -54,7 +54,7 @@ def load_traffic():
     """HBM bytes per launch from the committed PMC profile, if present (scripts/profile.sh)."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             best = json.load(open(p))
         except Exception:
@@ -153,7 +153,7 @@ def main():
         cnt = {k: v[0] / K for k, v in prof.items()}         # launches per step
         C = comp_n
         alg = {  # ALGORITHMIC HBM bytes per launch (DESIGN.md "kernels")
-            "huff_byte_hist": n, "huff_emit": n + C, "huff_dec_sync": C, "huff_dec_emit": C + n,
+            "huff_byte_hist": n, "huff_emit": n + C, "huff_dec_sync": C, "huff_dec_emit": C + n, "huff_dec_flat": C + n,
         }
         kernels = {}
         for k, ms in per.items():

@@ -13,12 +13,16 @@
 //                    again.  Iterated inside the block (LDS) and across blocks
 //                    (relaunch) until nothing changes: entry[g] == exit[g-1]
 //                    for every g with entry[0] exact, i.e. the true parse.
-//                    The first guess assumes fixed-length codes of the minimum
-//                    length, which is exact for flat alphabets (config 2a).
 //   D2  k_scan_u64   output offsets from the per-block byte counts
-//   D3  k_dec_emit   decode again from the now-exact entries, write the bytes.
-// Code lookup: a 2^K-entry table in LDS (K = min(maxlen,12)); longer codes finish
-// with a bit-by-bit walk of the tree's child array (global, L2 resident).
+//   D3  k_dec_emit   decode again from the now-exact entries; bytes are staged in
+//                    LDS and leave as 16-byte coalesced stores.
+//   F   k_dec_flat   when every code has the same length L (flat alphabets: the
+//                    tree is perfectly balanced) the payload is an array of L-bit
+//                    fields: no synchronisation is needed, each lane unpacks 16
+//                    fields and stores 16 bytes.
+// Code lookup: a 2^K-entry table in LDS (K = min(maxlen,12)), replicated so that
+// the lanes of a wavefront hit different banks; longer codes finish with a
+// bit-by-bit walk of the tree's child array (global, L2 resident).
 #include "codecs.h"
 
 namespace rsn {
@@ -29,8 +33,11 @@ constexpr int DB = 256;             // lanes per block
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits)
 constexpr int SBITS = SW * 32;
 constexpr int DATA_WORDS = DB * SW + 8;   // + overrun for a code that starts inside and ends outside
-constexpr int LUT_BITS_MAX = 12;
+constexpr int LUT_BITS_MAX = 11;
+constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
+constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
 constexpr uint32_t BAD_REL = 0xFFFF;
+constexpr uint32_t BAD_POS = 0xFFFFFFFFu;
 
 struct DecArgs {
     const uint8_t *base;        // 16-byte aligned pointer at or before the first payload byte
@@ -38,9 +45,9 @@ struct DecArgs {
     unsigned long long p0;      // bit position (from base) of the first code bit
     unsigned long long end;     // bit position one past the last payload bit
     uint32_t n_sub;             // number of subsequences
-    const uint32_t *lut; int K;
+    const uint32_t *lut; int K; int rep_log2;   // (1<<K) entries, each replicated 1<<rep_log2 times in LDS
     const int32_t *child;       // 2 per internal node: >=0 internal index, <0 -(rune+1)
-    uint32_t min_len; int ascii;
+    uint32_t min_len;
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
     int *changed; int pass;
@@ -49,7 +56,12 @@ struct DecArgs {
 
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return j + (j >> 5); }
 
-__device__ __forceinline__ void stage(const DecArgs &a, uint32_t blk, uint32_t *s_data, const uint32_t *__restrict__ lut_g, uint32_t *s_lut) {
+__device__ __forceinline__ void stage_lut(const DecArgs &a, uint32_t *s_lut) {
+    const int total = (1 << a.K) << a.rep_log2;
+    for (int i = threadIdx.x; i < total; i += DB) s_lut[i] = a.lut[i >> a.rep_log2];
+}
+
+__device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint32_t *s_data) {
     const size_t w0 = (size_t)blk * DB * SW;
     for (int i = threadIdx.x; i < DATA_WORDS; i += DB) {
         const size_t off = (w0 + i) * 4;
@@ -58,136 +70,178 @@ __device__ __forceinline__ void stage(const DecArgs &a, uint32_t blk, uint32_t *
         else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
         s_data[swz(i)] = v;
     }
-    for (int i = threadIdx.x; i < (1 << a.K); i += DB) s_lut[i] = lut_g[i];
 }
 
 __device__ __forceinline__ int dev_utf8_len(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
 
-// Decodes one codeword at block-relative bit `pos`; returns its length, rune in *rune.
-__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t pos, uint32_t *rune) {
-    const uint32_t wi = pos >> 5;
-    const unsigned long long win = (((unsigned long long)s_data[swz(wi)] << 32) | s_data[swz(wi + 1)]) << (pos & 31);
-    const uint32_t ent = s_lut[(uint32_t)(win >> (64 - a.K))];
-    if (!(ent & 0x80000000u)) { *rune = ent & 0x1FFFFFu; return ent >> 24; }
+// Sequential bit reader over the block's staged big-endian words.  (hi:lo) holds the
+// stream from `pos`; words below index wi are loaded.  A word is appended whenever
+// 32 or fewer valid bits remain, so at least 33 are valid after every skip().
+struct BitReader {
+    const uint32_t *s; uint32_t hi, lo, pos, wi;
+    __device__ __forceinline__ void init(const uint32_t *s_data, uint32_t p) {
+        s = s_data; pos = p;
+        const uint32_t w = p >> 5;
+        const unsigned long long v = (((unsigned long long)s[swz(w)] << 32) | s[swz(w + 1)]) << (p & 31);
+        hi = (uint32_t)(v >> 32); lo = (uint32_t)v; wi = w + 2;
+    }
+    __device__ __forceinline__ void advance(uint32_t l) {   // 1 <= l <= 31, no refill
+        hi = __builtin_amdgcn_alignbit(hi, lo, 32 - l);
+        lo <<= l;
+        pos += l;
+    }
+    __device__ __forceinline__ void refill() {
+        const uint32_t have = 32 * wi - pos;
+        if (have <= 32) {
+            const unsigned long long t = ((unsigned long long)s[swz(wi)] << 32) >> have;
+            hi |= (uint32_t)(t >> 32); lo = (uint32_t)t; wi++;
+        }
+    }
+    __device__ __forceinline__ uint32_t bit_at(uint32_t q) const { return (s[swz(q >> 5)] >> (31 - (q & 31))) & 1; }
+};
+
+// One codeword at the reader's position (>= K valid bits): returns the table entry's rune,
+// advances the reader WITHOUT refilling.  Long codes (flagged entries) walk the tree.
+template <bool SHORT>
+__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, BitReader &br, const uint32_t *s_lut, uint32_t lane_r) {
+    const uint32_t ent = s_lut[((br.hi >> (32 - a.K)) << a.rep_log2) | lane_r];
+    if (SHORT || !(ent & 0x80000000u)) {
+        br.advance(ent >> 24);
+        return ent & 0x1FFFFFu;
+    }
     int32_t node = (int32_t)(ent & 0x7FFFFFFFu);
-    uint32_t l = a.K;
+    uint32_t l = a.K, rune = 0;
     for (;;) {
-        const uint32_t q = pos + l;
-        const uint32_t bit = (s_data[swz(q >> 5)] >> (31 - (q & 31))) & 1;
-        const int32_t nxt = a.child[2 * node + bit];
+        const int32_t nxt = a.child[2 * node + br.bit_at(br.pos + l)];
         l++;
-        if (nxt < 0) { *rune = (uint32_t)(-(nxt + 1)); return l; }
-        if (l >= 64) { *rune = 0; return 65; }   // cannot happen for a tree accepted by the host (codes <= 64 bits)
+        if (nxt < 0) { rune = (uint32_t)(-(nxt + 1)); break; }
+        if (l >= 64) { l = 65; break; }   // cannot happen for a tree accepted by the host (codes <= 64 bits)
         node = nxt;
     }
+    br.init(br.s, br.pos + l);
+    return rune;
 }
 
-// Walk from block-relative bit `pos` to the first code boundary >= lim.
-__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t pos, uint32_t lim,
-                                     uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
+// Walk from block-relative bit `pos` to the first code boundary >= lim.  Two codewords are
+// decoded per refill (2*K <= 22 < 33 valid bits).  A code that runs past the end of the
+// payload can only be the last one of the walk, so that check happens once, after the loop.
+template <bool ASCII, bool SHORT>
+__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t pos,
+                                     uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
     uint32_t nb = 0;
-    bool bad = false;
-    while (pos < lim) {
-        uint32_t rune;
-        const uint32_t l = decode_one(a, s_data, s_lut, pos, &rune);
-        if (pos + l > end_rel) { bad = true; break; }   // code would run past the end of the payload
-        pos += l;
-        nb += a.ascii ? 1 : dev_utf8_len(rune);
+    BitReader br;
+    br.init(s_data, pos);
+    while (br.pos < lim) {
+        const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
+        nb += ASCII ? 1 : dev_utf8_len(r1);
+        if (br.pos < lim) {
+            const uint32_t r2 = decode_one<SHORT>(a, br, s_lut, lane_r);
+            nb += ASCII ? 1 : dev_utf8_len(r2);
+        }
+        br.refill();
     }
-    *exit_pos = bad ? 0xFFFFFFFFu : pos;
+    *exit_pos = br.pos > end_rel ? BAD_POS : br.pos;
     *nbytes = nb;
 }
 
-__global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a) {
+template <bool ASCII, bool SHORT>
+__global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
-    __shared__ uint32_t s_lut[1 << LUT_BITS_MAX];
+    __shared__ uint32_t s_lut[LUT_WORDS];
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
     const int tid = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
-    const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
-    const uint32_t g = blk * DB + tid;
-    const bool live = g < a.n_sub;
-    // block-relative positions (the block spans DB*SBITS bits; exits overshoot by < 64)
-    const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+    const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = tid * SBITS;
-    const uint32_t lim = min(my0 + SBITS, end_rel);
-
-    // entry of lane 0: the true start for block 0, else the predecessor block's published exit
-    if (tid == 0) {
-        int skip = 0;
-        if (a.pass > 0) {
-            unsigned long long e = a.p0;
-            if (blk > 0) {
-                const uint32_t xr = a.exit_rel[g - 1];
-                e = xr == BAD_REL ? ~0ull : min(blk_bit0, a.end) + xr;
+    stage_lut(a, s_lut);   // once per (persistent) block
+    for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
+        const uint32_t g = blk * DB + tid;
+        const bool live = g < a.n_sub;
+        // block-relative positions (the block spans DB*SBITS bits; exits overshoot by < 64)
+        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+        const uint32_t lim = min(my0 + SBITS, end_rel);
+        __syncthreads();   // previous iteration is done with s_skip / s_data / s_part
+        // lane 0's entry: the true start for block 0, else the predecessor block's published exit
+        if (tid == 0) {
+            int skip = 0;
+            if (a.pass > 0) {
+                unsigned long long e = a.p0;
+                if (blk > 0) {
+                    const uint32_t xr = a.exit_rel[g - 1];
+                    e = xr == BAD_REL ? ~0ull : blk_bit0 + xr;
+                }
+                const uint32_t er = a.entry_rel[g];
+                skip = er == BAD_REL ? e == ~0ull : e == blk_bit0 + er;
             }
-            const unsigned long long used = blk_bit0 + a.entry_rel[g];
-            skip = (e == used) || (e == ~0ull && a.entry_rel[g] == BAD_REL);
+            s_skip = skip;
         }
-        s_skip = skip;
-    }
-    __syncthreads();
-    if (s_skip) return;
-    stage(a, blk, s_data, a.lut, s_lut);
+        __syncthreads();
+        if (s_skip) continue;
+        stage_data(a, blk, s_data);
 
-    uint32_t e;   // block-relative entry; 0xFFFFFFFF = predecessor ran off the end
-    if (!live) e = 0xFFFFFFFFu;
-    else if (g == 0) e = (uint32_t)a.p0;
-    else if (a.pass == 0 || tid > 0) {
-        // first guess: codes of the minimum length, phase-locked to p0
-        const unsigned long long s0 = blk_bit0 + my0;
-        unsigned long long q = a.p0;
-        if (s0 > a.p0) q = a.p0 + (s0 - a.p0 + a.min_len - 1) / a.min_len * a.min_len;
-        e = (uint32_t)(q - blk_bit0);
-    } else {
-        const uint32_t xr = a.exit_rel[g - 1];
-        e = xr == BAD_REL ? 0xFFFFFFFFu : (uint32_t)(min(blk_bit0, a.end) - blk_bit0) + xr;
-    }
-    bool have = false;
-    uint32_t x = 0, nb = 0;
-    if (live && a.pass > 0 && tid > 0) {
-        // results of the previous pass stay valid while the entry they were computed from stands
-        const uint32_t er = a.entry_rel[g];
-        const uint32_t xr = a.exit_rel[g];
-        e = er == BAD_REL ? 0xFFFFFFFFu : my0 + er;
-        x = xr == BAD_REL ? 0xFFFFFFFFu : lim + xr;
-        nb = a.nbyte[g];
-        have = true;
-    }
-    __syncthreads();
-    for (int round = 0; round <= DB; round++) {
-        if (live && !have) {
-            if (e == 0xFFFFFFFFu) { x = 0xFFFFFFFFu; nb = 0; }
-            else walk(a, s_data, s_lut, e, lim, end_rel, &x, &nb);
+        uint32_t e;   // block-relative entry; BAD_POS = the predecessor ran off the end
+        if (!live) e = BAD_POS;
+        else if (g == 0) e = (uint32_t)a.p0;
+        else if (a.pass == 0 || tid > 0) {
+            // first guess: codes of the minimum length, phase-locked to p0 (exact for flat codes)
+            const unsigned long long s0 = blk_bit0 + my0;
+            unsigned long long q = a.p0;
+            if (s0 > a.p0) {
+                const unsigned long long d = s0 - a.p0 + a.min_len - 1;
+                q = a.p0 + (d - d % a.min_len);
+            }
+            e = (uint32_t)(q - blk_bit0);
+        } else {
+            const uint32_t xr = a.exit_rel[g - 1];
+            e = xr == BAD_REL ? BAD_POS : xr;
+        }
+        bool have = false;
+        uint32_t x = 0, nb = 0;
+        if (live && a.pass > 0 && tid > 0) {
+            // results of the previous pass stay valid while the entry they were computed from stands
+            const uint32_t er = a.entry_rel[g];
+            const uint32_t xr = a.exit_rel[g];
+            e = er == BAD_REL ? BAD_POS : my0 + er;
+            x = xr == BAD_REL ? BAD_POS : lim + xr;
+            nb = a.nbyte[g];
             have = true;
         }
-        s_exit[tid] = x;
         __syncthreads();
-        bool changed = false;
-        if (live && tid > 0) {
-            const uint32_t en = s_exit[tid - 1];
-            if (en != e) { e = en; have = false; changed = true; }
+        for (int round = 0; round <= DB; round++) {
+            if (live && !have) {
+                if (e == BAD_POS) { x = BAD_POS; nb = 0; }
+                else walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, e, lim, end_rel, &x, &nb);
+                have = true;
+            }
+            s_exit[tid] = x;
+            __syncthreads();
+            bool changed = false;
+            if (live && tid > 0) {
+                const uint32_t en = s_exit[tid - 1];
+                if (en != e) { e = en; have = false; changed = true; }
+            }
+            if (!__syncthreads_or(changed)) break;
         }
-        if (!__syncthreads_or(changed)) break;
-    }
-    if (live) {
-        a.entry_rel[g] = e == 0xFFFFFFFFu ? BAD_REL : (uint16_t)(e - my0);
-        a.exit_rel[g] = x == 0xFFFFFFFFu ? BAD_REL : (uint16_t)(x - lim);
-        a.nbyte[g] = (uint16_t)nb;
-    }
-    unsigned long long s = live ? nb : 0;
-    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
-    if ((tid & 63) == 0) s_part[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) {
-        a.blk_bytes[blk] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (a.pass > 0) *a.changed = 1;
+        if (live) {
+            a.entry_rel[g] = e == BAD_POS ? BAD_REL : (uint16_t)(e - my0);
+            a.exit_rel[g] = x == BAD_POS ? BAD_REL : (uint16_t)(x - lim);
+            a.nbyte[g] = (uint16_t)nb;
+        }
+        unsigned long long sum = live ? nb : 0;
+        for (int d = 32; d; d >>= 1) sum += __shfl_down(sum, d);
+        if ((tid & 63) == 0) s_part[tid >> 6] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            a.blk_bytes[blk] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            if (a.pass > 0) *a.changed = 1;
+        }
     }
 }
 
-// Per-lane byte sink: aligned 8-byte stores, byte stores only for the partial first/last word.
+// Per-lane byte sink for the direct (unstaged) path: aligned 8-byte stores, byte stores
+// only for the partial first/last word.
 struct Sink {
     uint8_t *wordp; unsigned long long acc; uint32_t cnt, lo;
     __device__ __forceinline__ void start(uint8_t *p) { lo = (uint32_t)((uintptr_t)p & 7); wordp = p - lo; cnt = lo; acc = 0; }
@@ -202,42 +256,145 @@ struct Sink {
     __device__ __forceinline__ void finish() { for (uint32_t k = lo; k < cnt; k++) wordp[k] = (uint8_t)(acc >> (8 * k)); }
 };
 
-__global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a) {
+template <class Put>
+__device__ __forceinline__ void put_rune(uint32_t rune, Put put) {   // string(rune) (huffman.go:138)
+    if (rune < 0x80) put(rune);
+    else if (rune < 0x800) { put(0xC0 | (rune >> 6)); put(0x80 | (rune & 0x3F)); }
+    else if (rune < 0x10000) { put(0xE0 | (rune >> 12)); put(0x80 | ((rune >> 6) & 0x3F)); put(0x80 | (rune & 0x3F)); }
+    else { put(0xF0 | (rune >> 18)); put(0x80 | ((rune >> 12) & 0x3F)); put(0x80 | ((rune >> 6) & 0x3F)); put(0x80 | (rune & 0x3F)); }
+}
+
+// Decode loop of D3: entries are exact, so the walk never runs off the payload.
+template <bool ASCII, bool SHORT, class Put>
+__device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r,
+                                          uint32_t pos, uint32_t lim, Put put) {
+    BitReader br;
+    br.init(s_data, pos);
+    while (br.pos < lim) {
+        const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
+        if (ASCII) put(r1); else put_rune(r1, put);
+        if (br.pos < lim) {
+            const uint32_t r2 = decode_one<SHORT>(a, br, s_lut, lane_r);
+            if (ASCII) put(r2); else put_rune(r2, put);
+        }
+        br.refill();
+    }
+}
+
+template <bool ASCII, bool SHORT>
+__global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
-    __shared__ uint32_t s_lut[1 << LUT_BITS_MAX];
+    __shared__ uint32_t s_lut[LUT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t blk = blockIdx.x;
-    const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
-    const uint32_t g = blk * DB + tid;
-    const bool live = g < a.n_sub;
-    const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+    const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = tid * SBITS;
-    const uint32_t lim = min(my0 + SBITS, end_rel);
-    stage(a, blk, s_data, a.lut, s_lut);
-    const uint32_t nb = live ? a.nbyte[g] : 0;
-    const uint32_t er = live ? a.entry_rel[g] : BAD_REL;
-    uint32_t incl = nb;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    uint32_t wpre = 0;
-    for (int k = 0; k < wv; k++) wpre += s_wsum[k];
-    if (!live || er == BAD_REL || nb == 0) return;
-    Sink sink;
-    sink.start(a.out + a.blk_off[blk] + wpre + incl - nb);
-    uint32_t pos = my0 + er;
-    while (pos < lim) {
-        uint32_t rune;
-        const uint32_t l = decode_one(a, s_data, s_lut, pos, &rune);
-        if (pos + l > end_rel) break;
-        pos += l;
-        if (a.ascii || rune < 0x80) sink.put(rune);
-        else if (rune < 0x800) { sink.put(0xC0 | (rune >> 6)); sink.put(0x80 | (rune & 0x3F)); }
-        else if (rune < 0x10000) { sink.put(0xE0 | (rune >> 12)); sink.put(0x80 | ((rune >> 6) & 0x3F)); sink.put(0x80 | (rune & 0x3F)); }
-        else { sink.put(0xF0 | (rune >> 18)); sink.put(0x80 | ((rune >> 12) & 0x3F)); sink.put(0x80 | ((rune >> 6) & 0x3F)); sink.put(0x80 | (rune & 0x3F)); }
+    stage_lut(a, s_lut);
+    for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
+        const uint32_t g = blk * DB + tid;
+        const bool live = g < a.n_sub;
+        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+        const uint32_t lim = min(my0 + SBITS, end_rel);
+        __syncthreads();   // previous iteration has drained s_out / s_data / s_wsum
+        stage_data(a, blk, s_data);
+        const uint32_t nb = live ? a.nbyte[g] : 0;
+        const uint32_t er = live ? a.entry_rel[g] : BAD_REL;
+        uint32_t incl = nb;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t wpre = 0, total = 0;
+        for (int k = 0; k < DB / 64; k++) { if (k < wv) wpre += s_wsum[k]; total += s_wsum[k]; }
+        const uint32_t my_off = wpre + incl - nb;                 // byte offset of this lane inside the block's output
+        uint8_t *dst = a.out + a.blk_off[blk];
+        const uint32_t al = (uint32_t)((uintptr_t)dst & 15);      // LDS image is shifted so that 16-byte units line up with global memory
+        const bool staged = total + al <= OUT_STAGE;              // uniform per block
+        if (live && er != BAD_REL && nb != 0) {
+            if (staged) {
+                uint8_t *o = s_out + al + my_off;
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
+            } else {
+                Sink sink;
+                sink.start(dst + my_off);
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
+                sink.finish();
+            }
+        }
+        if (!staged) continue;
+        __syncthreads();
+        const uint32_t span = al + total;                          // bytes [al, span) of s_out are this block's output
+        uint8_t *gbase = dst - al;                                 // 16-byte aligned
+        for (uint32_t u = tid; u * 16 < span; u += DB) {
+            const uint32_t b0 = u * 16;
+            if (b0 >= al && b0 + 16 <= span) *reinterpret_cast<uint4 *>(gbase + b0) = *reinterpret_cast<const uint4 *>(s_out + b0);
+            else for (uint32_t k = max(b0, al); k < min(b0 + 16, span); k++) gbase[k] = s_out[k];
+        }
     }
-    sink.finish();
+}
+
+// ---------------------------------------------------------------- F: flat codes
+// Every code is L bits: symbol i sits at bits [p0 + i*L, +L).  A lane takes 32
+// symbols = exactly L words (after a block-uniform funnel shift by p0 % 32), so
+// every field position inside those words is a compile-time constant.
+struct FlatArgs {
+    const uint8_t *base; size_t nbytes;
+    unsigned long long p0;       // bit position of the first field
+    unsigned long long n_sym;
+    const uint8_t *lut;          // 2^L bytes: field value -> symbol
+    uint8_t *out;
+};
+constexpr int FLAT_LANE_SYMS = 32;
+constexpr int FLAT_SYMS = DB * FLAT_LANE_SYMS;                  // symbols per block
+
+template <int L>
+__global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
+    constexpr int WORDS = DB * L + 2;
+    constexpr int RL = (L <= 7) ? 5 : (12 - L);                 // LUT copies: 32 for small tables, total <= 4 KiB
+    __shared__ uint32_t s_data[WORDS + WORDS / 32 + 2];
+    __shared__ uint8_t s_lut[(1 << L) << RL];
+    const int tid = threadIdx.x;
+    const unsigned long long sym0 = (unsigned long long)blockIdx.x * FLAT_SYMS;
+    const unsigned long long bit0 = a.p0 + sym0 * L;            // FLAT_SYMS*L is a multiple of 32: bit0 % 32 == p0 % 32
+    const size_t w0 = (size_t)(bit0 >> 5);
+    const uint32_t o0 = (uint32_t)(bit0 & 31);
+    for (int i = tid; i < WORDS; i += DB) {
+        const size_t off = (w0 + i) * 4;
+        uint32_t v = 0;
+        if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
+        else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
+        s_data[swz(i)] = v;
+    }
+    for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = a.lut[i >> RL];
+    __syncthreads();
+    const unsigned long long s_first = sym0 + (unsigned long long)tid * FLAT_LANE_SYMS;
+    if (s_first >= a.n_sym) return;
+    const uint32_t lane_r = tid & ((1u << RL) - 1);
+    uint32_t w[L + 1], v[L];
+#pragma unroll
+    for (int j = 0; j <= L; j++) w[j] = s_data[swz(tid * L + j)];
+#pragma unroll
+    for (int j = 0; j < L; j++) v[j] = (uint32_t)((((unsigned long long)w[j] << 32) | w[j + 1]) >> (32 - o0));
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < FLAT_LANE_SYMS; k++) {
+        constexpr uint32_t mask = (1u << L) - 1;
+        const int bp = k * L, wi = bp >> 5, sh = bp & 31;
+        uint32_t f;
+        if (sh + L <= 32) f = (v[wi] >> (32 - sh - L)) & mask;
+        else f = (uint32_t)((((unsigned long long)v[wi] << 32) | v[wi + 1 < L ? wi + 1 : wi]) >> (64 - sh - L)) & mask;
+        const uint32_t sym = s_lut[(f << RL) | lane_r];
+        if ((k & 3) == 0) o[k >> 2] = sym; else o[k >> 2] |= sym << (8 * (k & 3));
+    }
+    uint8_t *dst = a.out + s_first;
+    if (s_first + FLAT_LANE_SYMS <= a.n_sym) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        const uint32_t cnt = (uint32_t)(a.n_sym - s_first);
+        for (uint32_t k = 0; k < cnt; k++) dst[k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    }
 }
 
 namespace {
@@ -271,6 +428,12 @@ void build_tables(const HuffTree &t, int K, std::vector<uint32_t> &lut, std::vec
             st.push_back({t.left[it.node], it.prefix << 1, it.depth + 1});
         }
     }
+}
+
+int rep_for(int K) {   // replicate small tables up to 32x (one copy per LDS bank) within LUT_WORDS
+    int r = 0;
+    while (r < 5 && ((1 << K) << (r + 1)) <= LUT_WORDS) r++;
+    return r;
 }
 
 }  // namespace
@@ -323,30 +486,58 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
     if (max == 0) return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
 
+    bool ascii = true;
+    for (uint32_t i = 0; i < tree.n_leaves; i++) if (tree.rune[i] >= 0x80) ascii = false;
+    const size_t pay = sep + 3;                           // first payload byte
+    const size_t A0 = pay & ~(size_t)15;
+    void *p; int rc;
+
+    // ---- F: every code has the same length -> fixed-width unpack
+    static const bool no_flat = getenv("RSN_NO_FLAT") != nullptr;
+    if (ascii && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat) {
+        const uint32_t L = codes.max_len;
+        if (max % L) return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
+        const unsigned long long n_sym = max / L;
+        *out_n = (size_t)n_sym;
+        if (!d_out || n_sym > out_cap) { *out_n = round_up((size_t)n_sym, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %llu bytes, buffer holds %zu", n_sym, out_cap); }
+        std::vector<uint8_t> lut8((size_t)1 << L);
+        for (uint32_t i = 0; i < tree.n_leaves; i++) lut8[codes.code[i]] = (uint8_t)tree.rune[i];
+        rc = dev_buf(c, 5, lut8.size(), &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, lut8.data(), lut8.size(), hipMemcpyHostToDevice, s));
+        FlatArgs fa{};
+        fa.base = d_in + A0; fa.nbytes = n - A0; fa.p0 = 8ull * (pay - A0) + diff; fa.n_sym = n_sym;
+        fa.lut = (const uint8_t *)p; fa.out = d_out;
+        const dim3 grid((uint32_t)ceil_div((size_t)n_sym, FLAT_SYMS));
+        switch (L) {
+#define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(DB), 0, s, fa); break;
+            RSN_FLAT_CASE(1) RSN_FLAT_CASE(2) RSN_FLAT_CASE(3) RSN_FLAT_CASE(4) RSN_FLAT_CASE(5) RSN_FLAT_CASE(6)
+            RSN_FLAT_CASE(7)   // ASCII alphabets hold at most 2^7 symbols
+#undef RSN_FLAT_CASE
+            default: return c.fail(RSN_ERR_LIMIT, "huffman: flat code length %u", L);
+        }
+        RSN_HIP(hipStreamSynchronize(s));
+        return RSN_OK;
+    }
+
     // ---- tables
     const int K = (int)std::min<unsigned>(codes.max_len, LUT_BITS_MAX);
+    const bool short_codes = codes.max_len <= (unsigned)LUT_BITS_MAX;
     std::vector<uint32_t> lut; std::vector<int32_t> child;
     build_tables(tree, K, lut, child);
-    void *p;
-    int rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4, &p); if (rc) return rc;
+    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4, &p); if (rc) return rc;
     uint32_t *d_lut = (uint32_t *)p;
     int32_t *d_child = (int32_t *)(d_lut + lut.size());
     RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
 
     DecArgs a{};
-    const size_t pay = sep + 3;                           // first payload byte
-    const size_t A0 = pay & ~(size_t)15;
     a.base = d_in + A0; a.nbytes = n - A0;
     a.p0 = 8ull * (pay - A0) + diff;
     a.end = 8ull * (n - A0);
     const unsigned long long n_sub64 = (a.end + SBITS - 1) / SBITS;
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
-    a.lut = d_lut; a.K = K; a.child = d_child; a.min_len = codes.min_len;
-    bool ascii = true;
-    for (uint32_t i = 0; i < tree.n_leaves; i++) if (tree.rune[i] >= 0x80) ascii = false;
-    a.ascii = ascii;
+    a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.min_len = codes.min_len;
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;
@@ -359,14 +550,22 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     volatile int *h_changed = (volatile int *)hp;
 
+    const uint32_t grid_p = std::min<uint32_t>(n_blk, 256u * 8u * 2u);   // persistent blocks: the LUT is staged once per block
+    auto launch_sync = [&]() -> int {
+        if (ascii && short_codes) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (ascii) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (short_codes) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<false, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else RSN_LAUNCH("huff_dec_sync", (k_dec_sync<false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        return RSN_OK;
+    };
     // ---- D1: iterate to the fixed point
     a.pass = 0;
-    RSN_LAUNCH("huff_dec_sync", k_dec_sync, dim3(n_blk), dim3(DB), 0, s, a);
+    rc = launch_sync(); if (rc) return rc;
     for (uint32_t pass = 1;; pass++) {
         if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
         a.pass = (int)pass;
         RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
-        RSN_LAUNCH("huff_dec_sync", k_dec_sync, dim3(n_blk), dim3(DB), 0, s, a);
+        rc = launch_sync(); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync((void *)h_changed, d_changed, 4, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (!*h_changed) break;
@@ -385,7 +584,10 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- D3
     a.blk_off = d_blk_off; a.out = d_out;
-    RSN_LAUNCH("huff_dec_emit", k_dec_emit, dim3(n_blk), dim3(DB), 0, s, a);
+    if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     RSN_HIP(hipStreamSynchronize(s));
     return RSN_OK;
 }

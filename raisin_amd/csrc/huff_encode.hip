@@ -204,23 +204,29 @@ __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------- K3: exclusive scan (single block)
+// 8 consecutive items per lane, 8192 per sweep.
 __global__ __launch_bounds__(1024) void k_scan_u64(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
                                                    uint32_t n, unsigned long long *__restrict__ total) {
+    constexpr int IT = 8;
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const unsigned long long x = i < n ? in[i] : 0;
-        unsigned long long s = x;
+    for (uint32_t base = 0; base < n; base += 1024 * IT) {
+        const uint32_t i0 = base + tid * IT;
+        unsigned long long x[IT], loc = 0;
+#pragma unroll
+        for (int k = 0; k < IT; k++) { x[k] = i0 + k < n ? in[i0 + k] : 0; loc += x[k]; }
+        unsigned long long s = loc;
         for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d); if (lane >= d) s += y; }
         if (lane == 63) wsum[wv] = s;
         __syncthreads();
         unsigned long long pre = carry_s;
         for (int k = 0; k < wv; k++) pre += wsum[k];
-        if (i < n) out[i] = pre + s - x;
+        unsigned long long run = pre + s - loc;
+#pragma unroll
+        for (int k = 0; k < IT; k++) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
         __syncthreads();
         if (tid == 1023) carry_s = pre + s;
         __syncthreads();

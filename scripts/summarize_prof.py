@@ -54,7 +54,8 @@ def main():
             a[1] += 1
         for k, (tot, cnt) in acc.items():
             res[k][key] = tot / cnt
-    names = {"k_byte_hist": "huff_byte_hist", "k_emit<0>": "huff_emit", "k_dec_sync": "huff_dec_sync", "k_dec_emit": "huff_dec_emit"}
+    names = {"k_byte_hist": "huff_byte_hist", "k_emit<0>": "huff_emit", "k_dec_sync": "huff_dec_sync", "k_dec_emit": "huff_dec_emit",
+             "k_dec_flat": "huff_dec_flat"}
     final = {}
     for k, v in res.items():
         base = k

@@ -47,6 +47,24 @@ def test_skewed_self_sync(huff, oracle, seed):
     assert huff.Decompress(c) == data
 
 
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5, 6, 7])
+def test_flat_codes_every_width(huff, oracle, L):
+    """Exactly 2^L equiprobable symbols -> all codes L bits -> the fixed-width unpack path."""
+    k = 1 << L
+    for reps, extra in ((37, 0), (8200, 0), (1000, 3)):
+        lo = 0 if k == 128 else 40
+        buf = bytearray(bytes(range(lo, lo + k)) * reps)
+        random.Random(L * 100 + reps).shuffle(buf)
+        data = bytes(buf)
+        if extra:   # perturb counts a little: lengths stay equal while no count doubles another
+            data += bytes(range(lo, lo + min(k, extra)))
+        c = oracle.huffman_compress(data)
+        t = oracle.huffman_table(data)
+        assert {x[3] for x in t} == {L}
+        assert huff.Decompress(c) == data
+        assert huff.Decompress(huff.Compress(data)) == data
+
+
 def test_two_symbols_one_bit_codes(huff, oracle):
     data = rnd_bytes(1, 700001, 0, 2)
     c = oracle.huffman_compress(data)
