@@ -32,7 +32,10 @@ __global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out
 constexpr int DB = 256;             // lanes per block
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits)
 constexpr int SBITS = SW * 32;
-constexpr int DATA_WORDS = DB * SW + 8;   // + overrun for a code that starts inside and ends outside
+constexpr int ORG_WORDS = 4;              // words staged in front of the block: warm-up room for the entry guess
+constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are offset by this
+constexpr int WARM = 96;                  // bits decoded ahead of a subsequence to let the guess self-synchronise
+constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
@@ -47,7 +50,7 @@ struct DecArgs {
     uint32_t n_sub;             // number of subsequences
     const uint32_t *lut; int K; int rep_log2;   // (1<<K) entries, each replicated 1<<rep_log2 times in LDS
     const int32_t *child;       // 2 per internal node: >=0 internal index, <0 -(rune+1)
-    uint32_t min_len;
+    uint32_t min_len; int flat_guess;
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
     int *changed; int pass;
@@ -61,13 +64,36 @@ __device__ __forceinline__ void stage_lut(const DecArgs &a, uint32_t *s_lut) {
     for (int i = threadIdx.x; i < total; i += DB) s_lut[i] = a.lut[i >> a.rep_log2];
 }
 
+// Stages payload words [w0, w0+DATA_WORDS) as big-endian words into the swizzled LDS image.
+// Interior blocks take a branch-free path: all 16-byte loads are issued before the first use.
 __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint32_t *s_data) {
-    const size_t w0 = (size_t)blk * DB * SW;
+    const long long w0 = (long long)blk * DB * SW - ORG_WORDS;   // staged word i is payload word w0+i; w0*4 is a multiple of 16
+    static_assert(DATA_WORDS % 4 == 0, "staged in 16-byte units");
+    constexpr int NV = DATA_WORDS / 4, PER = (NV + DB - 1) / DB;
+    if (w0 >= 0 && (size_t)(w0 + DATA_WORDS) * 4 <= a.nbytes) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.base + (size_t)w0 * 4);
+        uint4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int idx = threadIdx.x + k * DB; if (idx < NV) v[k] = src[idx]; }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int idx = threadIdx.x + k * DB;
+            if (idx < NV) {
+                const uint32_t j = swz(4 * idx);           // 4 consecutive words never straddle a 32-word group
+                s_data[j] = __builtin_bswap32(v[k].x); s_data[j + 1] = __builtin_bswap32(v[k].y);
+                s_data[j + 2] = __builtin_bswap32(v[k].z); s_data[j + 3] = __builtin_bswap32(v[k].w);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < DATA_WORDS; i += DB) {
-        const size_t off = (w0 + i) * 4;
+        const long long w = w0 + i;
         uint32_t v = 0;
-        if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
-        else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
+        if (w >= 0) {
+            const size_t off = (size_t)w * 4;
+            if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
+            else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
+        }
         s_data[swz(i)] = v;
     }
 }
@@ -153,14 +179,14 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ int s_skip;
     const int tid = threadIdx.x;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
-    const uint32_t my0 = tid * SBITS;
+    const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);   // once per (persistent) block
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
         const bool live = g < a.n_sub;
         // block-relative positions (the block spans DB*SBITS bits; exits overshoot by < 64)
-        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0 + ORG, (unsigned long long)(ORG + DB * SBITS + 4096));
         const uint32_t lim = min(my0 + SBITS, end_rel);
         __syncthreads();   // previous iteration is done with s_skip / s_data / s_part
         // lane 0's entry: the true start for block 0, else the predecessor block's published exit
@@ -180,22 +206,33 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         __syncthreads();
         if (s_skip) continue;
         stage_data(a, blk, s_data);
+        __syncthreads();   // the warm-up guess below reads the staged words
 
         uint32_t e;   // block-relative entry; BAD_POS = the predecessor ran off the end
         if (!live) e = BAD_POS;
-        else if (g == 0) e = (uint32_t)a.p0;
+        else if (g == 0) e = (uint32_t)a.p0 + ORG;
         else if (a.pass == 0 || tid > 0) {
-            // first guess: codes of the minimum length, phase-locked to p0 (exact for flat codes)
-            const unsigned long long s0 = blk_bit0 + my0;
-            unsigned long long q = a.p0;
-            if (s0 > a.p0) {
-                const unsigned long long d = s0 - a.p0 + a.min_len - 1;
-                q = a.p0 + (d - d % a.min_len);
+            const long long p0_rel = (long long)a.p0 - (long long)blk_bit0 + ORG;
+            if (p0_rel >= (long long)my0) e = (uint32_t)p0_rel;          // the stream starts inside/after this subsequence
+            else if (a.flat_guess) {
+                // codes of one length: boundaries are phase-locked to p0 (exact)
+                const unsigned long long d = (unsigned long long)((long long)my0 - p0_rel) + a.min_len - 1;   // > 2^32 on large inputs
+                e = (uint32_t)(p0_rel + (long long)(d - d % a.min_len));
+            } else {
+                // decode from WARM bits ahead of the subsequence: prefix codes self-synchronise within a few
+                // codewords, so the first boundary at or after my0 is very likely the true entry
+                const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - WARM);
+                BitReader br;
+                br.init(s_data, start);
+                while (br.pos < my0) {
+                    (void)decode_one<SHORT>(a, br, s_lut, lane_r);
+                    br.refill();
+                }
+                e = br.pos;
             }
-            e = (uint32_t)(q - blk_bit0);
         } else {
             const uint32_t xr = a.exit_rel[g - 1];
-            e = xr == BAD_REL ? BAD_POS : xr;
+            e = xr == BAD_REL ? BAD_POS : ORG + xr;
         }
         bool have = false;
         uint32_t x = 0, nb = 0;
@@ -289,13 +326,13 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_wsum[DB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
-    const uint32_t my0 = tid * SBITS;
+    const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
         const bool live = g < a.n_sub;
-        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0, (unsigned long long)(DB * SBITS + 4096));
+        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0 + ORG, (unsigned long long)(ORG + DB * SBITS + 4096));
         const uint32_t lim = min(my0 + SBITS, end_rel);
         __syncthreads();   // previous iteration has drained s_out / s_data / s_wsum
         stage_data(a, blk, s_data);
@@ -359,12 +396,22 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     const unsigned long long bit0 = a.p0 + sym0 * L;            // FLAT_SYMS*L is a multiple of 32: bit0 % 32 == p0 % 32
     const size_t w0 = (size_t)(bit0 >> 5);
     const uint32_t o0 = (uint32_t)(bit0 & 31);
-    for (int i = tid; i < WORDS; i += DB) {
-        const size_t off = (w0 + i) * 4;
-        uint32_t v = 0;
-        if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
-        else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
-        s_data[swz(i)] = v;
+    if ((w0 + WORDS) * 4 <= a.nbytes) {                         // interior block: branch-free, loads issued together
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.base) + w0;
+        constexpr int PER = (WORDS + DB - 1) / DB;
+        uint32_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) v[k] = src[i]; }
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) s_data[swz(i)] = __builtin_bswap32(v[k]); }
+    } else {
+        for (int i = tid; i < WORDS; i += DB) {
+            const size_t off = (w0 + i) * 4;
+            uint32_t v = 0;
+            if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
+            else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
+            s_data[swz(i)] = v;
+        }
     }
     for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = a.lut[i >> RL];
     __syncthreads();
@@ -538,6 +585,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.min_len = codes.min_len;
+    a.flat_guess = codes.min_len == codes.max_len;
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;

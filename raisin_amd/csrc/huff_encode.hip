@@ -44,21 +44,32 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
         for (int i = tid; i < 256 * R; i += HB) h[i] = 0;
         __syncthreads();
         const size_t base = (size_t)t * TILE;
-#pragma unroll 4
-        for (int k = 0; k < TILE / ROUND; k++) {
-            const size_t off = base + (size_t)(k * HB + tid) * 16;
-            if (off + 16 <= n) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(in + off);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        auto add16 = [&](const uint4 &v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    atomicAdd(&h[((w[j]) & 0xFF) * R + copy], 1u);
-                    atomicAdd(&h[((w[j] >> 8) & 0xFF) * R + copy], 1u);
-                    atomicAdd(&h[((w[j] >> 16) & 0xFF) * R + copy], 1u);
-                    atomicAdd(&h[(w[j] >> 24) * R + copy], 1u);
-                }
-            } else if (off < n) {
-                for (size_t p = off; p < n; p++) atomicAdd(&h[in[p] * R + copy], 1u);
+            for (int j = 0; j < 4; j++) {
+                atomicAdd(&h[((w[j]) & 0xFF) * R + copy], 1u);
+                atomicAdd(&h[((w[j] >> 8) & 0xFF) * R + copy], 1u);
+                atomicAdd(&h[((w[j] >> 16) & 0xFF) * R + copy], 1u);
+                atomicAdd(&h[(w[j] >> 24) * R + copy], 1u);
+            }
+        };
+        if (base + TILE <= n) {
+            // full tile: branch-free, 4 loads in flight per lane before the first LDS atomic
+            const uint4 *src = reinterpret_cast<const uint4 *>(in + base) + tid;
+#pragma unroll
+            for (int k0 = 0; k0 < TILE / ROUND; k0 += 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = src[(k0 + k) * HB];
+#pragma unroll
+                for (int k = 0; k < 4; k++) add16(v[k]);
+            }
+        } else {
+            for (int k = 0; k < TILE / ROUND; k++) {
+                const size_t off = base + (size_t)(k * HB + tid) * 16;
+                if (off + 16 <= n) add16(*reinterpret_cast<const uint4 *>(in + off));
+                else if (off < n) for (size_t p = off; p < n; p++) atomicAdd(&h[in[p] * R + copy], 1u);
             }
         }
         __syncthreads();
@@ -325,6 +336,8 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     uint32_t fill = (uint32_t)(bit0 & 127);       // bits of the window that precede this block's data
     __syncthreads();
 
+    uint4 pre = {0, 0, 0, 0};                                   // software prefetch of the next round's 16 bytes per lane
+    if (MODE != MODE_RUNE && in0 + (size_t)tid * 16 + 16 <= in1) pre = *reinterpret_cast<const uint4 *>(a.in + in0 + (size_t)tid * 16);
     for (size_t pos = in0; pos < in1; pos += ROUND) {
         const size_t P = pos + (size_t)tid * 16;
         // ---- pass 1: look up, sum code lengths
@@ -338,9 +351,9 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
             for (int k = 0; k < 16; k++) if ((smask >> k) & 1) mylen += a.len8[rune[k]];
         } else {
             if (P + 16 <= in1) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(a.in + P);
-                w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
+                w4[0] = pre.x; w4[1] = pre.y; w4[2] = pre.z; w4[3] = pre.w;
                 smask = 0xFFFF;
+                if (P + ROUND + 16 <= in1) pre = *reinterpret_cast<const uint4 *>(a.in + P + ROUND);
             } else if (P < in1) {
                 const int cnt = (int)(in1 - P);
                 for (int k = 0; k < cnt; k++) w4[k >> 2] |= (uint32_t)a.in[P + k] << (8 * (k & 3));

@@ -104,10 +104,11 @@ struct MatchArgs {
 #define RSN_DPP_WAVE_SHL1 0x130   // lane i <- lane i+1
 #define RSN_DPP_WAVE_SHR1 0x138   // lane i <- lane i-1
 
+// One step of one lane: lanes 0..62 take the run of the lane above (position+1, same
+// diagonal), lane 63 takes the carry; key = min(run,d)<<16 | d folded into the maximum.
 template <bool MASKED>
 __device__ __forceinline__ void match_step(uint32_t X, uint32_t Y, uint32_t cin16, uint32_t &R16, uint32_t &Bd, uint32_t &best,
                                            bool valid) {
-    // lanes 0..62 take the run of the lane above (position+1, same diagonal); lane 63 takes the carry
     const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)cin16, (int)R16, RSN_DPP_WAVE_SHL1, 0xF, 0xF, false);
     bool eq = X == Y;
     if (MASKED) eq = eq && valid;
@@ -117,22 +118,43 @@ __device__ __forceinline__ void match_step(uint32_t X, uint32_t Y, uint32_t cin1
     best = max(best, key);
 }
 
+// 64 steps t0..t0+63 of one wavefront.  MASKED: some lanes are outside this wave's
+// diagonal range (first/last 63 steps).  CHECKED: the candidate index may fall outside
+// the stream (only position blocks next to the start or the end of the stream).
+template <bool MASKED, bool CHECKED>
+__device__ __forceinline__ void match_chunk(const uint8_t *ybase, long long y0, uint32_t E, uint32_t t0, uint32_t nsteps, uint32_t DWk,
+                                            int lane, uint32_t X, uint32_t vCin, uint32_t &vCout, uint32_t &R16, uint32_t &Bd, uint32_t &best) {
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const uint32_t t = t0 + k;
+        if (!MASKED || t < nsteps) {
+            uint32_t Y = ybase[-(int)t];
+            if (CHECKED) { const long long y = y0 - (long long)t; if (y < 0 || y >= (long long)E) Y = 0x200; }
+            const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
+            const bool valid = !MASKED || (t + (uint32_t)lane - 63u) < DWk;   // local diagonal index in [0, DWk)
+            match_step<MASKED>(X, Y, cin, R16, Bd, best, valid);
+        }
+        // collect lane 0's run: shift the collector up one lane, lane 0 <- R16[0]
+        vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
+    }
+}
+
 __global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W4 = a.DW * MATCH_WAVES;                          // >= W
     const uint32_t WUB = (a.W + 63) / 64 * 64;                       // warm-up positions above the strip
-    const uint32_t RLEN = MATCH_STRIP + WUB + W4;                    // staged positions
-    uint16_t *s_b = reinterpret_cast<uint16_t *>(smem);              // bytes (0x200 = outside the stream)
-    uint16_t *s_carry = s_b + RLEN;                                  // [MATCH_WAVES][DW] runs entering from the block above
+    const uint32_t RLEN = (MATCH_STRIP + WUB + W4 + 15) & ~15u;      // staged positions
+    uint8_t *s_b = smem;                                             // stream bytes (0 outside the stream: see CHECKED)
+    uint16_t *s_carry = reinterpret_cast<uint16_t *>(smem + RLEN);   // [MATCH_WAVES][DW] runs entering from the block above
     uint32_t *s_comb = reinterpret_cast<uint32_t *>(s_carry + MATCH_WAVES * a.DW + (MATCH_WAVES * a.DW & 1));   // [2][MATCH_WAVES][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps the loop bounds in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: keeps the loop bounds in SGPRs
     const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
     const long long r0 = b0 - (long long)W4;
     for (uint32_t i = tid; i < RLEN; i += LB) {
         const long long p = r0 + i;
-        s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0x200;
+        s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0;
     }
     for (uint32_t i = tid; i < MATCH_WAVES * a.DW; i += LB) s_carry[i] = 0;
     __syncthreads();
@@ -151,33 +173,16 @@ __global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
         uint32_t best = 0, R16 = 0;
         // lane l meets diagonal Dk + (t - 62 + l) at step t; candidate index y = P0 + 62 - t - Dk for every lane
         uint32_t Bd = (Dk + (uint32_t)lane - 63u) * 0x10001u;         // becomes (Dk + t - 62 + l)*0x10001 after the step's increment
-        const uint16_t *ybase = s_b + (P0 + 62 - (long long)Dk - r0);
+        const long long y0 = P0 + 62 - (long long)Dk;
+        const uint8_t *ybase = s_b + (y0 - r0);
+        const bool checked = P0 < (long long)W4 || P0 + 63 >= (long long)a.E;   // block-uniform
         for (uint32_t t0 = 0; t0 < nsteps; t0 += 64) {
             const uint32_t ci = t0 + lane;
             const uint32_t vCin = ci < DWk ? (uint32_t)carry[ci] << 16 : 0u;
             uint32_t vCout = 0;
-            if (t0 >= 63 && t0 + 64 <= DWk) {
-#pragma unroll
-                for (int k = 0; k < 64; k++) {
-                    const uint32_t Y = ybase[-(int)(t0 + k)];
-                    const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
-                    match_step<false>(X, Y, cin, R16, Bd, best, true);
-                    // collect lane 0's run: shift the collector up one lane, lane 0 <- R16[0]
-                    vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 64; k++) {
-                    const uint32_t t = t0 + k;
-                    if (t < nsteps) {
-                        const uint32_t Y = ybase[-(int)t];
-                        const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
-                        const bool valid = (t + (uint32_t)lane - 63u) < DWk;   // local diagonal index in [0, DWk)
-                        match_step<true>(X, Y, cin, R16, Bd, best, valid);
-                    }
-                    vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
-                }
-            }
+            if (checked) match_chunk<true, true>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
+            else if (t0 >= 63 && t0 + 64 <= DWk) match_chunk<false, false>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
+            else match_chunk<true, false>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
             // lane 0 met local diagonal index t-63 at step t; after 64 shifts the value of step k sits in lane 63-k
             const uint32_t co = t0 - (uint32_t)lane;
             if (co < DWk) carry[co] = (uint16_t)(vCout >> 16);
@@ -352,7 +357,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys};
     {
         const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
-        const size_t shmem = (size_t)(MATCH_STRIP + WUB + W4) * 2 + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;
+        const size_t shmem = (size_t)((MATCH_STRIP + WUB + W4 + 15) & ~15u) + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;
         static thread_local size_t attr_set = 0;
         if (shmem > attr_set) {
             RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
