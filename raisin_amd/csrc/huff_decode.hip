@@ -32,12 +32,12 @@ __global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out
 constexpr int DB = 256;             // lanes per block
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits)
 constexpr int SBITS = SW * 32;
-constexpr int ORG_WORDS = 4;              // words staged in front of the block: warm-up room for the entry guess
+constexpr int ORG_WORDS = 8;              // words staged in front of the block: warm-up room for the entry guess
 constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are offset by this
-constexpr int WARM = 96;                  // bits decoded ahead of a subsequence to let the guess self-synchronise
 constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
+constexpr int KM = 12;              // index bits of the multi-symbol table (ASCII alphabets with codes <= 11 bits)
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
 constexpr uint32_t BAD_REL = 0xFFFF;
 constexpr uint32_t BAD_POS = 0xFFFFFFFFu;
@@ -50,7 +50,8 @@ struct DecArgs {
     uint32_t n_sub;             // number of subsequences
     const uint32_t *lut; int K; int rep_log2;   // (1<<K) entries, each replicated 1<<rep_log2 times in LDS
     const int32_t *child;       // 2 per internal node: >=0 internal index, <0 -(rune+1)
-    uint32_t min_len; int flat_guess;
+    const uint32_t *mlut;       // MULTI: 2^12 entries, up to 3 symbols each: sym1 | sym2<<8 | sym3<<16 | bits<<24 | (n-1)<<28
+    uint32_t min_len; int flat_guess; int warm;   // warm: bits decoded ahead of a subsequence so that the guess self-synchronises
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
     int *changed; int pass;
@@ -151,12 +152,23 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, BitReader &br, 
 // Walk from block-relative bit `pos` to the first code boundary >= lim.  Two codewords are
 // decoded per refill (2*K <= 22 < 33 valid bits).  A code that runs past the end of the
 // payload can only be the last one of the walk, so that check happens once, after the loop.
-template <bool ASCII, bool SHORT>
-__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t pos,
-                                     uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
+template <bool ASCII, bool SHORT, bool MULTI>
+__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut, uint32_t lane_r,
+                                     uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
     uint32_t nb = 0;
     BitReader br;
     br.init(s_data, pos);
+    if (MULTI) {
+        // up to 3 codewords per table lookup while a whole KM-bit step stays inside the subsequence
+        const uint32_t safe = lim >= KM ? lim - KM : 0;
+        while (br.pos <= safe && lim >= KM) {
+            const uint32_t e = s_mlut[br.hi >> (32 - KM)];
+            const uint32_t n = (e >> 28) & 3;
+            if (n == 0) { (void)decode_one<SHORT>(a, br, s_lut, lane_r); nb++; }   // first code longer than KM bits
+            else { br.advance((e >> 24) & 15); nb += n; }
+            br.refill();
+        }
+    }
     while (br.pos < lim) {
         const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
         nb += ASCII ? 1 : dev_utf8_len(r1);
@@ -170,10 +182,11 @@ __device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, c
     *nbytes = nb;
 }
 
-template <bool ASCII, bool SHORT>
+template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
     __shared__ uint32_t s_lut[LUT_WORDS];
+    __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
@@ -181,6 +194,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);   // once per (persistent) block
+    if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
             } else {
                 // decode from WARM bits ahead of the subsequence: prefix codes self-synchronise within a few
                 // codewords, so the first boundary at or after my0 is very likely the true entry
-                const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - WARM);
+                const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
                 BitReader br;
                 br.init(s_data, start);
                 while (br.pos < my0) {
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         for (int round = 0; round <= DB; round++) {
             if (live && !have) {
                 if (e == BAD_POS) { x = BAD_POS; nb = 0; }
-                else walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, e, lim, end_rel, &x, &nb);
+                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, e, lim, end_rel, &x, &nb);
                 have = true;
             }
             s_exit[tid] = x;
@@ -302,11 +316,26 @@ __device__ __forceinline__ void put_rune(uint32_t rune, Put put) {   // string(r
 }
 
 // Decode loop of D3: entries are exact, so the walk never runs off the payload.
-template <bool ASCII, bool SHORT, class Put>
-__device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r,
-                                          uint32_t pos, uint32_t lim, Put put) {
+template <bool ASCII, bool SHORT, bool MULTI, class Put>
+__device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut,
+                                          uint32_t lane_r, uint32_t pos, uint32_t lim, Put put) {
     BitReader br;
     br.init(s_data, pos);
+    if (MULTI) {
+        const uint32_t safe = lim >= KM ? lim - KM : 0;
+        while (br.pos <= safe && lim >= KM) {
+            const uint32_t e = s_mlut[br.hi >> (32 - KM)];
+            const uint32_t n = (e >> 28) & 3;
+            if (n == 0) put(decode_one<SHORT>(a, br, s_lut, lane_r));           // first code longer than KM bits
+            else {
+                br.advance((e >> 24) & 15);
+                put(e & 0xFF);
+                if (n >= 2) put((e >> 8) & 0xFF);
+                if (n >= 3) put((e >> 16) & 0xFF);
+            }
+            br.refill();
+        }
+    }
     while (br.pos < lim) {
         const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
         if (ASCII) put(r1); else put_rune(r1, put);
@@ -318,16 +347,18 @@ __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_da
     }
 }
 
-template <bool ASCII, bool SHORT>
+template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
     __shared__ uint32_t s_lut[LUT_WORDS];
+    __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);
+    if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -351,11 +382,11 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
         if (live && er != BAD_REL && nb != 0) {
             if (staged) {
                 uint8_t *o = s_out + al + my_off;
-                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
+                emit_walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, my0 + er, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
             } else {
                 Sink sink;
                 sink.start(dst + my_off);
-                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
+                emit_walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
                 sink.finish();
             }
         }
@@ -571,9 +602,33 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const bool short_codes = codes.max_len <= (unsigned)LUT_BITS_MAX;
     std::vector<uint32_t> lut; std::vector<int32_t> child;
     build_tables(tree, K, lut, child);
-    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4, &p); if (rc) return rc;
+    // multi-symbol table: decode as many whole codewords (<= 3) as fit in KM bits
+    static const bool no_multi = getenv("RSN_NO_MULTI") != nullptr;
+    // worth it when a KM-bit window usually holds two or more codewords
+    unsigned long long n_syms_total = 0;
+    for (uint32_t i = 0; i < tree.n_leaves; i++) n_syms_total += tree.freq[i];
+    const bool multi = ascii && !no_multi && n_syms_total && codes.total_bits * 10 <= n_syms_total * 65;   // mean code <= 6.5 bits
+    std::vector<uint32_t> mlut;
+    if (multi) {
+        mlut.assign((size_t)1 << KM, 0);
+        for (uint32_t v = 0; v < (1u << KM); v++) {
+            uint32_t used = 0, nsym = 0, ent = 0;
+            while (nsym < 3 && used < (uint32_t)KM) {
+                int32_t node = tree.root;
+                uint32_t q = used;
+                while (!tree.is_leaf(node) && q < (uint32_t)KM) { node = ((v >> (KM - 1 - q)) & 1) ? tree.right[node] : tree.left[node]; q++; }
+                if (!tree.is_leaf(node)) break;            // ran out of bits inside a codeword
+                ent |= (tree.rune[node] & 0xFF) << (8 * nsym);
+                used = q; nsym++;
+            }
+            mlut[v] = ent | (used << 24) | (nsym << 28);   // nsym == 0: the first code is longer than KM bits
+        }
+    }
+    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4 + mlut.size() * 4, &p); if (rc) return rc;
     uint32_t *d_lut = (uint32_t *)p;
     int32_t *d_child = (int32_t *)(d_lut + lut.size());
+    uint32_t *d_mlut = (uint32_t *)(d_child + child.size());
+    if (multi) RSN_HIP(hipMemcpyAsync(d_mlut, mlut.data(), mlut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
 
@@ -584,8 +639,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const unsigned long long n_sub64 = (a.end + SBITS - 1) / SBITS;
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
+    a.mlut = d_mlut;
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.min_len = codes.min_len;
     a.flat_guess = codes.min_len == codes.max_len;
+    static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 96; }();
+    a.warm = std::min(std::max(warm_env, 0), ORG - 32);
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;
@@ -600,10 +658,13 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
 
     const uint32_t grid_p = std::min<uint32_t>(n_blk, 256u * 8u * 2u);   // persistent blocks: the LUT is staged once per block
     auto launch_sync = [&]() -> int {
-        if (ascii && short_codes) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-        else if (ascii) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-        else if (short_codes) RSN_LAUNCH("huff_dec_sync", (k_dec_sync<false, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-        else RSN_LAUNCH("huff_dec_sync", (k_dec_sync<false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        const char *nm = a.pass == 0 ? "huff_dec_sync" : a.pass == 1 ? "huff_dec_sync_fix" : "huff_dec_sync_verify";
+        if (multi && short_codes) RSN_LAUNCH(nm, (k_dec_sync<true, true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (multi) RSN_LAUNCH(nm, (k_dec_sync<true, false, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (ascii && short_codes) RSN_LAUNCH(nm, (k_dec_sync<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (ascii) RSN_LAUNCH(nm, (k_dec_sync<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else if (short_codes) RSN_LAUNCH(nm, (k_dec_sync<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        else RSN_LAUNCH(nm, (k_dec_sync<false, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
         return RSN_OK;
     };
     // ---- D1: iterate to the fixed point
@@ -632,10 +693,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- D3
     a.blk_off = d_blk_off; a.out = d_out;
-    if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-    else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-    else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
-    else RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    // (the multi-symbol table pays in the counting walk only: with byte stores per symbol the emit loop measured slower)
+    if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+    else RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     RSN_HIP(hipStreamSynchronize(s));
     return RSN_OK;
 }

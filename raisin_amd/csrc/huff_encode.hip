@@ -30,30 +30,33 @@ constexpr int ROUND = HB * 16;     // input bytes per block round (16 B per lane
 enum { MODE_ASCII = 0, MODE_ASCII_WIDE = 1, MODE_RUNE = 2 };
 
 // ---------------------------------------------------------------- K1: byte histogram
-// R replicated sub-histograms, bin-major (h[bin*R + copy]) so that copies of one
-// bin sit in different LDS banks; copy = lane % R.
-template <int R>
+// 128 bins x 32 copies, bin-major: copy = lane % 32 IS the LDS bank, so the 32 lanes of a
+// half-wavefront never collide whatever the data.  Only 7-bit symbols are counted: an input
+// with any byte >= 0x80 is merely flagged (ghist[128]) and re-histogrammed by the rune path,
+// whose symbols are runes, not bytes (huffman.go:309).
 __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in, size_t n, uint32_t n_tiles,
                                                   uint32_t *__restrict__ tile_hist,
                                                   unsigned long long *__restrict__ ghist) {
-    __shared__ uint32_t h[256 * R];
+    __shared__ uint32_t h[128 * 32];
     const int tid = threadIdx.x;
-    const int copy = tid & (R - 1);
+    const uint32_t copy = tid & 31;
     unsigned long long mine = 0;
+    uint32_t hi_any = 0;
+    auto add16 = [&](const uint4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hi_any |= w[j];
+            atomicAdd(&h[((w[j] & 0x7F) << 5) | copy], 1u);
+            atomicAdd(&h[(((w[j] >> 8) & 0x7F) << 5) | copy], 1u);
+            atomicAdd(&h[(((w[j] >> 16) & 0x7F) << 5) | copy], 1u);
+            atomicAdd(&h[(((w[j] >> 24) & 0x7F) << 5) | copy], 1u);
+        }
+    };
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        for (int i = tid; i < 256 * R; i += HB) h[i] = 0;
+        for (int i = tid; i < 128 * 32; i += HB) h[i] = 0;
         __syncthreads();
         const size_t base = (size_t)t * TILE;
-        auto add16 = [&](const uint4 &v) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                atomicAdd(&h[((w[j]) & 0xFF) * R + copy], 1u);
-                atomicAdd(&h[((w[j] >> 8) & 0xFF) * R + copy], 1u);
-                atomicAdd(&h[((w[j] >> 16) & 0xFF) * R + copy], 1u);
-                atomicAdd(&h[(w[j] >> 24) * R + copy], 1u);
-            }
-        };
         if (base + TILE <= n) {
             // full tile: branch-free, 4 loads in flight per lane before the first LDS atomic
             const uint4 *src = reinterpret_cast<const uint4 *>(in + base) + tid;
@@ -69,18 +72,21 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
             for (int k = 0; k < TILE / ROUND; k++) {
                 const size_t off = base + (size_t)(k * HB + tid) * 16;
                 if (off + 16 <= n) add16(*reinterpret_cast<const uint4 *>(in + off));
-                else if (off < n) for (size_t p = off; p < n; p++) atomicAdd(&h[in[p] * R + copy], 1u);
+                else if (off < n) for (size_t p = off; p < n; p++) { hi_any |= in[p]; atomicAdd(&h[((in[p] & 0x7F) << 5) | copy], 1u); }
             }
         }
         __syncthreads();
-        uint32_t s = 0;
+        if (tid < 128) {
+            uint32_t s = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) s += h[tid * R + ((r + tid) & (R - 1))];
-        tile_hist[(size_t)t * 256 + tid] = s;
-        mine += s;
+            for (int r = 0; r < 32; r++) s += h[(tid << 5) | ((r + tid) & 31)];   // rotated: conflict-free
+            tile_hist[(size_t)t * 128 + tid] = s;
+            mine += s;
+        }
         __syncthreads();
     }
-    if (mine) atomicAdd(&ghist[tid], mine);
+    if (tid < 128 && mine) atomicAdd(&ghist[tid], mine);
+    if (hi_any & 0x80808080u) atomicAdd(&ghist[128], 1ull);
 }
 
 // ---------------------------------------------------------------- Go UTF-8 classification (rune path)
@@ -177,16 +183,14 @@ __global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in
 }
 
 // ---------------------------------------------------------------- K2: tile bit totals
-// one wavefront per tile: sum_s hist[t][s] * len[s]
+// one wavefront per tile: sum_s hist[t][s] * len[s] over the 128 byte bins
 __global__ __launch_bounds__(HB) void k_tile_bits(const uint32_t *__restrict__ tile_hist, const uint8_t *__restrict__ lens,
                                                   uint32_t n_tiles, unsigned long long *__restrict__ tile_bits) {
     const uint32_t t = blockIdx.x * (HB / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
-    const uint32_t *h = tile_hist + (size_t)t * 256;
-    unsigned long long s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) s += (unsigned long long)h[lane + 64 * k] * lens[lane + 64 * k];
+    const uint32_t *h = tile_hist + (size_t)t * 128;
+    unsigned long long s = (unsigned long long)h[lane] * lens[lane] + (unsigned long long)h[lane + 64] * lens[lane + 64];
     for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
     if (lane == 0) tile_bits[t] = s;
 }
@@ -287,15 +291,14 @@ struct EmitArgs {
 // trailing partial word may be shared with neighbours -> ds_or; words in between
 // are wholly owned -> plain ds_write.
 struct Packer {
-    uint32_t *win; unsigned long long acc; uint32_t nb, w; bool first;
-    __device__ __forceinline__ void start(uint32_t *window, uint32_t bit_off) { win = window; acc = 0; nb = bit_off & 31; w = bit_off >> 5; first = true; }
+    uint32_t *win; unsigned long long acc; uint32_t nb, w;
+    __device__ __forceinline__ void start(uint32_t *window, uint32_t bit_off) { win = window; acc = 0; nb = bit_off & 31; w = bit_off >> 5; }
     __device__ __forceinline__ void put(uint32_t code, uint32_t len) {   // len <= 26
         acc = (acc << len) | code;
         nb += len;
         if (nb >= 32) {
             nb -= 32;
-            const uint32_t word = (uint32_t)(acc >> nb);
-            if (first) { atomicOr(&win[w], word); first = false; } else win[w] = word;
+            atomicOr(&win[w], (uint32_t)(acc >> nb));   // the window is zeroed every round: OR == store, and is safe on shared words
             w++;
         }
     }
@@ -309,12 +312,24 @@ struct Packer {
     }
 };
 
+// Wavefront inclusive scan on DPP (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     constexpr int MAXLEN = EmitCfg<MODE>::MAXLEN;
     constexpr int WIN_WORDS = ROUND * MAXLEN / 32 + 8;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN_WORDS];
-    __shared__ uint32_t s_tab[MODE == MODE_ASCII ? 256 : 1];
+    constexpr int TREP = 1;                                     // copies of the code table: lanes l and l+8k share one, spreads the lookups over banks
+    __shared__ uint32_t s_tab[MODE == MODE_ASCII ? 128 * TREP : 1];
     __shared__ unsigned long long s_code[MODE == MODE_ASCII_WIDE ? 256 : 1];
     __shared__ uint8_t s_len[MODE == MODE_ASCII_WIDE ? 256 : 1];
     __shared__ uint32_t s_wsum[HB / 64];
@@ -326,7 +341,8 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     const size_t in0 = (size_t)t0 * TILE;
     const size_t in1 = min((size_t)t1 * TILE, a.n);
 
-    if (MODE == MODE_ASCII) s_tab[tid] = a.tab32[tid];
+    if (MODE == MODE_ASCII) for (int i = tid; i < 128 * TREP; i += HB) s_tab[i] = a.tab32[i / TREP];
+    const uint32_t trep = tid & (TREP - 1);
     if (MODE == MODE_ASCII_WIDE) { s_code[tid] = a.code64[tid]; s_len[tid] = a.len8[tid]; }
     for (int i = tid; i < WIN_WORDS; i += HB) s_win[i] = 0;
 
@@ -359,21 +375,29 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
                 for (int k = 0; k < cnt; k++) w4[k >> 2] |= (uint32_t)a.in[P + k] << (8 * (k & 3));
                 smask = (1u << cnt) - 1;
             }
+            if (MODE == MODE_ASCII && pos + ROUND <= in1) {
+                // full round (block-uniform): no per-symbol masking, 16 independent LDS lookups
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
-                if (MODE == MODE_ASCII) {
-                    const uint32_t ent = ((smask >> k) & 1) ? s_tab[b] : 0;
-                    e[k] = ent;
-                    mylen += ent >> 26;
-                } else {
-                    if ((smask >> k) & 1) mylen += s_len[b];
+                for (int k = 0; k < 16; k++) {
+                    e[k] = s_tab[(((w4[k >> 2] >> (8 * (k & 3))) & 0x7F) * TREP) | trep];
+                    mylen += e[k] >> 26;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                    if (MODE == MODE_ASCII) {
+                        const uint32_t ent = ((smask >> k) & 1) ? s_tab[((b & 0x7F) * TREP) | trep] : 0;
+                        e[k] = ent;
+                        mylen += ent >> 26;
+                    } else {
+                        if ((smask >> k) & 1) mylen += s_len[b];
+                    }
                 }
             }
         }
         // ---- block exclusive scan of mylen
-        uint32_t incl = mylen;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        const uint32_t incl = wave_incl_scan(mylen);
         if (lane == 63) s_wsum[wv] = incl;
         __syncthreads();
         uint32_t wpre = 0, total = 0;
@@ -449,21 +473,13 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     int rc = dev_buf(c, 1, 256 * 8, &p); if (rc) return rc;
     unsigned long long *d_gh = (unsigned long long *)p;
     RSN_HIP(hipMemsetAsync(d_gh, 0, 256 * 8, s));
-    static int R = [] { const char *e = getenv("RSN_HIST_R"); return e ? atoi(e) : 8; }();
     const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 2048);
-    switch (R) {
-        case 1: RSN_LAUNCH("huff_byte_hist", k_byte_hist<1>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
-        case 4: RSN_LAUNCH("huff_byte_hist", k_byte_hist<4>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
-        case 16: RSN_LAUNCH("huff_byte_hist", k_byte_hist<16>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
-        case 32: RSN_LAUNCH("huff_byte_hist", k_byte_hist<32>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
-        default: RSN_LAUNCH("huff_byte_hist", k_byte_hist<8>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh); break;
-    }
+    RSN_LAUNCH("huff_byte_hist", k_byte_hist, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
     void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 8, &hp); if (rc) return rc;
     unsigned long long *h = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h, d_gh, 256 * 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
-    ascii = true;
-    for (int b = 128; b < 256; b++) if (h[b]) ascii = false;
+    ascii = h[128] == 0;   // no byte >= 0x80 seen
     syms.clear();
     if (ascii) {
         for (uint32_t b = 0; b < 128; b++) if (h[b]) syms.push_back({b, h[b]});
@@ -496,7 +512,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
     const uint32_t n_tiles = (uint32_t)ceil_div(n, TILE);
     void *p;
-    int rc = dev_buf(c, 0, (size_t)n_tiles * 256 * 4, &p); if (rc) return rc;
+    int rc = dev_buf(c, 0, (size_t)n_tiles * 128 * 4, &p); if (rc) return rc;
     uint32_t *d_tile_hist = (uint32_t *)p;
 
     std::vector<HuffSym> syms;
