@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--mib", type=int, default=1024, help="buffer size per GPU (default: the 1 GiB of BASELINE.json)")
     ap.add_argument("--cpu-sample-mib", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
     import torch
@@ -79,8 +80,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            local_rank = 0                       # test mode: every rank drives GPU 0, collectives run on host tensors
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         print("bench.py: --gpus %d needs the torch.distributed launcher (WORLD_SIZE unset)" % args.gpus, file=sys.stderr)
         sys.exit(2)
@@ -129,7 +134,7 @@ def main():
     t_max = elapsed
     if dist is not None:
         from raisin_amd import shard
-        t_max = shard.max_over_ranks(dist, elapsed, device)
+        t_max = shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
 
     lossless = bool(d.numel() == n and torch.equal(d, src))
     comp_n = int(c.numel())
@@ -138,7 +143,7 @@ def main():
     if dist is not None:
         # config 5: compressed segments to rank 0 over RCCL, timed on its own (not part of `value`)
         from raisin_amd import shard
-        seg = c.clone()
+        seg = c.clone() if args.dist_backend == "nccl" else c.cpu()
         fence()
         g0 = time.perf_counter()
         got = shard.gather_segments(dist, seg, 0)
