@@ -454,6 +454,115 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- K5a: emit, ASCII alphabet, codes <= 26 bits
+// The hot kernel.  Same bit layout and hand-over rules as k_emit, tuned for issue slots
+// (the kernel is VALU-issue-bound, profiles/): 32 symbols per lane and round halve the
+// per-round work (scan, barriers, flush), full rounds are branch-free, and the flush pass
+// clears the LDS window as it drains it.
+template <int A32_SPL>                      // symbols per lane per round (multiple of 16)
+__global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
+    constexpr int A32_ROUND = HB * A32_SPL;
+    constexpr int A32_WIN = A32_ROUND * 26 / 32 + 8;
+    constexpr int NV = A32_SPL / 16;
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[A32_WIN];
+    __shared__ uint32_t s_tab[128];
+    __shared__ uint32_t s_wsum[HB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t t0 = blockIdx.x * a.tiles_per_block;
+    if (t0 >= a.n_tiles) return;
+    const uint32_t t1 = min(t0 + a.tiles_per_block, a.n_tiles);
+    const size_t in0 = (size_t)t0 * TILE;
+    const size_t in1 = min((size_t)t1 * TILE, a.n);
+    if (tid < 128) s_tab[tid] = a.tab32[tid];
+    for (int i = tid; i < A32_WIN; i += HB) s_win[i] = 0;
+    const unsigned long long bit0 = a.base_bits + a.tile_off[t0];
+    const unsigned long long unit0 = bit0 >> 7;
+    unsigned long long win_unit = unit0;
+    uint32_t fill = (uint32_t)(bit0 & 127);
+    __syncthreads();
+
+    uint4 pre[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) pre[k] = make_uint4(0, 0, 0, 0);
+    if (in0 + A32_ROUND <= in1) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.in + in0 + (size_t)tid * A32_SPL);
+#pragma unroll
+        for (int k = 0; k < NV; k++) pre[k] = src[k];
+    }
+    for (size_t pos = in0; pos < in1; pos += A32_ROUND) {
+        const size_t P = pos + (size_t)tid * A32_SPL;
+        uint32_t e[A32_SPL];
+        uint32_t mylen = 0;
+        if (pos + A32_ROUND <= in1) {
+            uint32_t w[NV * 4];
+#pragma unroll
+            for (int k = 0; k < NV; k++) { w[4 * k] = pre[k].x; w[4 * k + 1] = pre[k].y; w[4 * k + 2] = pre[k].z; w[4 * k + 3] = pre[k].w; }
+            if (pos + 2 * A32_ROUND <= in1) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.in + P + A32_ROUND);
+#pragma unroll
+                for (int k = 0; k < NV; k++) pre[k] = src[k];
+            }
+#pragma unroll
+            for (int k = 0; k < A32_SPL; k++) {
+                e[k] = s_tab[(w[k >> 2] >> (8 * (k & 3))) & 0x7F];
+                mylen += e[k] >> 26;
+            }
+        } else {
+            // last, partial round of the input
+#pragma unroll
+            for (int k = 0; k < A32_SPL; k++) {
+                e[k] = (P + k < in1) ? s_tab[a.in[P + k] & 0x7F] : 0;
+                mylen += e[k] >> 26;
+            }
+        }
+        const uint32_t incl = wave_incl_scan(mylen);
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t wpre = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < HB / 64; k++) { const uint32_t x = s_wsum[k]; if (k < wv) wpre += x; total += x; }
+        Packer pk;
+        pk.start(s_win, fill + wpre + incl - mylen);
+#pragma unroll
+        for (int k = 0; k < A32_SPL; k++) pk.put(e[k] & 0x3FFFFFFu, e[k] >> 26);
+        if (mylen) pk.finish();
+        __syncthreads();
+        // drain complete 16-byte units and clear them behind us
+        const uint32_t tot_bits = fill + total;
+        const uint32_t n_units = tot_bits >> 7;
+        for (uint32_t u = tid; u < n_units; u += HB) {
+            uint4 v = *reinterpret_cast<const uint4 *>(&s_win[u * 4]);
+            *reinterpret_cast<uint4 *>(&s_win[u * 4]) = make_uint4(0, 0, 0, 0);
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y); v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+            const unsigned long long g = win_unit + u;
+            uint32_t *dst = a.out_words + g * 4;
+            if (g == unit0) {
+                if (v.x) atomicOr(dst + 0, v.x);
+                if (v.y) atomicOr(dst + 1, v.y);
+                if (v.z) atomicOr(dst + 2, v.z);
+                if (v.w) atomicOr(dst + 3, v.w);
+            } else {
+                *reinterpret_cast<uint4 *>(dst) = v;
+            }
+        }
+        uint32_t carry = 0;
+        if (tid < 4) carry = s_win[n_units * 4 + tid];
+        __syncthreads();
+        if (tid < 4) {                      // the partial unit becomes the front of the next window
+            if (n_units) s_win[n_units * 4 + tid] = 0;
+            s_win[tid] = carry;
+        }
+        win_unit += n_units;
+        fill = tot_bits & 127;
+        // the scan barrier of the next round orders these writes before the next pack
+    }
+    __syncthreads();
+    if (fill && tid < 4) {
+        const uint32_t v = __builtin_bswap32(s_win[tid]);
+        if (v) atomicOr(a.out_words + win_unit * 4 + tid, v);
+    }
+}
+
 // ======================================================================= host side
 namespace {
 
@@ -595,7 +704,12 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
                (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + codes.total_bits);
     RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
-    if (mode == MODE_ASCII) RSN_LAUNCH("huff_emit", k_emit<MODE_ASCII>, dim3(n_blocks), dim3(HB), 0, s, a);
+    static const bool emit16 = getenv("RSN_EMIT16") != nullptr;   // A/B switch: the 16-symbols-per-lane generic kernel
+    static const int emit_spl = [] { const char *e = getenv("RSN_EMIT_SPL"); return e ? atoi(e) : 32; }();
+    if (mode == MODE_ASCII && !emit16 && emit_spl == 64) RSN_LAUNCH("huff_emit", k_emit_ascii32<64>, dim3(n_blocks), dim3(HB), 0, s, a);
+    else if (mode == MODE_ASCII && !emit16 && emit_spl == 48) RSN_LAUNCH("huff_emit", k_emit_ascii32<48>, dim3(n_blocks), dim3(HB), 0, s, a);
+    else if (mode == MODE_ASCII && !emit16) RSN_LAUNCH("huff_emit", k_emit_ascii32<32>, dim3(n_blocks), dim3(HB), 0, s, a);
+    else if (mode == MODE_ASCII) RSN_LAUNCH("huff_emit", k_emit<MODE_ASCII>, dim3(n_blocks), dim3(HB), 0, s, a);
     else if (mode == MODE_ASCII_WIDE) RSN_LAUNCH("huff_emit_wide", k_emit<MODE_ASCII_WIDE>, dim3(n_blocks), dim3(HB), 0, s, a);
     else RSN_LAUNCH("huff_emit_rune", k_emit<MODE_RUNE>, dim3(n_blocks), dim3(HB), 0, s, a);
     RSN_HIP(hipStreamSynchronize(s));   // hdr (host memory) must outlive the copy

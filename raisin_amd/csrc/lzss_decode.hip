@@ -157,14 +157,31 @@ __global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ 
     }
 }
 
-// in_par[b] = parity of the 5C run that ends right before block b (sequential over block summaries)
-__global__ void k_une_carry(const uint8_t *__restrict__ summ, uint32_t n_blk, uint8_t *__restrict__ in_par) {
-    if (threadIdx.x || blockIdx.x) return;
-    uint32_t par = 0;
-    for (uint32_t b = 0; b < n_blk; b++) {
-        in_par[b] = (uint8_t)par;
+// in_par[b] = parity of the 5C run that ends right before block b.  The (all-5C, parity)
+// summaries combine associatively, so one block of 1024 lanes scans them: every lane folds a
+// contiguous chunk, lane 0 chains the 1024 chunk summaries, every lane replays its chunk.
+__global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ summ, uint32_t n_blk, uint8_t *__restrict__ in_par) {
+    __shared__ uint8_t s_chunk[1024];
+    __shared__ uint8_t s_in[1024];
+    const uint32_t per = (n_blk + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, n_blk);
+    uint32_t all = 2, par = 0;                       // summary of this lane's chunk, same encoding as summ[]
+    for (uint32_t b = b0; b < b1; b++) {
         const uint32_t v = summ[b];
-        par = (v & 2) ? par ^ (v & 1) : (v & 1);
+        if (v & 2) par ^= v & 1; else { all = 0; par = v & 1; }
+    }
+    s_chunk[threadIdx.x] = (uint8_t)(all | par);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t p = 0;
+        for (int k = 0; k < 1024; k++) { s_in[k] = (uint8_t)p; const uint32_t v = s_chunk[k]; p = (v & 2) ? p ^ (v & 1) : (v & 1); }
+    }
+    __syncthreads();
+    uint32_t p = s_in[threadIdx.x];
+    for (uint32_t b = b0; b < b1; b++) {
+        in_par[b] = (uint8_t)p;
+        const uint32_t v = summ[b];
+        p = (v & 2) ? p ^ (v & 1) : (v & 1);
     }
 }
 
@@ -276,7 +293,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
     uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + n_ub;
     RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);
-    RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(64), 0, s, d_summ, n_ub, d_inpar);
+    RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(1024), 0, s, d_summ, n_ub, d_inpar);
     RSN_LAUNCH("lzss_une_count", k_une_count, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_inpar, d_ulen);
     RSN_LAUNCH("lzss_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_ulen, d_uoff, n_ub, d_utot);
     RSN_HIP(hipMemcpyAsync(h64, d_utot, 8, hipMemcpyDeviceToHost, s));
