@@ -59,14 +59,25 @@ struct DecArgs {
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return j + (j >> 5); }
+// Subsequence image: every 8 payload words are followed by a COPY of the next word, so the two
+// dwords that hold any 32-bit window are always adjacent (one ds_read2_b32), and a lane stride of
+// 9 words puts the 32 lanes of a half-wavefront on 32 different banks.
+__device__ __forceinline__ uint32_t grp(uint32_t w) { return w + (w >> 3); }
+constexpr int DATA_PHYS = (ORG_WORDS + DB * SW + 8) / 8 * 9 + 2;
 
 __device__ __forceinline__ void stage_lut(const DecArgs &a, uint32_t *s_lut) {
     const int total = (1 << a.K) << a.rep_log2;
     for (int i = threadIdx.x; i < total; i += DB) s_lut[i] = a.lut[i >> a.rep_log2];
 }
 
-// Stages payload words [w0, w0+DATA_WORDS) as big-endian words into the swizzled LDS image.
+// Stages payload words [w0, w0+DATA_WORDS) as big-endian words into the grouped LDS image.
 // Interior blocks take a branch-free path: all 16-byte loads are issued before the first use.
+__device__ __forceinline__ void put_word(uint32_t *s_data, uint32_t j, uint32_t v) {
+    const uint32_t p = grp(j);
+    s_data[p] = v;
+    if ((j & 7) == 0 && j) s_data[p - 1] = v;      // the copy that closes the previous group
+}
+
 __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint32_t *s_data) {
     const long long w0 = (long long)blk * DB * SW - ORG_WORDS;   // staged word i is payload word w0+i; w0*4 is a multiple of 16
     static_assert(DATA_WORDS % 4 == 0, "staged in 16-byte units");
@@ -80,9 +91,11 @@ __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint3
         for (int k = 0; k < PER; k++) {
             const int idx = threadIdx.x + k * DB;
             if (idx < NV) {
-                const uint32_t j = swz(4 * idx);           // 4 consecutive words never straddle a 32-word group
-                s_data[j] = __builtin_bswap32(v[k].x); s_data[j + 1] = __builtin_bswap32(v[k].y);
-                s_data[j + 2] = __builtin_bswap32(v[k].z); s_data[j + 3] = __builtin_bswap32(v[k].w);
+                const uint32_t j = 4 * idx, pj = grp(j);   // 4 consecutive words never straddle a group
+                const uint32_t x = __builtin_bswap32(v[k].x);
+                s_data[pj] = x; s_data[pj + 1] = __builtin_bswap32(v[k].y);
+                s_data[pj + 2] = __builtin_bswap32(v[k].z); s_data[pj + 3] = __builtin_bswap32(v[k].w);
+                if ((j & 7) == 0 && j) s_data[pj - 1] = x;
             }
         }
         return;
@@ -95,96 +108,69 @@ __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint3
             if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
             else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
         }
-        s_data[swz(i)] = v;
+        put_word(s_data, (uint32_t)i, v);
     }
 }
 
 __device__ __forceinline__ int dev_utf8_len(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
 
-// Sequential bit reader over the block's staged big-endian words.  (hi:lo) holds the
-// stream from `pos`; words below index wi are loaded.  A word is appended whenever
-// 32 or fewer valid bits remain, so at least 33 are valid after every skip().
-struct BitReader {
-    const uint32_t *s; uint32_t hi, lo, pos, wi;
-    __device__ __forceinline__ void init(const uint32_t *s_data, uint32_t p) {
-        s = s_data; pos = p;
-        const uint32_t w = p >> 5;
-        const unsigned long long v = (((unsigned long long)s[swz(w)] << 32) | s[swz(w + 1)]) << (p & 31);
-        hi = (uint32_t)(v >> 32); lo = (uint32_t)v; wi = w + 2;
-    }
-    __device__ __forceinline__ void advance(uint32_t l) {   // 1 <= l <= 31, no refill
-        hi = __builtin_amdgcn_alignbit(hi, lo, 32 - l);
-        lo <<= l;
-        pos += l;
-    }
-    __device__ __forceinline__ void refill() {
-        const uint32_t have = 32 * wi - pos;
-        if (have <= 32) {
-            const unsigned long long t = ((unsigned long long)s[swz(wi)] << 32) >> have;
-            hi |= (uint32_t)(t >> 32); lo = (uint32_t)t; wi++;
-        }
-    }
-    __device__ __forceinline__ uint32_t bit_at(uint32_t q) const { return (s[swz(q >> 5)] >> (31 - (q & 31))) & 1; }
-};
+// The 32 stream bits that start at block-relative bit `pos`: two adjacent dwords, one 64-bit shift.
+__device__ __forceinline__ uint32_t window32(const uint32_t *s_data, uint32_t pos) {
+    const uint32_t p = grp(pos >> 5);
+    const unsigned long long v = (((unsigned long long)s_data[p] << 32) | s_data[p + 1]) << (pos & 31);
+    return (uint32_t)(v >> 32);
+}
+__device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) { return (s_data[grp(q >> 5)] >> (31 - (q & 31))) & 1; }
 
-// One codeword at the reader's position (>= K valid bits): returns the table entry's rune,
-// advances the reader WITHOUT refilling.  Long codes (flagged entries) walk the tree.
+// One codeword at `pos`: returns the rune and advances pos.  No state is carried between
+// symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
 template <bool SHORT>
-__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, BitReader &br, const uint32_t *s_lut, uint32_t lane_r) {
-    const uint32_t ent = s_lut[((br.hi >> (32 - a.K)) << a.rep_log2) | lane_r];
+__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos) {
+    const uint32_t ent = s_lut[((window32(s_data, pos) >> (32 - a.K)) << a.rep_log2) | lane_r];
     if (SHORT || !(ent & 0x80000000u)) {
-        br.advance(ent >> 24);
+        pos += ent >> 24;
         return ent & 0x1FFFFFu;
     }
     int32_t node = (int32_t)(ent & 0x7FFFFFFFu);
     uint32_t l = a.K, rune = 0;
     for (;;) {
-        const int32_t nxt = a.child[2 * node + br.bit_at(br.pos + l)];
+        const int32_t nxt = a.child[2 * node + bit_at(s_data, pos + l)];
         l++;
         if (nxt < 0) { rune = (uint32_t)(-(nxt + 1)); break; }
         if (l >= 64) { l = 65; break; }   // cannot happen for a tree accepted by the host (codes <= 64 bits)
         node = nxt;
     }
-    br.init(br.s, br.pos + l);
+    pos += l;
     return rune;
 }
 
-// Walk from block-relative bit `pos` to the first code boundary >= lim.  Two codewords are
-// decoded per refill (2*K <= 22 < 33 valid bits).  A code that runs past the end of the
-// payload can only be the last one of the walk, so that check happens once, after the loop.
+// Walk from block-relative bit `pos` to the first code boundary >= lim.  A code that runs past
+// the end of the payload can only be the last one of the walk: checked once, after the loop.
 template <bool ASCII, bool SHORT, bool MULTI>
 __device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut, uint32_t lane_r,
                                      uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
     uint32_t nb = 0;
-    BitReader br;
-    br.init(s_data, pos);
     if (MULTI) {
         // up to 3 codewords per table lookup while a whole KM-bit step stays inside the subsequence
         const uint32_t safe = lim >= KM ? lim - KM : 0;
-        while (br.pos <= safe && lim >= KM) {
-            const uint32_t e = s_mlut[br.hi >> (32 - KM)];
+        while (pos <= safe && lim >= KM) {
+            const uint32_t e = s_mlut[window32(s_data, pos) >> (32 - KM)];
             const uint32_t n = (e >> 28) & 3;
-            if (n == 0) { (void)decode_one<SHORT>(a, br, s_lut, lane_r); nb++; }   // first code longer than KM bits
-            else { br.advance((e >> 24) & 15); nb += n; }
-            br.refill();
+            if (n == 0) { (void)decode_one<SHORT>(a, s_data, s_lut, lane_r, pos); nb++; }   // first code longer than KM bits
+            else { pos += (e >> 24) & 15; nb += n; }
         }
     }
-    while (br.pos < lim) {
-        const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
-        nb += ASCII ? 1 : dev_utf8_len(r1);
-        if (br.pos < lim) {
-            const uint32_t r2 = decode_one<SHORT>(a, br, s_lut, lane_r);
-            nb += ASCII ? 1 : dev_utf8_len(r2);
-        }
-        br.refill();
+    while (pos < lim) {
+        const uint32_t r = decode_one<SHORT>(a, s_data, s_lut, lane_r, pos);
+        nb += ASCII ? 1 : dev_utf8_len(r);
     }
-    *exit_pos = br.pos > end_rel ? BAD_POS : br.pos;
+    *exit_pos = pos > end_rel ? BAD_POS : pos;
     *nbytes = nb;
 }
 
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
-    __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
+    __shared__ uint32_t s_data[DATA_PHYS];
     __shared__ uint32_t s_lut[LUT_WORDS];
     __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ uint32_t s_exit[DB];
@@ -236,13 +222,9 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
                 // decode from WARM bits ahead of the subsequence: prefix codes self-synchronise within a few
                 // codewords, so the first boundary at or after my0 is very likely the true entry
                 const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
-                BitReader br;
-                br.init(s_data, start);
-                while (br.pos < my0) {
-                    (void)decode_one<SHORT>(a, br, s_lut, lane_r);
-                    br.refill();
-                }
-                e = br.pos;
+                uint32_t q = start;
+                while (q < my0) (void)decode_one<SHORT>(a, s_data, s_lut, lane_r, q);
+                e = q;
             }
         } else {
             const uint32_t xr = a.exit_rel[g - 1];
@@ -319,37 +301,15 @@ __device__ __forceinline__ void put_rune(uint32_t rune, Put put) {   // string(r
 template <bool ASCII, bool SHORT, bool MULTI, class Put>
 __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut,
                                           uint32_t lane_r, uint32_t pos, uint32_t lim, Put put) {
-    BitReader br;
-    br.init(s_data, pos);
-    if (MULTI) {
-        const uint32_t safe = lim >= KM ? lim - KM : 0;
-        while (br.pos <= safe && lim >= KM) {
-            const uint32_t e = s_mlut[br.hi >> (32 - KM)];
-            const uint32_t n = (e >> 28) & 3;
-            if (n == 0) put(decode_one<SHORT>(a, br, s_lut, lane_r));           // first code longer than KM bits
-            else {
-                br.advance((e >> 24) & 15);
-                put(e & 0xFF);
-                if (n >= 2) put((e >> 8) & 0xFF);
-                if (n >= 3) put((e >> 16) & 0xFF);
-            }
-            br.refill();
-        }
-    }
-    while (br.pos < lim) {
-        const uint32_t r1 = decode_one<SHORT>(a, br, s_lut, lane_r);
-        if (ASCII) put(r1); else put_rune(r1, put);
-        if (br.pos < lim) {
-            const uint32_t r2 = decode_one<SHORT>(a, br, s_lut, lane_r);
-            if (ASCII) put(r2); else put_rune(r2, put);
-        }
-        br.refill();
+    while (pos < lim) {
+        const uint32_t r = decode_one<SHORT>(a, s_data, s_lut, lane_r, pos);
+        if (ASCII) put(r); else put_rune(r, put);
     }
 }
 
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
-    __shared__ uint32_t s_data[DATA_WORDS + DATA_WORDS / 32 + 2];
+    __shared__ uint32_t s_data[DATA_PHYS];
     __shared__ uint32_t s_lut[LUT_WORDS];
     __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
