@@ -48,3 +48,36 @@ def test_cpp_host_cli(tmp_path, oracle, samiam):
     assert src.read_bytes() == samiam and not rsn.exists()  # -delete defaults to true (cli.go:150)
     out = subprocess.check_output([exe, "-benchmark", str(src), "-algorithm=huffman,[lzss,huffman],dmc"]).decode()
     assert out.count("true") == 2 and "DNF" in out
+
+
+def test_concurrent_callers_are_independent(oracle, samiam):
+    """The engine runs codecs from concurrent goroutines (engine.go:235-244); librsn keeps all
+    state per calling thread, so parallel host threads must not disturb each other."""
+    import threading
+
+    import numpy as np
+    from raisin_amd import huffman, lz
+    rng = np.random.default_rng(77)
+    inputs = [rng.integers(0, 128, size=200000 + 1111 * i, dtype=np.uint8).tobytes() for i in range(4)] + [samiam * 30, samiam[:777]]
+    want_h = [oracle.huffman_compress(x) for x in inputs]
+    want_l = [oracle.lzss_compress(x[:60000]) for x in inputs]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                c = huffman.Compress(inputs[i])
+                assert c == want_h[i]
+                assert huffman.Decompress(c) == inputs[i]
+                lc = lz.CompressAsync(inputs[i][:60000])
+                assert lc == want_l[i]
+                assert lz.Decompress(lc) == inputs[i][:60000]
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
