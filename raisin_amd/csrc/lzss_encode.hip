@@ -159,6 +159,23 @@ __global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
     for (uint32_t i = tid; i < MATCH_WAVES * a.DW; i += LB) s_carry[i] = 0;
     __syncthreads();
 
+    // Shortcut for W-periodic stretches: a match on diagonal W that fills the whole window
+    // (or reaches the end of the stream) cannot be beaten -- L <= W, and W is the largest
+    // distance, i.e. the leftmost occurrence.  If that holds for every position of the strip
+    // (no mismatch fc[q] != fc[q-W] anywhere in [b0, b0+STRIP+W)), the search is skipped.
+    {
+        const long long q_end = min(b0 + (long long)MATCH_STRIP + (long long)a.W - 1, (long long)a.E);
+        bool ok = b0 >= (long long)a.W;
+        if (ok) for (long long q = b0 + tid; q < q_end; q += LB) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
+        if (__syncthreads_and(ok)) {
+            for (long long p = b0 + tid; p < min(b0 + (long long)MATCH_STRIP, (long long)a.E); p += LB) {
+                const uint32_t L = (uint32_t)min((long long)a.W, (long long)a.E - p);
+                a.keys[p] = (L << 16) | a.W;
+            }
+            return;
+        }
+    }
+
     const uint32_t Dk = wv * a.DW;                                    // this wave's diagonals: Dk+1 .. Dk+DWk
     const uint32_t DWk = Dk >= a.W ? 0 : min(a.DW, a.W - Dk);
     const uint32_t nsteps = DWk ? DWk + 63 : 0;
@@ -225,15 +242,53 @@ __global__ __launch_bounds__(LB) void k_parse_exit(const uint32_t *__restrict__ 
     for (int i = threadIdx.x; i < PT; i += LB) if (base + i < E) exit_rel[base + i] = (uint16_t)(nxt[i] - PT);
 }
 
-// serial over tiles: where does the chain that starts at position 0 enter each tile
-__global__ void k_parse_chain(const uint16_t *__restrict__ exit_rel, uint32_t n_tiles, uint32_t *__restrict__ entry) {
+// Where does the chain that starts at position 0 enter each tile?  One dependent load per
+// tile if done naively; instead tiles are grouped SUPER at a time:
+//   k_parse_super   for EVERY possible entry into a group's first tile, where the chain leaves
+//                   the group (SUPER dependent loads per entry, all entries in parallel)
+//   k_parse_chain   serial over groups only (n_tiles / SUPER dependent loads)
+//   k_parse_fill    per group, walk its SUPER tiles from the now-known entry
+constexpr int SUPER = 64;
+static_assert(MAX_WINDOW <= PT, "the chain must enter every group through its first tile");
+
+__device__ __forceinline__ unsigned long long chain_step(const uint16_t *__restrict__ exit_rel, unsigned long long pos, uint32_t t) {
+    // pos is a global position inside tile t (or beyond it): returns the first chain position >= end of tile t
+    const unsigned long long hi = (unsigned long long)(t + 1) * PT;
+    return pos >= hi ? pos : hi + exit_rel[pos];
+}
+
+__global__ __launch_bounds__(LB) void k_parse_super(const uint16_t *__restrict__ exit_rel, uint32_t n_tiles, uint32_t E,
+                                                    uint32_t *__restrict__ super_exit) {
+    const uint32_t g = blockIdx.x, t0 = g * SUPER, t1 = min(t0 + SUPER, n_tiles);
+    for (uint32_t e = threadIdx.x; e < PT; e += LB) {
+        unsigned long long pos = (unsigned long long)t0 * PT + e;
+        if (pos < E) for (uint32_t t = t0; t < t1; t++) pos = chain_step(exit_rel, pos, t);
+        super_exit[(size_t)g * PT + e] = (uint32_t)(pos - (unsigned long long)t1 * PT);   // overshoot past the group
+    }
+}
+
+__global__ void k_parse_chain(const uint32_t *__restrict__ super_exit, uint32_t n_groups, uint32_t n_tiles, unsigned long long *__restrict__ group_entry) {
     if (threadIdx.x || blockIdx.x) return;
     unsigned long long pos = 0;
-    for (uint32_t t = 0; t < n_tiles; t++) {
-        const unsigned long long hi = (unsigned long long)(t + 1) * PT;
-        if (pos >= hi) { entry[t] = NO_ENTRY; continue; }
-        entry[t] = (uint32_t)(pos - (unsigned long long)t * PT);
-        pos = hi + exit_rel[pos];
+    for (uint32_t g = 0; g < n_groups; g++) {
+        group_entry[g] = pos;                                       // global position where the chain enters (or jumps over) group g
+        const unsigned long long lo = (unsigned long long)g * SUPER * PT;
+        const unsigned long long hi = (unsigned long long)min((g + 1) * SUPER, n_tiles) * PT;
+        // a match is at most W <= PT long, so the chain always lands inside the group's FIRST tile
+        pos = hi + super_exit[(size_t)g * PT + (pos - lo)];
+    }
+}
+
+__global__ void k_parse_fill(const uint16_t *__restrict__ exit_rel, const unsigned long long *__restrict__ group_entry, uint32_t n_groups,
+                             uint32_t n_tiles, uint32_t *__restrict__ entry) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    unsigned long long pos = group_entry[g];
+    const uint32_t t0 = g * SUPER, t1 = min(t0 + SUPER, n_tiles);
+    for (uint32_t t = t0; t < t1; t++) {
+        const unsigned long long lo = (unsigned long long)t * PT;
+        entry[t] = pos >= lo + PT ? NO_ENTRY : (uint32_t)(pos - lo);
+        pos = chain_step(exit_rel, pos, t);
     }
 }
 
@@ -374,7 +429,15 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
     uint32_t *d_flags = d_entry + n_pt;
     RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
-    RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_exit, n_pt, d_entry);
+    {
+        const uint32_t n_groups = (uint32_t)ceil_div(n_pt, SUPER);
+        void *q; rc = dev_buf(c, 17, (size_t)n_groups * PT * 4 + (size_t)n_groups * 8 + 64, &q); if (rc) return rc;
+        uint32_t *d_super = (uint32_t *)q;
+        unsigned long long *d_gentry = (unsigned long long *)(d_super + (size_t)n_groups * PT);
+        RSN_LAUNCH("lzss_parse_super", k_parse_super, dim3(n_groups), dim3(LB), 0, s, d_exit, n_pt, E, d_super);
+        RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry);
+        RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
+    }
     RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_entry, d_flags, d_tbytes);
     RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
     RSN_HIP(hipMemcpyAsync(h64, d_ttot, 8, hipMemcpyDeviceToHost, s));
