@@ -215,6 +215,127 @@ __global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ E2': packed match search (lengths only)
+// Same sweep as k_match with two diagonals per lane packed in the 16-bit halves of one VGPR
+// (v_pk_* arithmetic): lane l meets diagonals Dk+1+j (low half) and Dk+H+1+j (high half),
+// j = t-63+l, so a wave's diagonal range takes half the steps.  Only the capped run length
+// survives packing (the 16-bit maximum cannot carry the distance); the distance of the few
+// positions that end up on the parse chain with a token-sized match is recovered afterwards
+// (k_parse_mark), which costs far less than carrying it through every (position, diagonal) pair.
+constexpr int MW2 = 4;                  // wavefronts per block of the packed sweep: fewer, longer diagonal ranges (less pipeline fill)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+template <bool MASKED, bool CHECKED>
+__device__ __forceinline__ void match2_chunk(const uint8_t *ybase, long long y0, uint32_t H, uint32_t E, uint32_t t0, uint32_t nsteps,
+                                             uint32_t Hk_lo, uint32_t Hk_hi, int lane, uint32_t X2, uint32_t vCin, uint32_t &vCout,
+                                             uint32_t &C2, uint32_t &D2, uint32_t &best2) {
+    const us2 one = {1, 1};
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const uint32_t t = t0 + k;
+        if (!MASKED || t < nsteps) {
+            uint32_t Ylo = ybase[-(int)t], Yhi = ybase[-(int)t - (int)H];
+            if (CHECKED) {
+                const long long y = y0 - (long long)t;
+                if (y < 0 || y >= (long long)E) Ylo = 0x200;
+                if (y - (long long)H < 0 || y - (long long)H >= (long long)E) Yhi = 0x200;
+            }
+            const uint32_t Y2 = Ylo | (Yhi << 16);
+            const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
+            const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)cin, (int)C2, RSN_DPP_WAVE_SHL1, 0xF, 0xF, false);
+            us2 m = __builtin_elementwise_sub_sat(one, as_us2(X2 ^ Y2));            // 1 where the bytes are equal
+            if (MASKED) {
+                const uint32_t j = t + (uint32_t)lane - 63u;                          // local diagonal index of this lane
+                const uint32_t vm = (j < Hk_lo ? 0x0000FFFFu : 0u) | (j < Hk_hi ? 0xFFFF0000u : 0u);
+                m = as_us2(as_u32(m) & vm);
+            }
+            D2 = as_u32(as_us2(D2) + one);                                            // per-half add: a wrapping low half must not carry
+            uint32_t grown;                                                          // (run + 1) * eq in one v_pk_mad_u16
+            asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(grown) : "v"(sh), "v"(as_u32(m)));
+            const us2 c = __builtin_elementwise_min(as_us2(grown), as_us2(D2));      // eq ? min(run+1, d) : 0
+            C2 = as_u32(c);
+            best2 = as_u32(__builtin_elementwise_max(as_us2(best2), c));
+        }
+        vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)C2, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
+    }
+}
+
+__global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t W4 = a.DW * MW2 + 16;                      // lead-in of the staged region (+16: the high half of an odd DW reads one byte further)
+    const uint32_t WUB = (a.W + 63) / 64 * 64;
+    const uint32_t RLEN = (MATCH_STRIP + WUB + W4 + 15) & ~15u;
+    const uint32_t H = (a.DW + 1) / 2;                                // diagonals per half
+    uint8_t *s_b = smem;
+    uint32_t *s_carry = reinterpret_cast<uint32_t *>(smem + RLEN);    // [MW2][H] packed runs entering from the block above
+    uint32_t *s_comb = s_carry + MW2 * H;                     // [2][MW2][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
+    const long long r0 = b0 - (long long)W4;
+    for (uint32_t i = tid; i < RLEN; i += MW2 * 64) {
+        const long long p = r0 + i;
+        s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0;
+    }
+    for (uint32_t i = tid; i < MW2 * H; i += MW2 * 64) s_carry[i] = 0;
+    __syncthreads();
+    {   // W-periodic strip: nothing to search (see k_match)
+        const long long q_end = min(b0 + (long long)MATCH_STRIP + (long long)a.W - 1, (long long)a.E);
+        bool ok = b0 >= (long long)a.W;
+        if (ok) for (long long q = b0 + tid; q < q_end; q += MW2 * 64) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
+        if (__syncthreads_and(ok)) {
+            for (long long p = b0 + tid; p < min(b0 + (long long)MATCH_STRIP, (long long)a.E); p += MW2 * 64) {
+                const uint32_t L = (uint32_t)min((long long)a.W, (long long)a.E - p);
+                a.keys[p] = (L << 16) | a.W;
+            }
+            return;
+        }
+    }
+    const uint32_t Dk = wv * a.DW;                                    // this wave: diagonals Dk+1 .. Dk+DWk
+    const uint32_t DWk = Dk >= a.W ? 0 : min(a.DW, a.W - Dk);
+    const uint32_t Hk_lo = min(H, DWk), Hk_hi = DWk > H ? DWk - H : 0; // valid local indices in each half
+    const uint32_t nsteps = Hk_lo ? Hk_lo + 63 : 0;
+    uint32_t *carry = s_carry + wv * H;
+    const int nPB = (int)((MATCH_STRIP + WUB) / 64);
+
+    for (int pb = nPB - 1; pb >= 0; pb--) {
+        const long long P0 = b0 + 64ll * pb;
+        if (P0 >= (long long)a.E) continue;
+        const long long p = P0 + lane;
+        const uint32_t X = p < (long long)a.E ? (uint32_t)s_b[p - r0] : 0x300u;
+        const uint32_t X2 = X | (X << 16);
+        uint32_t best2 = 0, C2 = 0;
+        // lane l meets local index j = t-63+l: diagonals Dk+1+j (low) and Dk+H+1+j (high); D2 holds both, one step behind
+        const uint32_t d0 = Dk + (uint32_t)lane - 63u;                // diagonal of the low half before the first increment
+        uint32_t D2 = (d0 & 0xFFFFu) | (((d0 + H) & 0xFFFFu) << 16);
+        const long long y0 = P0 + 62 - (long long)Dk;                 // candidate index of the low half at t = 0
+        const uint8_t *ybase = s_b + (y0 - r0);
+        const bool checked = P0 < (long long)W4 || P0 + 63 >= (long long)a.E;
+        for (uint32_t t0 = 0; t0 < nsteps; t0 += 64) {
+            const uint32_t ci = t0 + lane;
+            const uint32_t vCin = ci < Hk_lo ? carry[ci] : 0u;
+            uint32_t vCout = 0;
+            if (checked) match2_chunk<true, true>(ybase, y0, H, a.E, t0, nsteps, Hk_lo, Hk_hi, lane, X2, vCin, vCout, C2, D2, best2);
+            else if (t0 >= 63 && t0 + 64 <= Hk_hi) match2_chunk<false, false>(ybase, y0, H, a.E, t0, nsteps, Hk_lo, Hk_hi, lane, X2, vCin, vCout, C2, D2, best2);
+            else match2_chunk<true, false>(ybase, y0, H, a.E, t0, nsteps, Hk_lo, Hk_hi, lane, X2, vCin, vCout, C2, D2, best2);
+            const uint32_t co = t0 - (uint32_t)lane;                  // value of step k sits in lane 63-k
+            if (co < Hk_lo) carry[co] = vCout;
+        }
+        uint32_t *comb = s_comb + (pb & 1) * (MW2 * 64);
+        comb[wv * 64 + lane] = max(best2 & 0xFFFFu, best2 >> 16);
+        __syncthreads();
+        if (wv == 0 && pb < MATCH_STRIP / 64 && p < (long long)a.E) {
+            uint32_t L = comb[lane];
+#pragma unroll
+            for (int w = 1; w < MW2; w++) L = max(L, comb[w * 64 + lane]);
+            a.keys[p] = L << 16;                                      // distance filled in later for chain positions that need it
+        }
+    }
+}
+
 // ------------------------------------------------------------------ E3: greedy chain
 __device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len) {   // len("<off,len>"), lzss.go:318-320
     auto digits = [](uint32_t v) { return v < 10 ? 1u : v < 100 ? 2u : v < 1000 ? 3u : v < 10000 ? 4u : 5u; };
@@ -292,13 +413,71 @@ __global__ void k_parse_fill(const uint16_t *__restrict__ exit_rel, const unsign
     }
 }
 
-// walk the tile's part of the chain, flag the visited positions, count the output bytes
-__global__ __launch_bounds__(LB) void k_parse_mark(const uint32_t *__restrict__ keys, uint32_t E, const uint32_t *__restrict__ entry,
-                                                   uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+// The distance of a match whose length is already known: the LARGEST d <= min(i,W) with
+// fc[i-d : i-d+L] == fc[i : i+L] and d >= L (leftmost occurrence, bytes.Index lzss.go:419).
+// One wavefront scans 64 candidate distances per step from the far end of the window; the
+// bytes come from the tile image in LDS (sb[k] = fc[org + k]).
+__device__ __forceinline__ uint32_t leftmost_distance(const uint8_t *sb, uint32_t org, uint32_t i, uint32_t L, uint32_t W, int lane) {
+    const uint32_t dmax = min(i, W);
+    const uint32_t mi = i - org;                                  // index of fc[i] in the tile image
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(sb);
+    auto load4 = [&](uint32_t k) {                                // 4 bytes at any byte index: two aligned dwords + v_alignbyte
+        const uint32_t w0 = sw[k >> 2], w1 = sw[(k >> 2) + 1];
+        return __builtin_amdgcn_alignbyte(w1, w0, k & 3);
+    };
+    const uint32_t pat4 = load4(mi);                              // L >= 6: the first four bytes filter the candidates
+    auto verify = [&](uint32_t ci) {                              // bytes 4..L-1, four at a time
+        uint32_t q = 4;
+        while (q + 4 <= L && load4(ci + q) == load4(mi + q)) q += 4;
+        if (q + 4 <= L) return false;
+        if (q < L) return ((load4(ci + q) ^ load4(mi + q)) & (0xFFFFFFFFu >> (8 * (4 - (L - q))))) == 0;
+        return true;
+    };
+    // 256 candidates per round (4 per lane, loads issued together), farthest first
+    for (uint32_t c0 = 0; c0 + L <= dmax; c0 += 256) {
+        uint32_t f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) f[u] = load4(mi - dmax + c0 + u * 64 + (uint32_t)lane);   // may read a few bytes past the window: inside the image
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t off = c0 + u * 64 + (uint32_t)lane;
+            bool ok = off + L <= dmax && f[u] == pat4;
+            if (ok) ok = verify(mi - dmax + off);
+            const unsigned long long hit = __ballot(ok);
+            if (hit) return dmax - (c0 + u * 64 + (uint32_t)__builtin_ctzll(hit));
+        }
+    }
+    return 0;                                                      // unreachable: L was produced by some diagonal
+}
+
+// walk the tile's part of the chain, flag the visited positions, complete the keys of the
+// visited positions whose match is long enough to become a token, count the output bytes
+__global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ fc, uint32_t *__restrict__ keys, uint32_t E, uint32_t W,
+                                                   const uint32_t *__restrict__ entry, uint32_t *__restrict__ flags,
+                                                   unsigned long long *__restrict__ tile_bytes, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_bytes[];   // fc[base-W, base+PT+W): window before, longest match after
     __shared__ uint16_t nxt[PT];
     __shared__ uint32_t fl[PT / 32];
     __shared__ uint32_t part[LB / 64];
+    __shared__ uint16_t need[PT / 6 + 8];             // chain positions whose distance is still unknown (matches of >= 6: at most PT/6)
+    __shared__ uint32_t n_need;
     const uint32_t base = blockIdx.x * PT;
+    const uint32_t org = (base >= W ? base - W : 0) & ~15u;        // 16-byte aligned start of the tile image
+    const uint32_t span = min(base + PT + W, E) - org;
+    (void)dbg;
+    {   // full 16-byte units first (loads issued together), then the ragged tail
+        const uint32_t nv = span / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(fc + org);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_bytes);
+        for (uint32_t i0 = 0; i0 < nv; i0 += 4 * LB) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + k * LB + threadIdx.x; if (i < nv) v[k] = src[i]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t i = i0 + k * LB + threadIdx.x; if (i < nv) dst[i] = v[k]; }
+        }
+        for (uint32_t i = nv * 16 + threadIdx.x; i < span; i += LB) s_bytes[i] = fc[org + i];
+    }
     for (int i = threadIdx.x; i < PT; i += LB) {
         const uint32_t p = base + i;
         uint32_t L = p < E ? keys[p] >> 16 : 1;
@@ -306,11 +485,28 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint32_t *__restrict__ 
         nxt[i] = (uint16_t)(i + L);
     }
     for (int i = threadIdx.x; i < PT / 32; i += LB) fl[i] = 0;
+    if (threadIdx.x == 0) n_need = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t i = entry[blockIdx.x];
+        uint32_t i = entry[blockIdx.x], nn = 0;
         const uint32_t lim = min((uint32_t)PT, E - base);
-        while (i < lim) { fl[i >> 5] |= 1u << (i & 31); i = nxt[i]; }
+        while (i < lim) {
+            fl[i >> 5] |= 1u << (i & 31);
+            const uint32_t j = nxt[i];
+            if (j - i >= 6) need[nn++] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143)
+            i = j;
+        }
+        n_need = nn;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t k = wv; k < n_need; k += LB / 64) {
+        const uint32_t p = base + need[k];
+        const uint32_t key = keys[p];
+        if ((key & 0xFFFF) == 0) {
+            const uint32_t d = leftmost_distance(s_bytes, org, p, key >> 16, W, lane);
+            if (lane == 0) keys[p] = key | d;
+        }
     }
     __syncthreads();
     uint32_t bytes = 0;
@@ -418,7 +614,21 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             attr_set = shmem;
         }
-        RSN_LAUNCH("lzss_match", k_match, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(LB), shmem, s, ma);
+        static const bool unpacked = getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: the 32-bit (length+distance) sweep
+        if (unpacked) {
+            RSN_LAUNCH("lzss_match", k_match, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(LB), shmem, s, ma);
+        } else {
+            MatchArgs m2 = ma;
+            m2.DW = (W + MW2 - 1) / MW2;
+            const uint32_t W4b = m2.DW * MW2 + 16;
+            const size_t shmem2 = (size_t)((MATCH_STRIP + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
+            static thread_local size_t attr2_set = 0;
+            if (shmem2 > attr2_set) {
+                RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+                attr2_set = shmem2;
+            }
+            RSN_LAUNCH("lzss_match", k_match2, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(MW2 * 64), shmem2, s, m2);
+        }
     }
     // ---- E3
     const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
@@ -438,7 +648,12 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry);
         RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
     }
-    RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_entry, d_flags, d_tbytes);
+    {
+        const size_t sh = (size_t)PT + 2 * (size_t)W + 48;
+        static thread_local size_t mark_attr = 0;
+        if (sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); mark_attr = sh; }
+        RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, getenv("RSN_DBG") ? atoi(getenv("RSN_DBG")) : 0);
+    }
     RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
     RSN_HIP(hipMemcpyAsync(h64, d_ttot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
