@@ -461,10 +461,56 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
     __shared__ uint32_t part[LB / 64];
     __shared__ uint16_t need[PT / 6 + 8];             // chain positions whose distance is still unknown (matches of >= 6: at most PT/6)
     __shared__ uint32_t n_need;
+    __shared__ uint16_t seg_entry[PT / 128];
     const uint32_t base = blockIdx.x * PT;
     const uint32_t org = (base >= W ? base - W : 0) & ~15u;        // 16-byte aligned start of the tile image
     const uint32_t span = min(base + PT + W, E) - org;
     (void)dbg;
+    for (int i = threadIdx.x; i < PT; i += LB) {
+        const uint32_t p = base + i;
+        uint32_t L = p < E ? keys[p] >> 16 : 1;
+        if (L == 0) L = 1;
+        nxt[i] = (uint16_t)(i + L);
+    }
+    for (int i = threadIdx.x; i < PT / 32; i += LB) fl[i] = 0;
+    if (threadIdx.x == 0) n_need = 0;
+    __syncthreads();
+    // The chain inside the tile, without a serial walk over up to PT positions: (1) pointer jumping
+    // gives, for every position, where its chain leaves its 128-position segment; (2) one lane
+    // hops over the 64 segments to find each segment's entry; (3) 64 lanes walk their own segment.
+    constexpr int SEG = 128;
+    uint16_t *sx = reinterpret_cast<uint16_t *>(s_bytes);          // where the chain from each position leaves its segment (the byte image is staged afterwards)
+    for (int i = threadIdx.x; i < PT; i += LB) sx[i] = nxt[i];
+    __syncthreads();
+    for (int round = 0; round < 7; round++) {                       // 2^7 = SEG hops
+        for (int i = threadIdx.x; i < PT; i += LB) {
+            const uint32_t j = sx[i];
+            if (j < (uint32_t)((i / SEG + 1) * SEG)) sx[i] = sx[j];
+        }
+        __syncthreads();
+    }
+    const uint32_t lim = min((uint32_t)PT, E - base);
+    if (threadIdx.x == 0) {
+        uint32_t e = entry[blockIdx.x];
+        for (int sgm = 0; sgm < PT / SEG; sgm++) {
+            const uint32_t hi = (sgm + 1) * SEG;
+            if (e >= hi) { seg_entry[sgm] = 0xFFFF; continue; }
+            seg_entry[sgm] = (uint16_t)e;
+            e = sx[e];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < PT / SEG) {
+        uint32_t i = seg_entry[threadIdx.x];
+        const uint32_t hi = min((threadIdx.x + 1) * SEG, lim);
+        while (i < hi) {                                             // this lane owns the flag words of its segment
+            fl[i >> 5] |= 1u << (i & 31);
+            const uint32_t j = nxt[i];
+            if (j - i >= 6) need[atomicAdd(&n_need, 1u)] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143)
+            i = j;
+        }
+    }
+    __syncthreads();                                                 // sx is dead: the same LDS now receives the byte image
     {   // full 16-byte units first (loads issued together), then the ragged tail
         const uint32_t nv = span / 16;
         const uint4 *src = reinterpret_cast<const uint4 *>(fc + org);
@@ -477,26 +523,6 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
             for (int k = 0; k < 4; k++) { const uint32_t i = i0 + k * LB + threadIdx.x; if (i < nv) dst[i] = v[k]; }
         }
         for (uint32_t i = nv * 16 + threadIdx.x; i < span; i += LB) s_bytes[i] = fc[org + i];
-    }
-    for (int i = threadIdx.x; i < PT; i += LB) {
-        const uint32_t p = base + i;
-        uint32_t L = p < E ? keys[p] >> 16 : 1;
-        if (L == 0) L = 1;
-        nxt[i] = (uint16_t)(i + L);
-    }
-    for (int i = threadIdx.x; i < PT / 32; i += LB) fl[i] = 0;
-    if (threadIdx.x == 0) n_need = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t i = entry[blockIdx.x], nn = 0;
-        const uint32_t lim = min((uint32_t)PT, E - base);
-        while (i < lim) {
-            fl[i >> 5] |= 1u << (i & 31);
-            const uint32_t j = nxt[i];
-            if (j - i >= 6) need[nn++] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143)
-            i = j;
-        }
-        n_need = nn;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -649,7 +675,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
     }
     {
-        const size_t sh = (size_t)PT + 2 * (size_t)W + 48;
+        const size_t sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
         static thread_local size_t mark_attr = 0;
         if (sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); mark_attr = sh; }
         RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, getenv("RSN_DBG") ? atoi(getenv("RSN_DBG")) : 0);
