@@ -136,6 +136,22 @@ def main():
         from raisin_amd import shard
         t_max = shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
 
+    # context for the roofline: what a plain device-to-device copy and a read-only pass reach on THIS GPU
+    # (torch kernels, timed with torch events on torch's stream; not part of the timed region above)
+    def _rate(fn, nbytes, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return nbytes / (e0.elapsed_time(e1) / reps) / 1e6
+    copy_gbps = _rate(lambda: dec_buf[:n].copy_(src), 2 * n)
+    read_gbps = _rate(lambda: src.view(torch.int64).sum(), n)
+
     lossless = bool(d.numel() == n and torch.equal(d, src))
     comp_n = int(c.numel())
 
@@ -190,6 +206,7 @@ def main():
             "encode_frac_of_hbm_peak_2N_plus_C": round((2 * n + C) / (enc_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
             "encode_input_read_frac_of_hbm_peak": round(n / (enc_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
             "ratio_pct": round(100.0 * C / n, 3), "lossless": lossless,
+            "hbm_calibration_GBps": {"torch_copy_read_plus_write": round(copy_gbps, 1), "torch_read_only_sum": round(read_gbps, 1)},
             "roofline": roofline, "kernels": kernels,
         }
         if gather_ms is not None:

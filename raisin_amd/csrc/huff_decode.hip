@@ -379,11 +379,14 @@ constexpr int FLAT_SYMS = DB * FLAT_LANE_SYMS;                  // symbols per b
 template <int L>
 __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     constexpr int WORDS = DB * L + 2;
-    constexpr int RL = (L <= 7) ? 5 : (12 - L);                 // LUT copies: 32 for small tables, total <= 4 KiB
+    constexpr int RL = 5;                                       // 32 dword copies per entry: the copy index IS the bank
     __shared__ uint32_t s_data[WORDS + WORDS / 32 + 2];
-    __shared__ uint8_t s_lut[(1 << L) << RL];
+    __shared__ uint32_t s_lut[(1 << L) << RL];
     const int tid = threadIdx.x;
-    const unsigned long long sym0 = (unsigned long long)blockIdx.x * FLAT_SYMS;
+    for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = a.lut[i >> RL];
+    const uint32_t n_chunks = (uint32_t)((a.n_sym + FLAT_SYMS - 1) / FLAT_SYMS);
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // persistent: the table is staged once
+    const unsigned long long sym0 = (unsigned long long)chunk * FLAT_SYMS;
     const unsigned long long bit0 = a.p0 + sym0 * L;            // FLAT_SYMS*L is a multiple of 32: bit0 % 32 == p0 % 32
     const size_t w0 = (size_t)(bit0 >> 5);
     const uint32_t o0 = (uint32_t)(bit0 & 31);
@@ -404,10 +407,9 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
             s_data[swz(i)] = v;
         }
     }
-    for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = a.lut[i >> RL];
     __syncthreads();
     const unsigned long long s_first = sym0 + (unsigned long long)tid * FLAT_LANE_SYMS;
-    if (s_first >= a.n_sym) return;
+    if (s_first < a.n_sym) {
     const uint32_t lane_r = tid & ((1u << RL) - 1);
     uint32_t w[L + 1], v[L];
 #pragma unroll
@@ -432,6 +434,9 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     } else {
         const uint32_t cnt = (uint32_t)(a.n_sym - s_first);
         for (uint32_t k = 0; k < cnt; k++) dst[k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    }
+    }
+    __syncthreads();                                               // s_data is restaged by the next chunk
     }
 }
 
@@ -545,7 +550,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         FlatArgs fa{};
         fa.base = d_in + A0; fa.nbytes = n - A0; fa.p0 = 8ull * (pay - A0) + diff; fa.n_sym = n_sym;
         fa.lut = (const uint8_t *)p; fa.out = d_out;
-        const dim3 grid((uint32_t)ceil_div((size_t)n_sym, FLAT_SYMS));
+        const dim3 grid((uint32_t)std::min<size_t>(ceil_div((size_t)n_sym, FLAT_SYMS), 256 * 8));
         switch (L) {
 #define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(DB), 0, s, fa); break;
             RSN_FLAT_CASE(1) RSN_FLAT_CASE(2) RSN_FLAT_CASE(3) RSN_FLAT_CASE(4) RSN_FLAT_CASE(5) RSN_FLAT_CASE(6)

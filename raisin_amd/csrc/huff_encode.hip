@@ -271,13 +271,15 @@ __global__ void k_emit_init(uint32_t *__restrict__ out_words, const unsigned lon
 
 // ---------------------------------------------------------------- K5: emit
 template <int MODE> struct EmitCfg;
-template <> struct EmitCfg<MODE_ASCII> { static constexpr int MAXLEN = 26; };
+constexpr int TAB_LEN_SHIFT = 24;                      // table entry = len<<24 | code: the length is the top BYTE (SDWA operand)
+constexpr uint32_t TAB_CODE_MASK = (1u << TAB_LEN_SHIFT) - 1;
+template <> struct EmitCfg<MODE_ASCII> { static constexpr int MAXLEN = TAB_LEN_SHIFT; };
 template <> struct EmitCfg<MODE_ASCII_WIDE> { static constexpr int MAXLEN = 64; };
 template <> struct EmitCfg<MODE_RUNE> { static constexpr int MAXLEN = 64; };
 
 struct EmitArgs {
     const uint8_t *in; size_t n;
-    const uint32_t *tab32;               // MODE_ASCII: 256 x (len<<26 | code)
+    const uint32_t *tab32;               // MODE_ASCII: 256 x (len<<24 | code)
     const unsigned long long *code64;    // WIDE: [256]; RUNE: [kMaxRune]
     const uint8_t *len8;                 // WIDE: [256]; RUNE: [kMaxRune]
     const unsigned long long *tile_off;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     e[k] = s_tab[(((w4[k >> 2] >> (8 * (k & 3))) & 0x7F) * TREP) | trep];
-                    mylen += e[k] >> 26;
+                    mylen += e[k] >> TAB_LEN_SHIFT;
                 }
             } else {
 #pragma unroll
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
                     if (MODE == MODE_ASCII) {
                         const uint32_t ent = ((smask >> k) & 1) ? s_tab[((b & 0x7F) * TREP) | trep] : 0;
                         e[k] = ent;
-                        mylen += ent >> 26;
+                        mylen += ent >> TAB_LEN_SHIFT;
                     } else {
                         if ((smask >> k) & 1) mylen += s_len[b];
                     }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
         pk.start(s_win, fill + wpre + incl - mylen);
         if (MODE == MODE_ASCII) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) pk.put(e[k] & 0x3FFFFFFu, e[k] >> 26);
+            for (int k = 0; k < 16; k++) pk.put(e[k] & TAB_CODE_MASK, e[k] >> TAB_LEN_SHIFT);
         } else if (MODE == MODE_ASCII_WIDE) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- K5a: emit, ASCII alphabet, codes <= 26 bits
+// ---------------------------------------------------------------- K5a: emit, ASCII alphabet, codes <= 24 bits
 // The hot kernel.  Same bit layout and hand-over rules as k_emit, tuned for issue slots
 // (the kernel is VALU-issue-bound, profiles/): 32 symbols per lane and round halve the
 // per-round work (scan, barriers, flush), full rounds are branch-free, and the flush pass
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
 template <int A32_SPL>                      // symbols per lane per round (multiple of 16)
 __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
     constexpr int A32_ROUND = HB * A32_SPL;
-    constexpr int A32_WIN = A32_ROUND * 26 / 32 + 8;
+    constexpr int A32_WIN = A32_ROUND * TAB_LEN_SHIFT / 32 + 8;
     constexpr int NV = A32_SPL / 16;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[A32_WIN];
     __shared__ uint32_t s_tab[128];
@@ -505,14 +507,14 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
 #pragma unroll
             for (int k = 0; k < A32_SPL; k++) {
                 e[k] = s_tab[(w[k >> 2] >> (8 * (k & 3))) & 0x7F];
-                mylen += e[k] >> 26;
+                mylen += e[k] >> TAB_LEN_SHIFT;
             }
         } else {
             // last, partial round of the input
 #pragma unroll
             for (int k = 0; k < A32_SPL; k++) {
                 e[k] = (P + k < in1) ? s_tab[a.in[P + k] & 0x7F] : 0;
-                mylen += e[k] >> 26;
+                mylen += e[k] >> TAB_LEN_SHIFT;
             }
         }
         const uint32_t incl = wave_incl_scan(mylen);
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
         Packer pk;
         pk.start(s_win, fill + wpre + incl - mylen);
 #pragma unroll
-        for (int k = 0; k < A32_SPL; k++) pk.put(e[k] & 0x3FFFFFFu, e[k] >> 26);
+        for (int k = 0; k < A32_SPL; k++) pk.put(e[k] & TAB_CODE_MASK, e[k] >> TAB_LEN_SHIFT);
         if (mylen) pk.finish();
         __syncthreads();
         // drain complete 16-byte units and clear them behind us
@@ -561,6 +563,107 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
         const uint32_t v = __builtin_bswap32(s_win[tid]);
         if (v) atomicOr(a.out_words + win_unit * 4 + tid, v);
     }
+}
+
+// ---------------------------------------------------------------- K5f: emit, flat code
+// Every code has the same length L (balanced tree: alphabets of 2^L near-equal symbols,
+// config 2a).  Bit offsets are arithmetic: no per-tile bit counts, no scan, no LDS bit window.
+// A lane packs 32 symbols into exactly L words with compile-time field positions; the
+// stream's start phase (base_bits % 32) is one block-uniform funnel shift against the last
+// word of the lane before.  Every output word has ONE owner (plain stores); only the word
+// that also holds header bytes is merged with atomicOr.
+struct FlatEmitArgs {
+    const uint8_t *in; size_t n;
+    const uint8_t *codes;                // 128 bytes: symbol -> L-bit code
+    unsigned long long base_bits;        // bit position of the first code bit in out
+    uint32_t *out_words;
+};
+constexpr int FE_SPL = 32;
+constexpr int FE_SYMS = HB * FE_SPL;     // symbols per block
+
+template <int L>
+__global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
+    __shared__ uint32_t s_code[128 * 32];                         // 32 dword copies per symbol: the copy index IS the bank
+    __shared__ uint32_t s_o[HB * L + HB * L / 32 + 2];            // block's output words (swizzled), drained coalesced
+    __shared__ uint32_t s_last[HB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 128 * 32; i += HB) s_code[i] = a.codes[i >> 5];
+    __syncthreads();
+    const uint32_t rep = tid & 31;
+    const uint32_t n_chunks = (uint32_t)((a.n + FE_SYMS - 1) / FE_SYMS);
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // persistent: the code table is staged once
+    const size_t s0 = (size_t)chunk * FE_SYMS + (size_t)tid * FE_SPL;
+    auto pack32 = [&](size_t first, uint32_t *v) {                // 32 symbols at `first` -> L big-endian words
+        uint32_t w[8];
+        if (first + 32 <= a.n) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.in + first);
+            const uint4 x = src[0], y = src[1];
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = 0;
+            for (int k = 0; k < 32 && first + k < a.n; k++) w[k >> 2] |= (uint32_t)a.in[first + k] << (8 * (k & 3));
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) v[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            uint32_t code = s_code[(((w[k >> 2] >> (8 * (k & 3))) & 0x7F) << 5) | rep];
+            if (first + 32 > a.n && first + k >= a.n) code = 0;   // past the end of the input: zero bits
+            const int bp = k * L, wi = bp >> 5, sh = bp & 31;
+            if (sh + L <= 32) v[wi] |= code << (32 - sh - L);
+            else { v[wi] |= code >> (sh + L - 32); v[wi + 1 < L ? wi + 1 : wi] |= code << (64 - sh - L); }
+        }
+    };
+    uint32_t v[L];
+    if (s0 < a.n) pack32(s0, v);
+    else {
+#pragma unroll
+        for (int j = 0; j < L; j++) v[j] = 0;
+    }
+    // last word of the previous lane's group: DPP inside the wavefront, LDS across wavefronts,
+    // recomputed from the input across blocks
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[L - 1], 0x138, 0xF, 0xF, false);   // wave_shr:1
+    if (lane == 63) s_last[wv] = v[L - 1];
+    __syncthreads();
+    if (lane == 0) {
+        if (wv > 0) prev = s_last[wv - 1];
+        else if (chunk > 0) { uint32_t pv[L]; pack32(s0 - 32, pv); prev = pv[L - 1]; }
+        else prev = 0;                                            // in front of the stream: header bytes, merged below
+    }
+    const uint32_t o0 = (uint32_t)(a.base_bits & 31);
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const uint32_t hi = j ? v[j - 1] : prev;
+        const uint32_t ow = (uint32_t)((((unsigned long long)hi << 32) | v[j]) >> o0);   // (hi << (32-o0)) | (v[j] >> o0)
+        const uint32_t i = tid * L + j;
+        s_o[i + (i >> 5)] = __builtin_bswap32(ow);
+    }
+    __syncthreads();
+    // drain: the block's HB*L words are contiguous in the output
+    const unsigned long long total_syms = a.n;
+    const unsigned long long wbase = (a.base_bits >> 5) + (unsigned long long)chunk * (HB * L);
+    const unsigned long long end_word = (a.base_bits + total_syms * L + 31) >> 5;                 // one past the last word holding stream bits
+    for (int i = tid; i < HB * L; i += HB) {
+        const unsigned long long g = wbase + i;
+        if (g >= end_word) break;
+        const uint32_t val = s_o[i + (i >> 5)];
+        if (g == (a.base_bits >> 5)) { if (val) atomicOr(a.out_words + g, val); }   // shares its dword with header bytes
+        else a.out_words[g] = val;
+    }
+    // the word after the block holds the low o0 bits of this block's last logical word; the NEXT block writes it
+    // (as its first word) unless this is the last block
+    if (o0 && tid == HB - 1) {
+        const unsigned long long g = wbase + (unsigned long long)(HB * L);
+        const bool last_block = chunk + 1 == n_chunks;
+        if (last_block && g < end_word) a.out_words[g] = __builtin_bswap32(v[L - 1] << (32 - o0));
+    }
+    __syncthreads();                                               // s_o / s_last are reused by the next chunk
+    }
+}
+
+__global__ void k_zero_unit(uint32_t *out_words, unsigned long long unit) {
+    if (threadIdx.x < 4) out_words[unit * 4 + threadIdx.x] = 0;
 }
 
 // ======================================================================= host side
@@ -654,7 +757,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
 
     // ---- code tables
-    const int mode = !ascii ? MODE_RUNE : (codes.max_len <= 26 ? MODE_ASCII : MODE_ASCII_WIDE);
+    const int mode = !ascii ? MODE_RUNE : (codes.max_len <= (unsigned)TAB_LEN_SHIFT ? MODE_ASCII : MODE_ASCII_WIDE);
     EmitArgs a{};
     uint8_t *d_len8 = nullptr;
     if (mode == MODE_RUNE) {
@@ -675,7 +778,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         for (uint32_t i = 0; i < tree.n_leaves; i++) {
             const uint32_t r = tree.rune[i];
             ht->c64[r] = codes.code[i]; ht->l8[r] = codes.len[i];
-            if (codes.max_len <= 26) ht->t32[r] = ((uint32_t)codes.len[i] << 26) | (uint32_t)codes.code[i];
+            if (codes.max_len <= (unsigned)TAB_LEN_SHIFT) ht->t32[r] = ((uint32_t)codes.len[i] << TAB_LEN_SHIFT) | (uint32_t)codes.code[i];
         }
         rc = dev_buf(c, 3, sizeof(Tab), &p); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(p, ht, sizeof(Tab), hipMemcpyHostToDevice, s));
@@ -684,6 +787,30 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         d_len8 = dt->l8;
     }
     a.len8 = d_len8;
+
+    // ---- flat code: offsets are arithmetic
+    static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
+    if (mode == MODE_ASCII && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat_emit) {
+        const unsigned L = codes.max_len;
+        void *hp2; rc = pinned_buf(c, 256, &hp2); if (rc) return rc;
+        uint8_t *hcodes = (uint8_t *)hp2;
+        memset(hcodes, 0, 128);
+        for (uint32_t i = 0; i < tree.n_leaves; i++) hcodes[tree.rune[i]] = (uint8_t)codes.code[i];
+        rc = dev_buf(c, 3, 256, &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, hcodes, 128, hipMemcpyHostToDevice, s));
+        FlatEmitArgs fa{d_in, n, (const uint8_t *)p, base_bits, (uint32_t *)d_out};
+        RSN_LAUNCH("huff_emit_init", k_zero_unit, dim3(1), dim3(64), 0, s, (uint32_t *)d_out, base_bits >> 7);
+        RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+        const dim3 grid((uint32_t)std::min<size_t>(ceil_div(n, FE_SYMS), 256 * 8));
+        switch (L) {
+#define RSN_FE(LL) case LL: RSN_LAUNCH("huff_emit", k_emit_flat<LL>, grid, dim3(HB), 0, s, fa); break;
+            RSN_FE(1) RSN_FE(2) RSN_FE(3) RSN_FE(4) RSN_FE(5) RSN_FE(6) RSN_FE(7)
+#undef RSN_FE
+            default: break;
+        }
+        RSN_HIP(hipStreamSynchronize(s));
+        return RSN_OK;
+    }
 
     // ---- tile bit offsets
     rc = dev_buf(c, 4, ((size_t)n_tiles * 2 + 2) * 8, &p); if (rc) return rc;

@@ -62,6 +62,7 @@ def test_flat_codes_every_width(huff, oracle, L):
         t = oracle.huffman_table(data)
         assert {x[3] for x in t} == {L}
         assert huff.Decompress(c) == data
+        assert huff.Compress(data) == c            # flat-code emit kernel, every width and ragged tails
         assert huff.Decompress(huff.Compress(data)) == data
 
 

@@ -63,7 +63,7 @@ def test_single_symbol_and_empty(huff, oracle):
 def test_wide_codes(huff, oracle):
     data = fib_skewed(30)
     t = oracle.huffman_table(data)
-    assert max(x[3] for x in t) > 26
+    assert max(x[3] for x in t) > 24
     assert huff.Compress(data) == oracle.huffman_compress(data)
 
 
