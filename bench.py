@@ -136,6 +136,9 @@ def main():
         from raisin_amd import shard
         t_max = shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
 
+    lossless = bool(d.numel() == n and torch.equal(d, src))   # checked BEFORE anything else touches dec_buf
+    comp_n = int(c.numel())
+
     # context for the roofline: what a plain device-to-device copy and a read-only pass reach on THIS GPU
     # (torch kernels, timed with torch events on torch's stream; not part of the timed region above)
     def _rate(fn, nbytes, reps=10):
@@ -152,8 +155,6 @@ def main():
     copy_gbps = _rate(lambda: dec_buf[:n].copy_(src), 2 * n)
     read_gbps = _rate(lambda: src.view(torch.int64).sum(), n)
 
-    lossless = bool(d.numel() == n and torch.equal(d, src))
-    comp_n = int(c.numel())
 
     gather_ms = None
     if dist is not None:
