@@ -55,7 +55,7 @@ def main():
         for k, (tot, cnt) in acc.items():
             res[k][key] = tot / cnt
     names = {"k_byte_hist": "huff_byte_hist", "k_emit<0>": "huff_emit", "k_dec_sync": "huff_dec_sync", "k_dec_emit": "huff_dec_emit",
-             "k_dec_flat": "huff_dec_flat", "k_emit_ascii32": "huff_emit"}
+             "k_dec_flat": "huff_dec_flat", "k_emit_ascii32": "huff_emit", "k_emit_flat": "huff_emit"}
     final = {}
     for k, v in res.items():
         base = k
