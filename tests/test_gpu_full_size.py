@@ -88,3 +88,26 @@ def test_bench_two_ranks_control_flow():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["lossless"] is True and j["scaling"] == "weak"
     assert j["config"]["chunks"] == 2 and "gather_ms" in j and j["value"] > 0
+
+
+def test_beyond_4GiB_offsets():
+    """5 GiB per call: every byte/bit offset above 2^32 (flat and general Huffman paths)."""
+    import torch
+    from raisin_amd import huffman
+    n = 5 * GIB
+    g = torch.Generator(device="cuda").manual_seed(7)
+    base = torch.randint(0, 128, (GIB,), dtype=torch.uint8, device="cuda", generator=g)
+    src = base.repeat(5)
+    del base
+    c = huffman.compress_tensor(src)
+    assert c.numel() > n * 7 // 8                       # 128 equiprobable symbols: flat 7-bit code
+    d = huffman.decompress_tensor(c)
+    assert d.numel() == n and torch.equal(d, src)
+    del c, d
+    # general path: a skewed 64 MiB block tiled to 5 GiB
+    w = torch.tensor([2.0 ** (-i / 6) for i in range(96)], device="cuda")
+    blk = (torch.multinomial(w, 1 << 26, replacement=True).to(torch.uint8) + 32)
+    src = blk.repeat(80)
+    c = huffman.compress_tensor(src)
+    d = huffman.decompress_tensor(c)
+    assert d.numel() == n and torch.equal(d, src)
