@@ -485,15 +485,18 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
     *out_n = 0;
     // ---- header to the host: strings.SplitN(content, "\\\n", 2) (huffman.go:261)
+    // (fetched into pinned memory: 4 KiB covers every ASCII-alphabet header, larger ones grow 8x per try)
     std::vector<uint8_t> head;
     size_t sep = (size_t)-1;
-    for (size_t want = 1 << 16;; want *= 8) {
+    for (size_t want = 4096;; want *= 8) {
         const size_t k = std::min(want, n);
         const size_t old = head.size();
-        head.resize(k);
         if (k > old) {
-            RSN_HIP(hipMemcpyAsync(head.data() + old, d_in + old, k - old, hipMemcpyDeviceToHost, s));
+            void *hpin; int prc = pinned_buf(c, k - old + 64, &hpin); if (prc) return prc;
+            RSN_HIP(hipMemcpyAsync(hpin, d_in + old, k - old, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
+            head.resize(k);
+            memcpy(head.data() + old, hpin, k - old);
         }
         for (size_t i = old ? old - 1 : 0; i + 1 < k; i++) if (head[i] == 0x5C && head[i + 1] == 0x0A) { sep = i; break; }
         if (sep != (size_t)-1 || k == n) break;
@@ -501,9 +504,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (sep == (size_t)-1) return c.fail(RSN_ERR_FORMAT, "huffman: no '\\\\\\n' separator (reference: index out of range, huffman.go:264)");
     if (sep + 3 > head.size() && sep + 3 <= n) {   // make sure the pad byte is on the host
         const size_t old = head.size();
-        head.resize(sep + 3);
-        RSN_HIP(hipMemcpyAsync(head.data() + old, d_in + old, sep + 3 - old, hipMemcpyDeviceToHost, s));
+        void *hpin; int prc = pinned_buf(c, 64, &hpin); if (prc) return prc;
+        RSN_HIP(hipMemcpyAsync(hpin, d_in + old, sep + 3 - old, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
+        head.resize(sep + 3);
+        memcpy(head.data() + old, hpin, sep + 3 - old);
     }
     std::vector<HuffSym> syms; std::string msg;
     if (!parse_header(head.data(), sep, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
@@ -543,10 +548,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         const unsigned long long n_sym = max / L;
         *out_n = (size_t)n_sym;
         if (!d_out || n_sym > out_cap) { *out_n = round_up((size_t)n_sym, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %llu bytes, buffer holds %zu", n_sym, out_cap); }
-        std::vector<uint8_t> lut8((size_t)1 << L);
+        void *hl; rc = pinned_buf(c, 256, &hl); if (rc) return rc;
+        uint8_t *lut8 = (uint8_t *)hl;
         for (uint32_t i = 0; i < tree.n_leaves; i++) lut8[codes.code[i]] = (uint8_t)tree.rune[i];
-        rc = dev_buf(c, 5, lut8.size(), &p); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(p, lut8.data(), lut8.size(), hipMemcpyHostToDevice, s));
+        rc = dev_buf(c, 5, 256, &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, lut8, (size_t)1 << L, hipMemcpyHostToDevice, s));
         FlatArgs fa{};
         fa.base = d_in + A0; fa.nbytes = n - A0; fa.p0 = 8ull * (pay - A0) + diff; fa.n_sym = n_sym;
         fa.lut = (const uint8_t *)p; fa.out = d_out;

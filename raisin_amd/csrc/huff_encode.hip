@@ -574,9 +574,10 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
 // that also holds header bytes is merged with atomicOr.
 struct FlatEmitArgs {
     const uint8_t *in; size_t n;
-    const uint8_t *codes;                // 128 bytes: symbol -> L-bit code
+    const uint8_t *codes;                // 128 bytes: symbol -> L-bit code, followed by the header bytes
     unsigned long long base_bits;        // bit position of the first code bit in out
     uint32_t *out_words;
+    uint32_t hdr_len;                    // bytes of header || "\\\n" || pad byte, staged behind the code table
 };
 constexpr int FE_SPL = 32;
 constexpr int FE_SYMS = HB * FE_SPL;     // symbols per block
@@ -648,8 +649,12 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
         const unsigned long long g = wbase + i;
         if (g >= end_word) break;
         const uint32_t val = s_o[i + (i >> 5)];
-        if (g == (a.base_bits >> 5)) { if (val) atomicOr(a.out_words + g, val); }   // shares its dword with header bytes
-        else a.out_words[g] = val;
+        if (g == (a.base_bits >> 5)) {
+            // this dword also holds the last header bytes (and the pad bits): merge them in registers
+            uint32_t hb = 0;
+            for (uint32_t k = (uint32_t)(g * 4); k < a.hdr_len; k++) hb |= (uint32_t)a.codes[128 + k] << (8 * (k & 3));
+            a.out_words[g] = val | hb;
+        } else a.out_words[g] = val;
     }
     // the word after the block holds the low o0 bits of this block's last logical word; the NEXT block writes it
     // (as its first word) unless this is the last block
@@ -659,6 +664,11 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
         if (last_block && g < end_word) a.out_words[g] = __builtin_bswap32(v[L - 1] << (32 - o0));
     }
     __syncthreads();                                               // s_o / s_last are reused by the next chunk
+    }
+    if (blockIdx.x == 0) {                                         // header bytes in front of the first payload dword
+        const uint32_t whole = (uint32_t)(a.base_bits >> 5) * 4;
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out_words);
+        for (uint32_t k = tid; k < whole && k < a.hdr_len; k += HB) o8[k] = a.codes[128 + k];
     }
 }
 
@@ -792,15 +802,14 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
     if (mode == MODE_ASCII && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat_emit) {
         const unsigned L = codes.max_len;
-        void *hp2; rc = pinned_buf(c, 256, &hp2); if (rc) return rc;
+        void *hp2; rc = pinned_buf(c, 128 + H + 16, &hp2); if (rc) return rc;
         uint8_t *hcodes = (uint8_t *)hp2;
         memset(hcodes, 0, 128);
         for (uint32_t i = 0; i < tree.n_leaves; i++) hcodes[tree.rune[i]] = (uint8_t)codes.code[i];
-        rc = dev_buf(c, 3, 256, &p); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(p, hcodes, 128, hipMemcpyHostToDevice, s));
-        FlatEmitArgs fa{d_in, n, (const uint8_t *)p, base_bits, (uint32_t *)d_out};
-        RSN_LAUNCH("huff_emit_init", k_zero_unit, dim3(1), dim3(64), 0, s, (uint32_t *)d_out, base_bits >> 7);
-        RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+        memcpy(hcodes + 128, hdr.data(), H);                      // one upload: code table + header
+        rc = dev_buf(c, 3, 128 + H + 16, &p); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(p, hcodes, 128 + H, hipMemcpyHostToDevice, s));
+        FlatEmitArgs fa{d_in, n, (const uint8_t *)p, base_bits, (uint32_t *)d_out, (uint32_t)H};
         const dim3 grid((uint32_t)std::min<size_t>(ceil_div(n, FE_SYMS), 256 * 8));
         switch (L) {
 #define RSN_FE(LL) case LL: RSN_LAUNCH("huff_emit", k_emit_flat<LL>, grid, dim3(HB), 0, s, fa); break;
