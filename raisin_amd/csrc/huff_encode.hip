@@ -330,8 +330,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     constexpr int MAXLEN = EmitCfg<MODE>::MAXLEN;
     constexpr int WIN_WORDS = ROUND * MAXLEN / 32 + 8;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[WIN_WORDS];
-    constexpr int TREP = 1;                                     // copies of the code table: lanes l and l+8k share one, spreads the lookups over banks
-    __shared__ uint32_t s_tab[MODE == MODE_ASCII ? 128 * TREP : 1];
+    __shared__ uint32_t s_tab[MODE == MODE_ASCII ? 128 : 1];
     __shared__ unsigned long long s_code[MODE == MODE_ASCII_WIDE ? 256 : 1];
     __shared__ uint8_t s_len[MODE == MODE_ASCII_WIDE ? 256 : 1];
     __shared__ uint32_t s_wsum[HB / 64];
@@ -343,8 +342,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     const size_t in0 = (size_t)t0 * TILE;
     const size_t in1 = min((size_t)t1 * TILE, a.n);
 
-    if (MODE == MODE_ASCII) for (int i = tid; i < 128 * TREP; i += HB) s_tab[i] = a.tab32[i / TREP];
-    const uint32_t trep = tid & (TREP - 1);
+    if (MODE == MODE_ASCII && tid < 128) s_tab[tid] = a.tab32[tid];
     if (MODE == MODE_ASCII_WIDE) { s_code[tid] = a.code64[tid]; s_len[tid] = a.len8[tid]; }
     for (int i = tid; i < WIN_WORDS; i += HB) s_win[i] = 0;
 
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
                 // full round (block-uniform): no per-symbol masking, 16 independent LDS lookups
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    e[k] = s_tab[(((w4[k >> 2] >> (8 * (k & 3))) & 0x7F) * TREP) | trep];
+                    e[k] = s_tab[(w4[k >> 2] >> (8 * (k & 3))) & 0x7F];
                     mylen += e[k] >> TAB_LEN_SHIFT;
                 }
             } else {
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
                 for (int k = 0; k < 16; k++) {
                     const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
                     if (MODE == MODE_ASCII) {
-                        const uint32_t ent = ((smask >> k) & 1) ? s_tab[((b & 0x7F) * TREP) | trep] : 0;
+                        const uint32_t ent = ((smask >> k) & 1) ? s_tab[b & 0x7F] : 0;
                         e[k] = ent;
                         mylen += ent >> TAB_LEN_SHIFT;
                     } else {
@@ -672,22 +670,8 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
     }
 }
 
-__global__ void k_zero_unit(uint32_t *out_words, unsigned long long unit) {
-    if (threadIdx.x < 4) out_words[unit * 4 + threadIdx.x] = 0;
-}
-
 // ======================================================================= host side
 namespace {
-
-struct EncodePlan {
-    std::string header;      // header || "\\\n" || pad byte
-    unsigned pad = 0;
-    uint64_t total_bits = 0;
-    size_t out_n = 0;
-    bool ascii = true;
-    bool single = false;     // one distinct symbol: empty payload
-    unsigned max_len = 0;
-};
 
 int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t *d_tile_hist,
                        std::vector<HuffSym> &syms, bool &ascii) {

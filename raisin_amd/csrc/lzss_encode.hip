@@ -454,7 +454,7 @@ __device__ __forceinline__ uint32_t leftmost_distance(const uint8_t *sb, uint32_
 // visited positions whose match is long enough to become a token, count the output bytes
 __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ fc, uint32_t *__restrict__ keys, uint32_t E, uint32_t W,
                                                    const uint32_t *__restrict__ entry, uint32_t *__restrict__ flags,
-                                                   unsigned long long *__restrict__ tile_bytes, int dbg) {
+                                                   unsigned long long *__restrict__ tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_bytes[];   // fc[base-W, base+PT+W): window before, longest match after
     __shared__ uint16_t nxt[PT];
     __shared__ uint32_t fl[PT / 32];
@@ -465,7 +465,6 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
     const uint32_t base = blockIdx.x * PT;
     const uint32_t org = (base >= W ? base - W : 0) & ~15u;        // 16-byte aligned start of the tile image
     const uint32_t span = min(base + PT + W, E) - org;
-    (void)dbg;
     for (int i = threadIdx.x; i < PT; i += LB) {
         const uint32_t p = base + i;
         uint32_t L = p < E ? keys[p] >> 16 : 1;
@@ -678,7 +677,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         const size_t sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
         static thread_local size_t mark_attr = 0;
         if (sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); mark_attr = sh; }
-        RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, getenv("RSN_DBG") ? atoi(getenv("RSN_DBG")) : 0);
+        RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes);
     }
     RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
     RSN_HIP(hipMemcpyAsync(h64, d_ttot, 8, hipMemcpyDeviceToHost, s));
