@@ -3,7 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <map>
+#include <vector>
 
 namespace rsn {
 
@@ -148,9 +148,11 @@ bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg) {
 void emit_header(const std::vector<HuffSym> &by_rune, std::string &out) {
     const size_t a = by_rune.size();
     auto entry = [&](const HuffSym &s) {
-        char num[24];
-        const int k = snprintf(num, sizeof num, "%llu", (unsigned long long)s.freq);   // strconv.Itoa(val)
-        out.append(num, (size_t)k);
+        char num[24];                                                                   // strconv.Itoa(val)
+        int k = 0;
+        uint64_t v = s.freq;
+        do { num[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (k) out.push_back(num[--k]);
         out.push_back('|');
         if (s.rune == 10) { out.append("\\n"); return; }                                // huffman.go:316
         uint8_t u[4];
@@ -164,7 +166,11 @@ void emit_header(const std::vector<HuffSym> &by_rune, std::string &out) {
 }
 
 bool parse_header(const uint8_t *h, size_t n, std::vector<HuffSym> &syms, std::string &msg) {
-    std::map<uint32_t, uint64_t> table;   // symFreqs (huffman.go:197); later entries overwrite
+    // symFreqs (huffman.go:197): a map, so a later entry for the same rune overwrites an earlier one.
+    // Kept as an append-only list with a sequence number, resolved by one stable sort at the end.
+    struct Ent { uint32_t rune; uint64_t freq; };
+    std::vector<Ent> table;
+    table.reserve(256);
     uint64_t acc = 0;
     int digits = 0;
     for (size_t i = 0; i < n; i++) {
@@ -181,16 +187,20 @@ bool parse_header(const uint8_t *h, size_t n, std::vector<HuffSym> &syms, std::s
         if (i + 1 >= n) { msg = "huffman: header ends after '|' (reference: index out of range, huffman.go:210)"; return false; }
         if (h[i + 1] == '\\') {
             if (i + 2 >= n) { msg = "huffman: header ends after '\\' (reference: index out of range, huffman.go:210)"; return false; }
-            if (h[i + 2] == 'n') { table[10] = f; i += 2; continue; }   // huffman.go:211-212,222
+            if (h[i + 2] == 'n') { table.push_back({10, f}); i += 2; continue; }   // huffman.go:211-212,222
         }
         int sz;
         const uint32_t r = go_decode_rune(h + i + 1, n - (i + 1), &sz);  // the rune that starts at i+1 (huffman.go:214-220)
-        table[r] = f;
+        table.push_back({r, f});
         i += 1;                                       // huffman.go:222: one byte is skipped, whatever the rune's width
     }
+    std::stable_sort(table.begin(), table.end(), [](const Ent &a, const Ent &b) { return a.rune < b.rune; });
     syms.clear();
     syms.reserve(table.size());
-    for (auto &kv : table) syms.push_back({kv.first, kv.second});
+    for (size_t i = 0; i < table.size(); i++) {
+        if (i + 1 < table.size() && table[i + 1].rune == table[i].rune) continue;   // overwritten by a later entry
+        syms.push_back({table[i].rune, table[i].freq});
+    }
     return true;
 }
 
