@@ -47,76 +47,137 @@ int go_encode_rune(uint32_t r, uint8_t o[4]) {
 }
 
 namespace {
-// Go container/heap (go1.15 src/container/heap/heap.go) over node ids with
+// Go container/heap (go1.15 src/container/heap/heap.go) over tree nodes with
 // Less(i,j) = freq[i] < freq[j] (huffman.go:43-45).  Ties are broken only by
-// the sift order below, so it is reproduced exactly.
+// the sift order below, so it is reproduced exactly.  Items carry their
+// frequency inline (one cache line per level); Packed is the 8-byte form used
+// when every frequency fits 32 bits, Wide the general one.
+struct Packed {
+    uint64_t v;
+    static Packed make(uint64_t f, int32_t id) { return {(f << 32) | (uint32_t)id}; }
+    uint64_t freq() const { return v >> 32; }
+    int32_t id() const { return (int32_t)(uint32_t)v; }
+};
+struct Wide {
+    uint64_t f; int32_t i;
+    static Wide make(uint64_t f, int32_t id) { return {f, id}; }
+    uint64_t freq() const { return f; }
+    int32_t id() const { return i; }
+};
+
+template <typename Item>
 class GoHeap {
   public:
-    GoHeap(std::vector<int32_t> &items, const std::vector<uint64_t> &freq) : h_(items), f_(freq) {}
+    explicit GoHeap(std::vector<Item> &items) : h_(items) {}
     void init() { const int n = (int)h_.size(); for (int i = n / 2 - 1; i >= 0; i--) down(i, n); }
-    void push(int32_t x) { h_.push_back(x); up((int)h_.size() - 1); }
-    int32_t pop() {
+    void push(Item x) { h_.push_back(x); up((int)h_.size() - 1); }
+    Item pop() {
         const int n = (int)h_.size() - 1;
         std::swap(h_[0], h_[n]);
         down(0, n);
-        const int32_t x = h_.back();
+        const Item x = h_.back();
         h_.pop_back();
         return x;
     }
     size_t size() const { return h_.size(); }
 
   private:
-    bool less(int a, int b) const { return f_[h_[a]] < f_[h_[b]]; }
+    // up/down carry the moving item in a register and shift the others past it: the same final
+    // layout as heap.go's swap at every level, with half the stores.
     void up(int j) {
+        Item *h = h_.data();
+        const Item x = h[j];
         for (;;) {
             const int i = (j - 1) / 2;   // parent; truncating division, so j=0 gives 0
-            if (i == j || !less(j, i)) break;
-            std::swap(h_[i], h_[j]);
+            if (i == j || !(x.freq() < h[i].freq())) break;
+            h[j] = h[i];
             j = i;
         }
+        h[j] = x;
     }
     void down(int i, int n) {
+        Item *h = h_.data();
+        const Item x = h[i];
         for (;;) {
             const int l = 2 * i + 1;
             if (l >= n || l < 0) break;
+            __builtin_prefetch(h + std::min(4 * i + 3, n - 1));   // grandchildren: the loads below are a dependent chain
             int j = l;
-            if (l + 1 < n && less(l + 1, l)) j = l + 1;
-            if (!less(j, i)) break;
-            std::swap(h_[i], h_[j]);
+            if (l + 1 < n) j += (int)(h[l + 1].freq() < h[l].freq());
+            if (!(h[j].freq() < x.freq())) break;
+            h[i] = h[j];
             i = j;
         }
+        h[i] = x;
     }
-    std::vector<int32_t> &h_;
-    const std::vector<uint64_t> &f_;
+    std::vector<Item> &h_;
 };
+
+template <typename Item>
+void run_heap(HuffTree &t, size_t a) {
+    std::vector<Item> items;
+    items.reserve(a + 1);
+    for (size_t i = 0; i < a; i++) items.push_back(Item::make(t.freq[i], (int32_t)i));
+    GoHeap<Item> heap(items);
+    heap.init();                                    // huffman.go:93
+    while (heap.size() > 1) {                       // huffman.go:96-101
+        const Item x = heap.pop();
+        const Item y = heap.pop();
+        const int32_t id = (int32_t)t.freq.size();
+        const uint64_t f = x.freq() + y.freq();
+        t.freq.push_back(f);
+        t.left.push_back(x.id()); t.right.push_back(y.id()); t.rune.push_back(0);
+        heap.push(Item::make(f, id));
+    }
+    t.root = heap.pop().id();                       // huffman.go:102
+}
+
+// (freq asc, rune asc).  Callers nearly always hand the table over ascending by rune, where a
+// stable LSD radix sort on the frequency alone gives the same order in a few linear passes.
+void sort_leaves(std::vector<HuffSym> &syms) {
+    const size_t a = syms.size();
+    bool by_rune = true;
+    uint64_t fmax = 0;
+    for (size_t i = 0; i < a; i++) {
+        fmax = std::max(fmax, syms[i].freq);
+        if (i && syms[i - 1].rune >= syms[i].rune) by_rune = false;
+    }
+    if (!by_rune || a < 4096) {
+        std::sort(syms.begin(), syms.end(), [](const HuffSym &x, const HuffSym &y) {
+            return x.freq != y.freq ? x.freq < y.freq : x.rune < y.rune;
+        });
+        return;
+    }
+    std::vector<HuffSym> tmp(a);
+    HuffSym *src = syms.data(), *dst = tmp.data();
+    for (unsigned shift = 0; shift < 64 && (fmax >> shift) != 0; shift += 11) {
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < a; i++) count[((src[i].freq >> shift) & 2047) + 1]++;
+        for (int k = 0; k < 2048; k++) count[k + 1] += count[k];
+        for (size_t i = 0; i < a; i++) dst[count[(src[i].freq >> shift) & 2047]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != syms.data()) syms.swap(tmp);
+}
 }  // namespace
 
 bool build_tree(std::vector<HuffSym> &syms, HuffTree &t, std::string &msg) {
     const size_t a = syms.size();
     if (a == 0) { msg = "huffman: no symbols (reference panics in heap.Pop on an empty heap, huffman.go:102)"; return false; }
-    std::sort(syms.begin(), syms.end(), [](const HuffSym &x, const HuffSym &y) {
-        return x.freq != y.freq ? x.freq < y.freq : x.rune < y.rune;
-    });
+    sort_leaves(syms);
     t = HuffTree();
     t.n_leaves = (uint32_t)a;
     t.freq.reserve(2 * a); t.left.reserve(2 * a); t.right.reserve(2 * a); t.rune.reserve(2 * a);
-    std::vector<int32_t> items(a);
+    uint64_t total = 0;
+    bool wide = a >= (1u << 30);
     for (size_t i = 0; i < a; i++) {
         t.freq.push_back(syms[i].freq); t.rune.push_back(syms[i].rune);
         t.left.push_back(-1); t.right.push_back(-1);
-        items[i] = (int32_t)i;
+        if (syms[i].freq >> 32) wide = true;
+        total += syms[i].freq & 0xFFFFFFFFull;
     }
-    GoHeap heap(items, t.freq);
-    heap.init();                                    // huffman.go:93
-    while (heap.size() > 1) {                       // huffman.go:96-101
-        const int32_t x = heap.pop();
-        const int32_t y = heap.pop();
-        const int32_t id = (int32_t)t.freq.size();
-        t.freq.push_back(t.freq[x] + t.freq[y]);
-        t.left.push_back(x); t.right.push_back(y); t.rune.push_back(0);
-        heap.push(id);
-    }
-    t.root = heap.pop();                            // huffman.go:102
+    if (wide || (total >> 32)) run_heap<Wide>(t, a);
+    else run_heap<Packed>(t, a);
     return true;
 }
 
@@ -147,6 +208,7 @@ bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg) {
 
 void emit_header(const std::vector<HuffSym> &by_rune, std::string &out) {
     const size_t a = by_rune.size();
+    out.reserve(out.size() + 12 * a);
     auto entry = [&](const HuffSym &s) {
         char num[24];                                                                   // strconv.Itoa(val)
         int k = 0;
@@ -167,7 +229,7 @@ void emit_header(const std::vector<HuffSym> &by_rune, std::string &out) {
 
 bool parse_header(const uint8_t *h, size_t n, std::vector<HuffSym> &syms, std::string &msg) {
     // symFreqs (huffman.go:197): a map, so a later entry for the same rune overwrites an earlier one.
-    // Kept as an append-only list with a sequence number, resolved by one stable sort at the end.
+    // Kept as an append-only list, resolved by one stable sort at the end.
     struct Ent { uint32_t rune; uint64_t freq; };
     std::vector<Ent> table;
     table.reserve(256);
@@ -194,7 +256,9 @@ bool parse_header(const uint8_t *h, size_t n, std::vector<HuffSym> &syms, std::s
         table.push_back({r, f});
         i += 1;                                       // huffman.go:222: one byte is skipped, whatever the rune's width
     }
-    std::stable_sort(table.begin(), table.end(), [](const Ent &a, const Ent &b) { return a.rune < b.rune; });
+    bool ascending = true;                            // this library's own headers already are
+    for (size_t i = 1; i < table.size() && ascending; i++) ascending = table[i - 1].rune <= table[i].rune;
+    if (!ascending) std::stable_sort(table.begin(), table.end(), [](const Ent &a, const Ent &b) { return a.rune < b.rune; });
     syms.clear();
     syms.reserve(table.size());
     for (size_t i = 0; i < table.size(); i++) {

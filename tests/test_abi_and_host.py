@@ -81,6 +81,25 @@ def test_heap_tie_breaks_on_equal_frequencies(built, oracle):
         assert table == [(r, c, l) for r, f, c, l in oracle.huffman_table(data)]
 
 
+def test_large_alphabet_tree_matches_oracle(built, oracle):
+    """>= 4096 symbols takes the radix leaf sort and the packed heap; counts scaled past 2**32
+    take the wide heap and must give the same tree (every comparison scales with them)."""
+    import random
+    from raisin_amd import huffman
+    rng = random.Random(11)
+    runes = rng.sample([r for r in range(0x20, 0x30000) if not 0xD800 <= r < 0xE000 and r != 0x5C], 6000)
+    counts = {r: rng.choice((1, 1, 2, 3, 7)) for r in runes}
+    text = [r for r, c in counts.items() for _ in range(c)]
+    rng.shuffle(text)
+    data = "".join(map(chr, text)).encode("utf-8")
+    want = [(r, c, l) for r, f, c, l in oracle.huffman_table(data)]
+    table, header = huffman.plan(counts)
+    assert table == want
+    assert huffman.parse_header(header) == sorted(counts.items())
+    wide, _ = huffman.plan({r: c << 33 for r, c in counts.items()})
+    assert wide == want
+
+
 def test_header_parse_quirks(built):
     from raisin_amd import RsnError, huffman
     assert huffman.parse_header(b"3|\\n5||7|9") == [(10, 3), (0x39, 7), (0x7C, 5)]     # '\\n' escape, '|' and digit symbols
