@@ -99,6 +99,7 @@ __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in
 struct MatchArgs {
     const uint8_t *fc; uint32_t E; uint32_t W; uint32_t DW;   // DW = diagonals per wave
     uint32_t *keys;
+    const uint32_t *only;                                      // non-null: sweep only the strips flagged here (k_match_hash's hand-backs)
 };
 
 #define RSN_DPP_WAVE_SHL1 0x130   // lane i <- lane i+1
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.only && !a.only[blockIdx.x]) return;
     const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
     const long long r0 = b0 - (long long)W4;
     for (uint32_t i = tid; i < RLEN; i += MW2 * 64) {
@@ -334,6 +336,187 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
             a.keys[p] = L << 16;                                      // distance filled in later for chain positions that need it
         }
     }
+}
+
+// ------------------------------------------------------------------ E2'': bigram-bucket match search
+// The sweeps above cost W compares per position whatever the data.  Here a block takes HT
+// positions plus their window, groups every staged position by its first two bytes (counting
+// sort into 8192 LDS buckets: first byte | low five bits of the second, the other three bits
+// kept as a tag in the entry), and a position only examines the entries of its own bucket:
+//   * every candidate start j with fc[j:j+2] == fc[i:i+2] is in that bucket, so
+//     best = max over them of min(lcp(i,j), i-j) is exact whenever the answer is >= 2, and
+//     the packed maximum (L<<16 | distance) also yields the leftmost occurrence;
+//   * an answer of 0 or 1 is decided by whether ANY in-window entry of the 32 buckets that
+//     share the first byte exists.
+// Work is proportional to how often the bigram at i occurs in the window instead of W, which
+// on text is ~1% of W.  The result is the same function as k_match/k_match2; input where the
+// assumption fails (an lcp of HLMAX or more, or a lane running past H_ITER_CAP entries) flags
+// its strip and k_match2 redoes exactly those strips.
+constexpr int HT = 4096;                 // positions per block
+constexpr int HTH = 512;                 // threads per block
+constexpr int HSH = 9;                   // log2(HTH): entries of a bucket are ordered by staged offset >> HSH
+constexpr int HWMAX = 4096;              // largest window this path takes
+constexpr int HLMAX = 256;               // longest common prefix examined before the strip is handed back
+constexpr int HNB = 8192;                // buckets
+constexpr int H_STAGE = HWMAX + HT + HLMAX + 32;
+constexpr uint32_t H_ITER_CAP = (HT / HTH) * 768;   // trips per lane before the strip is handed back (the sweep costs ~W/6 trips per position)
+static_assert(HWMAX + HT <= 8192, "an entry keeps the staged offset in 13 bits");
+static_assert(MATCH_STRIP % HT == 0, "a strip is a whole number of hash tiles");
+static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH == 0, "round structure");
+
+struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; };
+
+__device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint32_t rel) {
+    const uint32_t q = rel >> 2, sh = (rel & 3) * 8;
+    const uint32_t w0 = sw[q], w1 = sw[q + 1], w2 = sw[q + 2];
+    return (unsigned long long)__builtin_amdgcn_alignbit(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+}
+
+__global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t sw[H_STAGE / 4];   // fc[r0, r0 + H_STAGE), zero outside the stream
+    __shared__ uint32_t s_cur[HNB / 2];                                  // two 16-bit counters per word: counts, then starts, then ends
+    __shared__ uint16_t s_list[HWMAX + HT];                              // staged offset | tag << 13, grouped by bucket
+    __shared__ uint32_t s_part[HTH / 64];
+    __shared__ uint32_t s_heavy, s_next;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t E = a.E, W = a.W;
+    const long long t0 = (long long)blockIdx.x * HT;
+    const long long r0 = t0 - HWMAX;
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
+    for (uint32_t v = tid; v < H_STAGE / 16; v += HTH) {
+        const long long P = r0 + 16ll * v;
+        uint4 x = {0, 0, 0, 0};
+        if (P >= 0 && P + 16 <= (long long)E) x = *reinterpret_cast<const uint4 *>(a.fc + P);
+        else if (P + 16 > 0 && P < (long long)E) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)E) w[k >> 2] |= (uint32_t)a.fc[q] << (8 * (k & 3)); }
+            x = {w[0], w[1], w[2], w[3]};
+        }
+        reinterpret_cast<uint4 *>(sw)[v] = x;
+    }
+    for (int i = tid; i < HNB / 2; i += HTH) s_cur[i] = 0;
+    if (tid == 0) { s_heavy = 0; s_next = 0; }
+    __syncthreads();
+
+    if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match)
+        bool ok = true;
+        const uint32_t qn = (uint32_t)min((long long)(HT + HLMAX), (long long)E - t0);
+        for (uint32_t q = tid; q < qn; q += HTH) ok = ok && sb[HWMAX + q] == sb[HWMAX + q - W];
+        if (__syncthreads_and(ok)) {
+            const long long q_end = min(t0 + (long long)HT + (long long)W - 1, (long long)E);
+            for (long long q = t0 + HT + HLMAX + tid; q < q_end; q += HTH) ok = ok && a.fc[q] == a.fc[q - W];
+            if (__syncthreads_and(ok)) {
+                for (long long p = t0 + tid; p < min(t0 + (long long)HT, (long long)E); p += HTH)
+                    a.keys[p] = ((uint32_t)min((long long)W, (long long)E - p) << 16) | W;
+                return;
+            }
+        }
+    }
+
+    // ---- group the staged positions by bigram: candidates are the positions [lo, hi)
+    const uint32_t rlo = (uint32_t)(max(0ll, t0 - (long long)W) - r0), rhi = (uint32_t)(min((long long)E - 1, t0 + (long long)HT) - r0);
+    for (uint32_t rel = tid; rel < HWMAX + HT; rel += HTH) {
+        if (rel < rlo || rel >= rhi) continue;
+        const uint32_t h = ((uint32_t)sb[rel] << 5) | (sb[rel + 1] & 31u);
+        atomicAdd(&s_cur[h >> 1], 1u << (16 * (h & 1)));
+    }
+    __syncthreads();
+    {
+        constexpr int PER = HNB / 2 / HTH;                               // counter words per thread
+        uint32_t sum = 0;
+        for (int k = 0; k < PER; k++) { const uint32_t x = s_cur[tid * PER + k]; sum += (x & 0xFFFF) + (x >> 16); }
+        uint32_t incl = sum;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int k = 0; k < wv; k++) run += s_part[k];
+        for (int k = 0; k < PER; k++) {
+            const uint32_t x = s_cur[tid * PER + k], c0 = x & 0xFFFF, c1 = x >> 16;
+            s_cur[tid * PER + k] = run | ((run + c0) << 16);
+            run += c0 + c1;
+        }
+    }
+    __syncthreads();
+    // rounds of HTH consecutive offsets with a barrier between them: inside a bucket the entries end
+    // up ordered by offset >> HSH, which is all the lower-bound search below needs
+    for (uint32_t rel = tid; rel < HWMAX + HT; rel += HTH) {
+        if (rel >= rlo && rel < rhi) {
+            const uint32_t b1 = sb[rel + 1];
+            const uint32_t h = ((uint32_t)sb[rel] << 5) | (b1 & 31u), sh = 16 * (h & 1);
+            const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
+            s_list[slot] = (uint16_t)(rel | ((b1 >> 5) << 13));
+        }
+        __syncthreads();
+    }
+    const uint16_t *ends = reinterpret_cast<const uint16_t *>(s_cur);    // ends[h]; the bucket starts at ends[h-1]
+
+    // ---- every lane takes positions off a shared counter and walks their buckets.  One flat trip
+    //      body (no continue): each lane reads at most one entry and makes at most one 8-byte
+    //      compare per trip, so lanes in different states share every trip.
+    const uint32_t npos = (uint32_t)min((long long)HT, (long long)E - t0);
+    bool have = false, ext = false, bytemode = false, search = false;
+    uint32_t ipos = 0, irel = 0, cur = 0, end = 0, bcur = 0, bend = 0, tag = 0, best = 0, prel = 0, off = 0, capE = 0, d = 0, iters = 0, slo = 0, shi = 0;
+    for (;;) {
+        if (!have) {                                                      // the only divergent region of a trip
+            if (s_heavy) break;
+            const uint32_t kp = atomicAdd(&s_next, 1u);
+            if (kp >= npos) break;
+            ipos = (uint32_t)t0 + kp;
+            irel = HWMAX + kp;
+            const uint32_t b0 = sb[irel], b1 = sb[irel + 1];
+            capE = E - ipos;
+            best = 0; have = true; off = 0; prel = irel; d = 0;
+            bcur = b0 ? ends[(b0 << 5) - 1] : 0; bend = ends[(b0 << 5) | 31];       // every staged position that starts with b0
+            const uint32_t h = (b0 << 5) | (b1 & 31u);
+            bytemode = capE < 2;
+            cur = bytemode ? bcur : (h ? ends[h - 1] : 0); end = bytemode ? bend : ends[h]; tag = b1 >> 5;
+            search = !bytemode && end - cur > 8;                          // long bucket: skip the entries before the window
+            slo = cur; shi = end;
+        }
+        if (++iters > H_ITER_CAP) { s_heavy = 1; break; }
+        // ---- entry step (skipped while a compare is being extended): one entry of the bucket, or one bisection step
+        const bool fetch = !ext;
+        const bool rd = fetch && (search || cur < end);
+        const uint32_t idx = search ? (slo + shi) >> 1 : cur;
+        const uint32_t e = s_list[rd ? idx : 0];
+        const uint32_t rel = e & 8191u;
+        const bool s_step = rd && search, w_step = rd && !search;
+        const bool below = (rel >> HSH) < ((irel - W) >> HSH);
+        slo = (s_step && below) ? idx + 1 : slo;
+        shi = (s_step && !below) ? idx : shi;
+        const bool s_done = s_step && slo >= shi;
+        search = search && !s_done;
+        cur = s_done ? slo : cur + (w_step ? 1u : 0u);
+        const uint32_t dn = irel - rel;
+        const bool inwin = dn - 1u < W;                                   // candidate start in [i-W, i)
+        const bool byte_hit = w_step && bytemode && inwin;                // the byte occurs in the window: L = 1
+        const bool past = w_step && !bytemode && (rel >> HSH) > (irel >> HSH);      // the rest of the bucket starts after i
+        const bool start = w_step && !bytemode && inwin && (e >> 13) == tag && dn > (best >> 16);   // same bigram, far enough back to beat the best
+        best = byte_hit ? (1u << 16) : best;
+        cur = (byte_hit || past) ? end : cur;
+        prel = start ? rel : prel;
+        d = start ? dn : d;
+        off = start ? 0u : off;
+        // ---- bucket exhausted: L = 0 so far falls back to the first-byte range, anything else is final
+        const bool exh = fetch && !rd;
+        const bool to_byte = exh && !bytemode && best == 0;
+        if (exh && !to_byte) { a.keys[ipos] = best; have = false; }
+        cur = to_byte ? bcur : cur;
+        end = to_byte ? bend : end;
+        bytemode = bytemode || to_byte;
+        // ---- compare step: eight more bytes of the current candidate
+        const bool cmp = ext || start;
+        const unsigned long long x = lds_load8(sw, prel + off) ^ lds_load8(sw, irel + off);
+        const uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        const uint32_t cap = min(d, capE);                                // entirely inside the window, and inside the stream
+        ext = cmp && n == 8 && off + 8 < cap;
+        best = (cmp && !ext) ? max(best, (min(off + n, cap) << 16) | d) : best;     // longest, then farthest back (bytes.Index, lzss.go:419)
+        off += ext ? 8u : 0u;
+        if (off >= HLMAX) { s_heavy = 1; break; }
+    }
+    __syncthreads();
+    if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / HT)] = 1;
 }
 
 // ------------------------------------------------------------------ E3: greedy chain
@@ -630,7 +813,17 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // ---- E2
     rc = dev_buf(c, 10, (size_t)E * 4 + 64, &p); if (rc) return rc;
     uint32_t *d_keys = (uint32_t *)p;
-    MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys};
+    MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, nullptr};
+    static const bool brute = getenv("RSN_LZSS_BRUTE") != nullptr || getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: sweep every strip
+    if (W <= HWMAX && !brute) {
+        const uint32_t n_strips = (uint32_t)ceil_div(E, MATCH_STRIP);
+        rc = dev_buf(c, 18, (size_t)n_strips * 4 + 64, &p); if (rc) return rc;
+        uint32_t *d_heavy = (uint32_t *)p;
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 4, s));
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy};
+        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
+        ma.only = d_heavy;
+    }
     {
         const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
         const size_t shmem = (size_t)((MATCH_STRIP + WUB + W4 + 15) & ~15u) + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;

@@ -98,6 +98,21 @@ def test_long_runs(lz, oracle):
         assert lz.Decompress(c) == data
 
 
+def test_bucket_search_hands_strips_back(lz, oracle):
+    """The bigram-bucket search gives a strip to the diagonal sweep when a common prefix reaches 256
+    bytes or a bucket walk runs too long; both kinds of strip next to ordinary ones must still
+    produce the oracle's bytes."""
+    rng = np.random.default_rng(77)
+    block = rng.integers(0, 256, size=1500, dtype=np.uint8).tobytes()
+    repeats = b"".join(block + rng.integers(0, 256, size=int(rng.integers(1, 400)), dtype=np.uint8).tobytes() for _ in range(24))
+    data = text(31, 40000) + rnd(5, 40000, b"ab") + repeats + rnd(6, 40000, bytes(range(256))) + rnd(7, 20000, b"abc") + text(32, 30000)
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
+    for w in (700, 2048):
+        assert lz.CompressAsync(data[:120000], False, w) == oracle.lzss_compress(data[:120000], w)
+
+
 def test_match_table_against_oracle(lz, oracle):
     """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
     data = text(21, 50000)
