@@ -7,10 +7,17 @@
 //        occurs in literals: EncodeOpeningSymbols maps it to FF, lzss.go:373-377), scan
 //        the output lengths, then give every escaped-stream byte a SOURCE: itself for a
 //        literal, position-ptr for a byte produced by a token.
-//   L2 k_lzd_jump     pointer jumping src[p] = src[src[p]] until every byte points at a
-//        literal (a token may copy bytes that were themselves produced by a token: the
-//        reference resolves that by running serially, lzss.go:349-353).
-//   L3 k_lzd_gather   fetch the literal each byte resolved to.
+//   L2 a token may copy bytes that were themselves produced by a token (the reference resolves
+//        that by running serially, lzss.go:349-353).  Tile path (every back-pointer <= DT):
+//          k_lzd_tiles    validate the tokens, find the item that starts every DT-byte output tile
+//          k_lzd_resolve  one block per tile: parse its items into LDS descriptors (literal /
+//                         position inside the tile / position in the previous tile's tail),
+//                         pointer-jump the in-tile references inside LDS
+//          k_lzd_compose / k_lzd_chain   tails only depend on the previous tail: compose the
+//                         tail maps of 32 tiles, chain the groups serially (a few MB in total)
+//          k_lzd_emit     per group, tile after tile: literal or byte of the previous tail
+//        Fallback for larger pointers: k_lzd_expand / k_lzd_jump / k_lzd_gather, pointer
+//        jumping src[p] = src[src[p]] over the whole stream in HBM.
 //   L4 k_une_*        DecodeOpeningSymbols: an escape byte 5C consumes the next byte, so a
 //        byte is escaped iff the run of 5C immediately before it has odd length; run
 //        parities are combined per lane, per block and across blocks, then count/scan/write.
@@ -58,17 +65,69 @@ __device__ __forceinline__ size_t skip_open_token(const uint8_t *__restrict__ in
     return s;
 }
 
+// The same two helpers over a staged copy (LDS): valid indices are [lo, hi).
+__device__ __forceinline__ Tok parse_tok_b(const uint8_t *b, int hi, int j) {
+    Tok t{0, 0, 0, false};
+    int k = j + 1;
+    unsigned long long v = 0; int nd = 0;
+    while (k < hi && nd < 10 && b[k] >= '0' && b[k] <= '9') { v = v * 10 + (b[k] - '0'); k++; nd++; }
+    if (nd == 0 || k >= hi || b[k] != ',' || v > 0xFFFFFFFFull) return t;
+    t.ptr = (uint32_t)v; k++;
+    v = 0; nd = 0;
+    while (k < hi && nd < 10 && b[k] >= '0' && b[k] <= '9') { v = v * 10 + (b[k] - '0'); k++; nd++; }
+    if (nd == 0 || k >= hi || b[k] != '>' || v > 0xFFFFFFFFull) return t;
+    t.len = (uint32_t)v; t.tl = (uint32_t)(k + 1 - j); t.ok = true;
+    return t;
+}
+
+__device__ __forceinline__ int skip_open_b(const uint8_t *b, int lo, int hi, int s, int *err) {
+    for (int back = 1; back < MAXTOK && s - back >= lo; back++) {
+        const uint8_t c = b[s - back];
+        if (c == '>') return s;
+        if (c == '<') {
+            const Tok t = parse_tok_b(b, hi, s - back);
+            if (!t.ok) { *err = 1; return s; }
+            const int end = s - back + (int)t.tl;
+            return end > s ? end : s;
+        }
+    }
+    return s;
+}
+
+constexpr int ZPAD = 32;                // staged bytes either side of a block (a token is at most MAXTOK - 1 long)
+
+// stage in[blk0 - ZPAD, blk0 + ZTILE + ZPAD) with 16-byte loads; returns the valid index range
+__device__ __forceinline__ void stage_block(const uint8_t *__restrict__ in, size_t n, size_t blk0, uint8_t *sin, int *lo, int *hi) {
+    for (int v = threadIdx.x; v < (ZTILE + 2 * ZPAD) / 16; v += ZB) {
+        const long long P = (long long)blk0 - ZPAD + 16ll * v;
+        uint4 x = {0, 0, 0, 0};
+        if (P >= 0 && P + 16 <= (long long)n) x = *reinterpret_cast<const uint4 *>(in + P);
+        else if (P + 16 > 0 && P < (long long)n) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)n) w[k >> 2] |= (uint32_t)in[q] << (8 * (k & 3)); }
+            x = {w[0], w[1], w[2], w[3]};
+        }
+        reinterpret_cast<uint4 *>(sin)[v] = x;
+    }
+    *lo = blk0 ? 0 : ZPAD;
+    *hi = (int)min((size_t)(ZTILE + 2 * ZPAD), n - blk0 + ZPAD);
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(ZB) void k_lzd_count(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, int *__restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t sin[ZTILE + 2 * ZPAD];
     __shared__ unsigned long long part[ZB / 64];
-    const size_t s = (size_t)blockIdx.x * ZTILE + threadIdx.x * 16;
+    int lo, hi;
+    stage_block(in, n, (size_t)blockIdx.x * ZTILE, sin, &lo, &hi);
+    const int s = ZPAD + threadIdx.x * 16;
     unsigned long long mine = 0;
-    if (s < n) {
+    if (s < hi) {
         int e = 0;
-        size_t pos = skip_open_token(in, n, s, &e);
-        const size_t lim = min(s + 16, n);
+        int pos = skip_open_b(sin, lo, hi, s, &e);
+        const int lim = min(s + 16, hi);
         while (pos < lim) {
-            if (in[pos] == '<') {
-                const Tok t = parse_tok(in, n, pos);
+            if (sin[pos] == '<') {
+                const Tok t = parse_tok_b(sin, hi, pos);
                 if (!t.ok) { e = 1; pos++; continue; }
                 mine += t.len; pos += t.tl;
             } else { mine++; pos++; }
@@ -136,6 +195,241 @@ __global__ __launch_bounds__(ZB) void k_lzd_gather(const uint32_t *__restrict__ 
     for (uint32_t p = blockIdx.x * ZB + threadIdx.x; p < E; p += stride) {
         const uint32_t a = src[p];
         if (a != p) esc[p] = esc[a];      // roots (literals) are never written here
+    }
+}
+
+// ------------------------------------------------------------------ L2: tile path
+constexpr int DT = 16384;               // escaped-stream bytes per resolve tile
+constexpr int DTH = 1024;               // threads of the tile kernels: 16 bytes per lane
+constexpr int DGRP = 32;                // tiles per chain group
+constexpr uint32_t D_LOC = 0x4000u;     // descriptor: position inside the tile
+constexpr uint32_t D_EXT = 0x8000u;     // descriptor: position inside the previous tile's tail; otherwise the literal byte
+constexpr uint32_t D_PAY = 0x3FFFu;
+constexpr int D_BIG = 32;               // longer tokens are expanded by the whole block
+constexpr int D_NBIG = DT / D_BIG + 2;
+static_assert(DT / 16 == DTH && DT <= 16384, "one 16-byte span per lane; 14-bit payload");
+
+// validate every token (lzss.go:349-350), record the largest back-pointer and, for every output
+// tile, the item that produces its first byte: {input position, output position of the item}
+__global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
+                                                  uint2 *__restrict__ tile_info, uint32_t *__restrict__ maxptr, int *__restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t sin[ZTILE + 2 * ZPAD];
+    __shared__ unsigned long long wsum[ZB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t blk0 = (size_t)blockIdx.x * ZTILE;
+    int lo, hi;
+    stage_block(in, n, blk0, sin, &lo, &hi);
+    const int s = ZPAD + tid * 16, lim = min(s + 16, hi);
+    unsigned long long mine = 0;
+    int pos0 = s, e = 0;
+    if (s < hi) {
+        pos0 = skip_open_b(sin, lo, hi, s, &e);
+        int pos = pos0;
+        while (pos < lim) {
+            if (sin[pos] == '<') { const Tok t = parse_tok_b(sin, hi, pos); if (!t.ok) { pos++; continue; } mine += t.len; pos += t.tl; }
+            else { mine++; pos++; }
+        }
+    }
+    unsigned long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned long long o = blk_off[blockIdx.x] + incl - mine;
+    for (int k = 0; k < wv; k++) o += wsum[k];
+    uint32_t mp = 0;
+    if (s < hi) {
+        int pos = pos0;
+        while (pos < lim) {
+            const uint32_t ipos = (uint32_t)(blk0 + (size_t)(pos - ZPAD));
+            if (sin[pos] == '<') {
+                const Tok t = parse_tok_b(sin, hi, pos);
+                if (!t.ok) { pos++; continue; }
+                if (t.ptr > o || t.len > t.ptr) e = 1;       // absolutePointer >= 0 and the slice ends inside out (lzss.go:349-350)
+                else if (t.len) {
+                    mp = max(mp, t.ptr);
+                    for (unsigned long long k = (o + DT - 1) / DT; k * DT < o + t.len; k++) tile_info[k] = make_uint2(ipos, (uint32_t)o);
+                }
+                o += t.len; pos += t.tl;
+            } else {
+                if (o % DT == 0) tile_info[o / DT] = make_uint2(ipos, (uint32_t)o);
+                o++; pos++;
+            }
+        }
+    }
+    for (int d = 32; d; d >>= 1) mp = max(mp, (uint32_t)__shfl_down(mp, d));
+    if (lane == 0 && mp) atomicMax(maxptr, mp);
+    if (e) atomicOr(err, 1);
+}
+
+struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback; };
+
+__global__ __launch_bounds__(DTH) void k_lzd_resolve(ResolveArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t sin[DT + 96];
+    __shared__ __attribute__((aligned(16))) uint16_t sd[DT];
+    __shared__ uint32_t s_part[DTH / 64];
+    __shared__ uint32_t s_big[D_NBIG * 3];
+    __shared__ uint32_t s_nbig;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t k = blockIdx.x, ts = k * DT;
+    const int tlen = (int)min((uint32_t)DT, a.E - ts);
+    const uint2 info = a.tile_info[k];
+    const size_t in0 = info.x;
+    const size_t in1 = k + 1 < a.n_tiles ? min(a.n, (size_t)a.tile_info[k + 1].x + MAXTOK) : a.n;
+    if (in1 - in0 > (size_t)(DT + 64)) { if (tid == 0) *a.fallback = 1; return; }   // zero-length tokens can stretch a tile's input without bound
+    const size_t inA = in0 & ~(size_t)15;
+    const int lo = (int)(in0 - inA), hi = lo + (int)(in1 - in0);
+    for (int v = tid; v * 16 < hi; v += DTH) {
+        const size_t P = inA + 16 * (size_t)v;
+        uint4 x = {0, 0, 0, 0};
+        if (P + 16 <= a.n) x = *reinterpret_cast<const uint4 *>(a.in + P);
+        else { uint32_t w[4] = {0, 0, 0, 0}; for (int q = 0; q < 16 && P + q < a.n; q++) w[q >> 2] |= (uint32_t)a.in[P + q] << (8 * (q & 3)); x = {w[0], w[1], w[2], w[3]}; }
+        reinterpret_cast<uint4 *>(sin)[v] = x;
+    }
+    if (tid == 0) s_nbig = 0;
+    __syncthreads();
+    const int TL = (int)a.TL;
+    auto token_desc = [&](int x, uint32_t ptr) -> uint16_t {              // source of output byte x of a token with this back-pointer
+        const int q = x - (int)ptr;
+        return (uint16_t)(q >= 0 ? (D_LOC | (uint32_t)q) : (D_EXT | (uint32_t)(TL + q)));
+    };
+    long long run = (long long)info.y - (long long)ts;                    // output offset (relative to the tile) of the first staged item: <= 0
+    for (int base = lo; base < hi; base += DTH * 16) {
+        const int s = base + tid * 16, lim = min(s + 16, hi);
+        uint32_t mine = 0;
+        int pos0 = s, e = 0;
+        if (s < hi) {
+            pos0 = skip_open_b(sin, lo, hi, s, &e);
+            int pos = pos0;
+            while (pos < lim) {
+                if (sin[pos] == '<') { const Tok t = parse_tok_b(sin, hi, pos); if (!t.ok) { pos++; continue; } mine += t.len; pos += t.tl; }
+                else { mine++; pos++; }
+            }
+        }
+        uint32_t incl = mine;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        long long o = run + (long long)(incl - mine);
+        uint32_t tot = 0;
+        for (int w = 0; w < DTH / 64; w++) { if (w < wv) o += s_part[w]; tot += s_part[w]; }
+        if (s < hi) {
+            int pos = pos0;
+            while (pos < lim && o < tlen) {
+                if (sin[pos] == '<') {
+                    const Tok t = parse_tok_b(sin, hi, pos);
+                    if (!t.ok) { pos++; continue; }
+                    if (t.len > D_BIG) {                                  // o > -2^32: the 32-bit two's complement survives the round trip
+                        if (o + (long long)t.len > 0) { const uint32_t b = atomicAdd(&s_nbig, 1u); s_big[3 * b] = (uint32_t)o; s_big[3 * b + 1] = t.ptr; s_big[3 * b + 2] = t.len; }
+                    } else {
+                        for (int j = 0; j < (int)t.len; j++) { const long long x = o + j; if (x >= 0 && x < tlen) sd[x] = token_desc((int)x, t.ptr); }
+                    }
+                    o += t.len; pos += t.tl;
+                } else {
+                    if (o >= 0) sd[o] = sin[pos];
+                    o++; pos++;
+                }
+            }
+        }
+        run += tot;
+        __syncthreads();
+    }
+    for (uint32_t b = 0; b < s_nbig; b++) {
+        const int o = (int)s_big[3 * b]; const uint32_t ptr = s_big[3 * b + 1], len = s_big[3 * b + 2];   // o in (-DT-len, DT)
+        const int x0 = max(o, 0), x1 = (int)min((long long)o + len, (long long)tlen);
+        for (int x = x0 + tid; x < x1; x += DTH) sd[x] = token_desc(x, ptr);
+    }
+    __syncthreads();
+    for (;;) {                                                            // in-tile pointer jumping, all in LDS
+        bool any = false;
+        for (int x = tid; x < tlen; x += DTH) {
+            const uint32_t v = sd[x];
+            if ((v >> 14) == 1) { const uint32_t w = sd[v & D_PAY]; sd[x] = (uint16_t)w; any = any || (w >> 14) == 1; }
+        }
+        if (!__syncthreads_or(any)) break;
+    }
+    for (int v = tid; v * 8 < tlen; v += DTH) reinterpret_cast<uint4 *>(a.desc + ts)[v] = reinterpret_cast<const uint4 *>(sd)[v];
+}
+
+// C_g = the tail map of the group's last tile expressed in the tail that precedes the group
+__global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict__ desc, uint32_t TL, uint16_t *__restrict__ comp) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
+    uint16_t *cur = reinterpret_cast<uint16_t *>(dsm), *nxt = cur + TL;
+    const size_t k0 = (size_t)blockIdx.x * DGRP;
+    for (uint32_t j = threadIdx.x; j < TL; j += DTH) cur[j] = desc[k0 * DT + DT - TL + j];
+    __syncthreads();
+    for (int t = 1; t < DGRP; t++) {
+        const uint16_t *m = desc + (k0 + t) * DT + DT - TL;
+        for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = m[j]; nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
+        __syncthreads();
+        uint16_t *sw = cur; cur = nxt; nxt = sw;
+    }
+    for (uint32_t j = threadIdx.x; j < TL; j += DTH) comp[(size_t)blockIdx.x * TL + j] = cur[j];
+}
+
+// gtail[g] = the bytes of the tail that ends group g: one block walks the groups in order
+__global__ __launch_bounds__(DTH) void k_lzd_chain(const uint16_t *__restrict__ comp, uint32_t TL, uint32_t n_links, uint8_t *__restrict__ gtail) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
+    uint8_t *prev = dsm, *val = dsm + TL;
+    constexpr int PER = DT / DTH;                                         // TL <= DT: at most this many entries per lane
+    for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = 0;
+    uint32_t m[PER], mn[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) { const uint32_t j = threadIdx.x + q * DTH; m[q] = j < TL && n_links ? comp[j] : 0; mn[q] = 0; }
+    __syncthreads();
+    for (uint32_t g = 0; g < n_links; g++) {
+        if (g + 1 < n_links) {                                            // the next group's map is in flight during this step
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) mn[q] = comp[(size_t)(g + 1) * TL + j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t j = threadIdx.x + q * DTH;
+            if (j < TL) { const uint8_t b = (m[q] & D_EXT) ? prev[m[q] & D_PAY] : (uint8_t)m[q]; val[j] = b; gtail[(size_t)g * TL + j] = b; }
+        }
+        __syncthreads();
+        uint8_t *sw = prev; prev = val; val = sw;
+#pragma unroll
+        for (int q = 0; q < PER; q++) m[q] = mn[q];
+    }
+}
+
+// the bytes of every tile of a group, tile after tile: a literal, or a byte of the previous tile's tail
+__global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t E,
+                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
+    uint8_t *prev = dsm, *nxt = dsm + TL;
+    const uint32_t g = blockIdx.x;
+    for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = g ? gtail[(size_t)(g - 1) * TL + j] : 0;
+    const uint32_t x0 = threadIdx.x * 16;
+    auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {
+        if (k < n_tiles && k * DT + x0 < E) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = p[0]; a1 = p[1]; }
+    };
+    uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, e0 = d0, e1 = d1;
+    load(g * DGRP, d0, d1);
+    __syncthreads();
+    for (int t = 0; t < DGRP; t++) {
+        const uint32_t k = g * DGRP + t;
+        if (k >= n_tiles) break;
+        load(k + 1 < (g + 1) * DGRP ? k + 1 : n_tiles, e0, e1);            // next tile's descriptors in flight during this one
+        const uint32_t ts = k * DT, len = min((uint32_t)DT, E - ts);
+        if (x0 < len) {
+            const uint32_t w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint32_t v = (w[q >> 1] >> (16 * (q & 1))) & 0xFFFF;
+                const uint32_t b = (v & D_EXT) ? prev[v & D_PAY] : (v & 0xFF);
+                o[q >> 2] |= b << (8 * (q & 3));
+            }
+            if (x0 + 16 <= len) *reinterpret_cast<uint4 *>(esc + ts + x0) = make_uint4(o[0], o[1], o[2], o[3]);
+            else for (uint32_t q = 0; x0 + q < len; q++) esc[ts + x0 + q] = (uint8_t)(o[q >> 2] >> (8 * (q & 3)));
+            if (x0 + 16 > DT - TL) {                                      // this span overlaps the tile's tail
+                for (uint32_t q = 0; q < 16; q++) { const uint32_t x = x0 + q; if (x >= DT - TL) nxt[x - (DT - TL)] = (uint8_t)(o[q >> 2] >> (8 * (q & 3))); }
+            }
+        }
+        __syncthreads();
+        uint8_t *sw = prev; prev = nxt; nxt = sw;
+        d0 = e0; d1 = e1;
     }
 }
 
@@ -252,13 +546,13 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: compressed input too large for one call");
     void *p; int rc;
     const uint32_t n_cb = (uint32_t)ceil_div(n, ZTILE);
-    rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 4) * 8, &p); if (rc) return rc;
+    rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 4) * 8, &p); if (rc) return rc;   // ... + flags: [0] error, [1] changed, [2] largest back-pointer, [3] tile path gave up
     unsigned long long *d_blen = (unsigned long long *)p, *d_boff = d_blen + n_cb, *d_btot = d_boff + n_cb;
-    int *d_flag = (int *)(d_btot + 1);                                    // [0] error, [1] changed
+    int *d_flag = (int *)(d_btot + 1);
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     volatile int *hflag = (volatile int *)(h64 + 1);
-    RSN_HIP(hipMemsetAsync(d_flag, 0, 8, s));
+    RSN_HIP(hipMemsetAsync(d_flag, 0, 16, s));
     RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
     RSN_LAUNCH("lzss_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_blen, d_boff, n_cb, d_btot);
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
@@ -268,25 +562,60 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (h64[0] >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
-    rc = dev_buf(c, 14, (size_t)E * 4 + 64, &p); if (rc) return rc;
-    uint32_t *d_src = (uint32_t *)p;
     rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_esc = (uint8_t *)p;
-    RSN_LAUNCH("lzss_dec_expand", k_lzd_expand, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_src, d_esc, d_flag);
-    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 8, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipStreamSynchronize(s));   // src[] is only safe to chase once every token has been validated
+    // ---- L2
+    const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), n_groups = (uint32_t)ceil_div(n_tiles, DGRP);
+    rc = dev_buf(c, 19, (size_t)n_tiles * 8 + 64, &p); if (rc) return rc;
+    uint2 *d_tinfo = (uint2 *)p;
+    uint32_t *d_maxptr = (uint32_t *)(d_flag + 2);
+    int *d_fallback = d_flag + 3;
+    volatile uint32_t *hmax = (volatile uint32_t *)(hflag + 2);
+    RSN_LAUNCH("lzss_dec_tiles", k_lzd_tiles, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_tinfo, d_maxptr, d_flag);
+    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));   // nothing may chase a pointer before every token has been validated
     if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
-    const uint32_t grid = (uint32_t)std::min<size_t>(ceil_div(E, ZB), 8192);
-    for (int round = 0;; round++) {
-        if (round > 40) return c.fail(RSN_ERR_DEVICE, "lzss: pointer jumping did not converge");
-        RSN_HIP(hipMemsetAsync(d_flag + 1, 0, 4, s));
-        RSN_LAUNCH("lzss_dec_jump", k_lzd_jump, dim3(grid), dim3(ZB), 0, s, d_src, E, d_flag + 1);
-        RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 8, hipMemcpyDeviceToHost, s));
+    static const bool force_jump = getenv("RSN_LZSS_DEC_JUMP") != nullptr;   // A/B switch: whole-stream pointer jumping
+    bool tile_path = !force_jump && hmax[0] <= (uint32_t)DT;
+    if (tile_path) {
+        uint32_t TL = 256;
+        while (TL < hmax[0]) TL <<= 1;
+        rc = dev_buf(c, 14, ((size_t)n_tiles * DT + 64) * 2, &p); if (rc) return rc;
+        uint16_t *d_desc = (uint16_t *)p;
+        rc = dev_buf(c, 22, (size_t)n_groups * TL * 3 + 64, &p); if (rc) return rc;
+        uint16_t *d_comp = (uint16_t *)p;
+        uint8_t *d_gtail = (uint8_t *)(d_comp + (size_t)n_groups * TL);
+        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback};
+        RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
+        static thread_local size_t attr_tl = 0;
+        if ((size_t)TL * 4 > attr_tl) {
+            RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lzd_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TL * 4)));
+            attr_tl = (size_t)TL * 4;
+        }
+        if (n_groups > 1) {
+            RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, d_comp);
+            RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_groups - 1, d_gtail);
+        }
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, d_esc);
+        RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
-        if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
-        if (!hflag[1]) break;
+        if (hflag[3]) tile_path = false;                                  // a tile's input did not fit (zero-length tokens): redo with the general path
     }
-    RSN_LAUNCH("lzss_dec_gather", k_lzd_gather, dim3(grid), dim3(ZB), 0, s, d_src, d_esc, E);
+    if (!tile_path) {
+        rc = dev_buf(c, 14, (size_t)E * 4 + 64, &p); if (rc) return rc;
+        uint32_t *d_src = (uint32_t *)p;
+        RSN_LAUNCH("lzss_dec_expand", k_lzd_expand, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_src, d_esc, d_flag);
+        const uint32_t grid = (uint32_t)std::min<size_t>(ceil_div(E, ZB), 8192);
+        for (int round = 0;; round++) {
+            if (round > 40) return c.fail(RSN_ERR_DEVICE, "lzss: pointer jumping did not converge");
+            RSN_HIP(hipMemsetAsync(d_flag + 1, 0, 4, s));
+            RSN_LAUNCH("lzss_dec_jump", k_lzd_jump, dim3(grid), dim3(ZB), 0, s, d_src, E, d_flag + 1);
+            RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 8, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            if (!hflag[1]) break;
+        }
+        RSN_LAUNCH("lzss_dec_gather", k_lzd_gather, dim3(grid), dim3(ZB), 0, s, d_src, d_esc, E);
+    }
     // ---- unescape
     const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);
     rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)n_ub * 2 + 64, &p); if (rc) return rc;

@@ -41,10 +41,12 @@ def main():
     print("%s %d MiB: encode %.1f ms (%.2f GB/s) -> %d B (%.2f%%)" % (kind, mib, (t1 - t0) * 1e3, n / (t1 - t0) / 1e9, c.numel(), 100.0 * c.numel() / n))
     for k, (cnt, ms) in sorted(_lib.prof_get().items()):
         print("  %-20s %3d launches  %.3f ms total" % (k, cnt, ms))
+    out = torch.empty(n + (1 << 16), dtype=torch.uint8, device="cuda")
+    d = lz.decompress_tensor(c, out=out)
+    torch.cuda.synchronize()
     _lib.prof_reset()
-    d = lz.decompress_tensor(c)
     t0 = time.perf_counter()
-    d = lz.decompress_tensor(c)
+    d = lz.decompress_tensor(c, out=out)
     t1 = time.perf_counter()
     print("decode %.1f ms (%.2f GB/s) lossless=%s" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e9, bool(torch.equal(d, src))))
     for k, (cnt, ms) in sorted(_lib.prof_get().items()):
