@@ -65,39 +65,118 @@ __device__ __forceinline__ size_t skip_open_token(const uint8_t *__restrict__ in
     return s;
 }
 
-// The same two helpers over a staged copy (LDS): valid indices are [lo, hi).
-__device__ __forceinline__ Tok parse_tok_b(const uint8_t *b, int hi, int j) {
+// ------------------------------------------------------------------ span parser
+// A lane owns 16 staged bytes.  Instead of walking them byte by byte (serial LDS reads, and a
+// wavefront pays for every lane's control path) it classifies them with bit masks.  Every '<'
+// opens a token (a literal '<' is escaped, lzss.go:373-377) that runs to the first '>' after
+// it, so with C = the bytes that are not '>' and S = the '<' bytes (plus bit 0 when the span
+// starts inside a token) the carry chain of C + S marks exactly the token bytes.  A token is at
+// most MAXTOK - 1 = 23 bytes, so whether a span starts inside one is decided by the last '<' or
+// '>' among the 22 bytes before it.
+__device__ __forceinline__ uint32_t pack_bit7(uint32_t z) { return ((z >> 7) * 0x00204081u >> 21) & 0xFu; }   // bit 7 of each byte -> 4 bits
+
+__device__ __forceinline__ void load_span(const uint32_t *sw, int sbyte, uint32_t w[4]) {      // 16 staged bytes from any offset
+    const int q = sbyte >> 2; const uint32_t sh = (uint32_t)(sbyte & 3) * 8;
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = sw[q + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+}
+
+// '<' mask in the low half, '>' mask in the high half
+__device__ __forceinline__ uint32_t ltgt_masks(const uint32_t w[4]) {
+    uint32_t lt = 0, gt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t y = w[k] ^ 0x3C3C3C3Cu;                            // '<' -> 00, '>' -> 02
+        const uint32_t y2 = y & 0xFDFDFDFDu;
+        const uint32_t t = ((y2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y2;       // bit 7 clear iff the byte is '<' or '>'
+        const uint32_t z = ~t & 0x80808080u;
+        const uint32_t g = z & (y << 6);                                  // bit 1 tells them apart
+        lt |= pack_bit7(z & ~g) << (4 * k);
+        gt |= pack_bit7(g) << (4 * k);
+    }
+    return lt | (gt << 16);
+}
+
+// the token whose '<' is staged byte j; sw = dword view, zero past the data, readable 28 bytes past j
+__device__ __forceinline__ Tok parse_tok_w(const uint32_t *sw, int j) {
+    const int q = (j + 1) >> 2; const uint32_t sh = (uint32_t)((j + 1) & 3) * 8;
+    uint32_t d[7], a[6];
+#pragma unroll
+    for (int k = 0; k < 7; k++) d[k] = sw[q + k];
+    uint32_t cm = 0, gm = 0, dm = 0;                                      // ',' / '>' / digit masks over the 24 bytes after '<'
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        a[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+        const uint32_t y = a[k] ^ 0x30303030u;                            // digits -> 00..09, ',' -> 1C, '>' -> 0E
+        const uint32_t td = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;        // bit 7 clear iff 00..09
+        const uint32_t yc = y ^ 0x1C1C1C1Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
+        const uint32_t yg = y ^ 0x0E0E0E0Eu, tg = ((yg & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yg;
+        dm |= pack_bit7(~td & 0x80808080u) << (4 * k);
+        cm |= pack_bit7(~tc & 0x80808080u) << (4 * k);
+        gm |= pack_bit7(~tg & 0x80808080u) << (4 * k);
+    }
     Tok t{0, 0, 0, false};
-    int k = j + 1;
-    unsigned long long v = 0; int nd = 0;
-    while (k < hi && nd < 10 && b[k] >= '0' && b[k] <= '9') { v = v * 10 + (b[k] - '0'); k++; nd++; }
-    if (nd == 0 || k >= hi || b[k] != ',' || v > 0xFFFFFFFFull) return t;
-    t.ptr = (uint32_t)v; k++;
-    v = 0; nd = 0;
-    while (k < hi && nd < 10 && b[k] >= '0' && b[k] <= '9') { v = v * 10 + (b[k] - '0'); k++; nd++; }
-    if (nd == 0 || k >= hi || b[k] != '>' || v > 0xFFFFFFFFull) return t;
-    t.len = (uint32_t)v; t.tl = (uint32_t)(k + 1 - j); t.ok = true;
+    const uint32_t pc = (uint32_t)__builtin_ctz(cm | (1u << 24)), pg = (uint32_t)__builtin_ctz(gm | (1u << 24));
+    if (pc < 1 || pc > 10 || pg < pc + 2 || pg > pc + 11) return t;     // 1..10 digits, ',', 1..10 digits, '>' (the first one)
+    const uint32_t need = ((1u << pg) - 1u) & ~(1u << pc);
+    if ((dm & need) != need) return t;
+    const unsigned long long A0 = a[0] | ((unsigned long long)a[1] << 32), A1 = a[2] | ((unsigned long long)a[3] << 32),
+                             A2 = a[4] | ((unsigned long long)a[5] << 32);
+    auto dig = [&](uint32_t k) { const unsigned long long W = k < 8 ? A0 : k < 16 ? A1 : A2; return (uint32_t)(W >> (8 * (k & 7))) & 0xFu; };
+    unsigned long long v = 0;
+    for (uint32_t k = 0; k < pc; k++) v = v * 10 + dig(k);
+    if (v > 0xFFFFFFFFull) return t;
+    t.ptr = (uint32_t)v;
+    v = 0;
+    for (uint32_t k = pc + 1; k < pg; k++) v = v * 10 + dig(k);
+    if (v > 0xFFFFFFFFull) return t;
+    t.len = (uint32_t)v; t.tl = pg + 2; t.ok = true;
     return t;
 }
 
-__device__ __forceinline__ int skip_open_b(const uint8_t *b, int lo, int hi, int s, int *err) {
-    for (int back = 1; back < MAXTOK && s - back >= lo; back++) {
-        const uint8_t c = b[s - back];
-        if (c == '>') return s;
-        if (c == '<') {
-            const Tok t = parse_tok_b(b, hi, s - back);
-            if (!t.ok) { *err = 1; return s; }
-            const int end = s - back + (int)t.tl;
-            return end > s ? end : s;
+struct Span {
+    uint32_t w[4];                       // the 16 bytes
+    uint32_t lit;                        // bit j: byte j is a literal
+    uint32_t ntok;                       // tokens that START in the span (a valid stream has at most 4: "<1,1>" is 5 bytes)
+    uint32_t tj[4], tptr[4], tlen[4];
+    uint32_t out;                        // bytes the span's items produce
+    bool err;
+};
+
+// masks[] holds ltgt_masks of every span, two spans of lead-in included: masks[sp + 2] is span sp
+__device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *masks, int sp, int sbyte, int valid, Span &r) {
+    const uint32_t m0 = masks[sp + 2], m1 = masks[sp + 1], m2 = masks[sp];
+    const uint32_t ltw = (m1 << 16) | (m2 & 0xFFFFu), gtw = (m1 & 0xFFFF0000u) | (m2 >> 16);   // the 32 bytes before the span
+    const uint32_t cin = (ltw & 0xFFFFFC00u) > (gtw & 0xFFFFFC00u) ? 1u : 0u;                  // last of '<','>' in the 22 bytes before is '<'
+    const uint32_t vm = valid >= 16 ? 0xFFFFu : ((1u << valid) - 1u);
+    const uint32_t lt = m0 & vm, C = ~(m0 >> 16) & 0xFFFFu;
+    const uint32_t T = C + (lt | cin);
+    r.lit = ~(T ^ C) & vm;
+    r.ntok = 0; r.err = false;
+    r.out = (uint32_t)__builtin_popcount(r.lit);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r.tj[k] = 16; r.tptr[k] = 0; r.tlen[k] = 0; }
+    uint32_t starts = lt;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (starts) {
+            const int j = __builtin_ctz(starts);
+            starts &= starts - 1;
+            const Tok t = parse_tok_w(sw, sbyte + j);
+            if (!t.ok) r.err = true;
+            else { r.tj[k] = (uint32_t)j; r.tptr[k] = t.ptr; r.tlen[k] = t.len; r.out += t.len; r.ntok = k + 1; }
         }
     }
-    return s;
+    if (starts) r.err = true;                                             // a fifth '<' cannot start a well-formed token
 }
 
-constexpr int ZPAD = 32;                // staged bytes either side of a block (a token is at most MAXTOK - 1 long)
+constexpr int ZPAD = 32;                // staged bytes either side of a block (two spans; a token is at most MAXTOK - 1 long)
 
-// stage in[blk0 - ZPAD, blk0 + ZTILE + ZPAD) with 16-byte loads; returns the valid index range
-__device__ __forceinline__ void stage_block(const uint8_t *__restrict__ in, size_t n, size_t blk0, uint8_t *sin, int *lo, int *hi) {
+// stage in[blk0 - ZPAD, blk0 + ZTILE + ZPAD) with 16-byte loads (zero outside the stream) and classify every span
+__device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_t n, size_t blk0, uint32_t *sw, uint32_t *masks, Span &r) {
     for (int v = threadIdx.x; v < (ZTILE + 2 * ZPAD) / 16; v += ZB) {
         const long long P = (long long)blk0 - ZPAD + 16ll * v;
         uint4 x = {0, 0, 0, 0};
@@ -107,32 +186,29 @@ __device__ __forceinline__ void stage_block(const uint8_t *__restrict__ in, size
             for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)n) w[k >> 2] |= (uint32_t)in[q] << (8 * (k & 3)); }
             x = {w[0], w[1], w[2], w[3]};
         }
-        reinterpret_cast<uint4 *>(sin)[v] = x;
+        reinterpret_cast<uint4 *>(sw)[v] = x;
     }
-    *lo = blk0 ? 0 : ZPAD;
-    *hi = (int)min((size_t)(ZTILE + 2 * ZPAD), n - blk0 + ZPAD);
     __syncthreads();
+    const int tid = threadIdx.x;
+    load_span(sw, ZPAD + 16 * tid, r.w);
+    masks[tid + 2] = ltgt_masks(r.w);
+    if (tid < 2) { uint32_t w[4]; load_span(sw, 16 * tid, w); masks[tid] = ltgt_masks(w); }
+    __syncthreads();
+    const long long left = (long long)n - (long long)blk0 - 16ll * tid;   // valid bytes of this lane's span
+    return left >= 16 ? 16 : left > 0 ? (int)left : 0;
 }
 
 __global__ __launch_bounds__(ZB) void k_lzd_count(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, int *__restrict__ err) {
-    __shared__ __attribute__((aligned(16))) uint8_t sin[ZTILE + 2 * ZPAD];
+    __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
+    __shared__ uint32_t masks[ZB + 2];
     __shared__ unsigned long long part[ZB / 64];
-    int lo, hi;
-    stage_block(in, n, (size_t)blockIdx.x * ZTILE, sin, &lo, &hi);
-    const int s = ZPAD + threadIdx.x * 16;
+    Span r;
+    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, r);
     unsigned long long mine = 0;
-    if (s < hi) {
-        int e = 0;
-        int pos = skip_open_b(sin, lo, hi, s, &e);
-        const int lim = min(s + 16, hi);
-        while (pos < lim) {
-            if (sin[pos] == '<') {
-                const Tok t = parse_tok_b(sin, hi, pos);
-                if (!t.ok) { e = 1; pos++; continue; }
-                mine += t.len; pos += t.tl;
-            } else { mine++; pos++; }
-        }
-        if (e) atomicOr(err, 1);
+    if (valid) {
+        span_parse(sw, masks, threadIdx.x, ZPAD + 16 * threadIdx.x, valid, r);
+        mine = r.out;
+        if (r.err) atomicOr(err, 1);
     }
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
@@ -213,23 +289,16 @@ static_assert(DT / 16 == DTH && DT <= 16384, "one 16-byte span per lane; 14-bit 
 // tile, the item that produces its first byte: {input position, output position of the item}
 __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
                                                   uint2 *__restrict__ tile_info, uint32_t *__restrict__ maxptr, int *__restrict__ err) {
-    __shared__ __attribute__((aligned(16))) uint8_t sin[ZTILE + 2 * ZPAD];
+    __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
+    __shared__ uint32_t masks[ZB + 2];
     __shared__ unsigned long long wsum[ZB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t blk0 = (size_t)blockIdx.x * ZTILE;
-    int lo, hi;
-    stage_block(in, n, blk0, sin, &lo, &hi);
-    const int s = ZPAD + tid * 16, lim = min(s + 16, hi);
+    Span r;
+    const int valid = stage_block(in, n, blk0, sw, masks, r);
     unsigned long long mine = 0;
-    int pos0 = s, e = 0;
-    if (s < hi) {
-        pos0 = skip_open_b(sin, lo, hi, s, &e);
-        int pos = pos0;
-        while (pos < lim) {
-            if (sin[pos] == '<') { const Tok t = parse_tok_b(sin, hi, pos); if (!t.ok) { pos++; continue; } mine += t.len; pos += t.tl; }
-            else { mine++; pos++; }
-        }
-    }
+    int e = 0;
+    if (valid) { span_parse(sw, masks, tid, ZPAD + 16 * tid, valid, r); mine = r.out; e = r.err; }
     unsigned long long incl = mine;
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(incl, d); if (lane >= d) incl += y; }
     if (lane == 63) wsum[wv] = incl;
@@ -237,35 +306,46 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
     unsigned long long o = blk_off[blockIdx.x] + incl - mine;
     for (int k = 0; k < wv; k++) o += wsum[k];
     uint32_t mp = 0;
-    if (s < hi) {
-        int pos = pos0;
-        while (pos < lim) {
-            const uint32_t ipos = (uint32_t)(blk0 + (size_t)(pos - ZPAD));
-            if (sin[pos] == '<') {
-                const Tok t = parse_tok_b(sin, hi, pos);
-                if (!t.ok) { pos++; continue; }
-                if (t.ptr > o || t.len > t.ptr) e = 1;       // absolutePointer >= 0 and the slice ends inside out (lzss.go:349-350)
-                else if (t.len) {
-                    mp = max(mp, t.ptr);
-                    for (unsigned long long k = (o + DT - 1) / DT; k * DT < o + t.len; k++) tile_info[k] = make_uint2(ipos, (uint32_t)o);
+    if (valid && !r.err) {
+        const uint32_t ipos0 = (uint32_t)(blk0 + 16 * (size_t)tid);
+        unsigned long long before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((uint32_t)k < r.ntok) {
+                const unsigned long long oo = o + (uint32_t)__builtin_popcount(r.lit & ((1u << r.tj[k]) - 1u)) + before;
+                const uint32_t ptr = r.tptr[k], len = r.tlen[k];
+                if (ptr > oo || len > ptr) e = 1;           // absolutePointer >= 0 and the slice ends inside out (lzss.go:349-350)
+                else if (len) {
+                    mp = max(mp, ptr);
+                    for (unsigned long long t = (oo + DT - 1) / DT; t * DT < oo + len; t++) tile_info[t] = make_uint2(ipos0 + r.tj[k], (uint32_t)oo);
                 }
-                o += t.len; pos += t.tl;
-            } else {
-                if (o % DT == 0) tile_info[o / DT] = make_uint2(ipos, (uint32_t)o);
-                o++; pos++;
+                before += len;
+            }
+        }
+        const unsigned long long first = (o + DT - 1) / DT * DT;              // first tile boundary at or after the span's output
+        if (first < o + mine) {                                              // rare: some literal of the span may be a tile's first byte
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if ((r.lit >> j) & 1) {
+                    unsigned long long oo = o + (uint32_t)__builtin_popcount(r.lit & ((1u << j) - 1u));
+#pragma unroll
+                    for (int k = 0; k < 4; k++) oo += r.tj[k] < (uint32_t)j ? r.tlen[k] : 0u;
+                    if (oo % DT == 0) tile_info[oo / DT] = make_uint2(ipos0 + j, (uint32_t)oo);
+                }
             }
         }
     }
     for (int d = 32; d; d >>= 1) mp = max(mp, (uint32_t)__shfl_down(mp, d));
-    if (lane == 0 && mp) atomicMax(maxptr, mp);
+    if (lane == 0 && mp > __atomic_load_n(maxptr, __ATOMIC_RELAXED)) atomicMax(maxptr, mp);   // same-address atomics serialise: only raise it
     if (e) atomicOr(err, 1);
 }
 
 struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback; };
 
 __global__ __launch_bounds__(DTH) void k_lzd_resolve(ResolveArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t sin[DT + 96];
+    __shared__ __attribute__((aligned(16))) uint32_t sw[(DT + 128) / 4 + 8];
     __shared__ __attribute__((aligned(16))) uint16_t sd[DT];
+    __shared__ uint32_t masks[DTH + 2];
     __shared__ uint32_t s_part[DTH / 64];
     __shared__ uint32_t s_big[D_NBIG * 3];
     __shared__ uint32_t s_nbig;
@@ -278,12 +358,12 @@ __global__ __launch_bounds__(DTH) void k_lzd_resolve(ResolveArgs a) {
     if (in1 - in0 > (size_t)(DT + 64)) { if (tid == 0) *a.fallback = 1; return; }   // zero-length tokens can stretch a tile's input without bound
     const size_t inA = in0 & ~(size_t)15;
     const int lo = (int)(in0 - inA), hi = lo + (int)(in1 - in0);
-    for (int v = tid; v * 16 < hi; v += DTH) {
+    for (int v = tid; v * 16 < hi + 32; v += DTH) {                       // 32 bytes past the range: a token near its end is read whole
         const size_t P = inA + 16 * (size_t)v;
         uint4 x = {0, 0, 0, 0};
         if (P + 16 <= a.n) x = *reinterpret_cast<const uint4 *>(a.in + P);
-        else { uint32_t w[4] = {0, 0, 0, 0}; for (int q = 0; q < 16 && P + q < a.n; q++) w[q >> 2] |= (uint32_t)a.in[P + q] << (8 * (q & 3)); x = {w[0], w[1], w[2], w[3]}; }
-        reinterpret_cast<uint4 *>(sin)[v] = x;
+        else if (P < a.n) { uint32_t w[4] = {0, 0, 0, 0}; for (int q = 0; q < 16 && P + q < a.n; q++) w[q >> 2] |= (uint32_t)a.in[P + q] << (8 * (q & 3)); x = {w[0], w[1], w[2], w[3]}; }
+        reinterpret_cast<uint4 *>(sw)[v] = x;
     }
     if (tid == 0) s_nbig = 0;
     __syncthreads();
@@ -292,50 +372,59 @@ __global__ __launch_bounds__(DTH) void k_lzd_resolve(ResolveArgs a) {
         const int q = x - (int)ptr;
         return (uint16_t)(q >= 0 ? (D_LOC | (uint32_t)q) : (D_EXT | (uint32_t)(TL + q)));
     };
-    long long run = (long long)info.y - (long long)ts;                    // output offset (relative to the tile) of the first staged item: <= 0
-    for (int base = lo; base < hi; base += DTH * 16) {
-        const int s = base + tid * 16, lim = min(s + 16, hi);
+    // every token here has len <= ptr <= DT (k_lzd_tiles checked it), so 32-bit offsets cannot overflow
+    int run = (int)((long long)info.y - (long long)ts);                   // output offset (relative to the tile) of the first staged item: <= 0
+    for (int base = 0; lo + 16 * base < hi; base += DTH) {
+        const int sp = base + tid, sbyte = lo + 16 * sp;
+        const int valid = hi - sbyte >= 16 ? 16 : hi - sbyte > 0 ? hi - sbyte : 0;
+        Span r;
+        uint32_t m = 0, lead = 0;
+        if (valid) { load_span(sw, sbyte, r.w); m = ltgt_masks(r.w); }
+        if (tid < 2 && base) lead = masks[DTH + tid];                     // the last two spans of the previous round
+        __syncthreads();
+        masks[tid + 2] = m;
+        if (tid < 2) masks[tid] = lead;
+        __syncthreads();
         uint32_t mine = 0;
-        int pos0 = s, e = 0;
-        if (s < hi) {
-            pos0 = skip_open_b(sin, lo, hi, s, &e);
-            int pos = pos0;
-            while (pos < lim) {
-                if (sin[pos] == '<') { const Tok t = parse_tok_b(sin, hi, pos); if (!t.ok) { pos++; continue; } mine += t.len; pos += t.tl; }
-                else { mine++; pos++; }
-            }
-        }
+        if (valid) { span_parse(sw, masks, tid, sbyte, valid, r); mine = r.out; }
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_part[wv] = incl;
         __syncthreads();
-        long long o = run + (long long)(incl - mine);
+        int o = run + (int)(incl - mine);
         uint32_t tot = 0;
-        for (int w = 0; w < DTH / 64; w++) { if (w < wv) o += s_part[w]; tot += s_part[w]; }
-        if (s < hi) {
-            int pos = pos0;
-            while (pos < lim && o < tlen) {
-                if (sin[pos] == '<') {
-                    const Tok t = parse_tok_b(sin, hi, pos);
-                    if (!t.ok) { pos++; continue; }
-                    if (t.len > D_BIG) {                                  // o > -2^32: the 32-bit two's complement survives the round trip
-                        if (o + (long long)t.len > 0) { const uint32_t b = atomicAdd(&s_nbig, 1u); s_big[3 * b] = (uint32_t)o; s_big[3 * b + 1] = t.ptr; s_big[3 * b + 2] = t.len; }
+        for (int w = 0; w < DTH / 64; w++) { if (w < wv) o += (int)s_part[w]; tot += s_part[w]; }
+        if (valid && o < tlen) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if ((r.lit >> j) & 1) {
+                    int x = o + __builtin_popcount(r.lit & ((1u << j) - 1u));
+#pragma unroll
+                    for (int q = 0; q < 4; q++) x += r.tj[q] < (uint32_t)j ? (int)r.tlen[q] : 0;
+                    if (x >= 0 && x < tlen) sd[x] = (uint16_t)((r.w[j >> 2] >> (8 * (j & 3))) & 0xFF);
+                }
+            }
+            int before = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if ((uint32_t)q < r.ntok) {
+                    const int x0 = o + __builtin_popcount(r.lit & ((1u << r.tj[q]) - 1u)) + before;
+                    const uint32_t ptr = r.tptr[q], len = r.tlen[q];
+                    if (len > D_BIG) {
+                        if (x0 + (int)len > 0 && x0 < tlen) { const uint32_t b = atomicAdd(&s_nbig, 1u); s_big[3 * b] = (uint32_t)x0; s_big[3 * b + 1] = ptr; s_big[3 * b + 2] = len; }
                     } else {
-                        for (int j = 0; j < (int)t.len; j++) { const long long x = o + j; if (x >= 0 && x < tlen) sd[x] = token_desc((int)x, t.ptr); }
+                        for (int j = 0; j < (int)len; j++) { const int x = x0 + j; if (x >= 0 && x < tlen) sd[x] = token_desc(x, ptr); }
                     }
-                    o += t.len; pos += t.tl;
-                } else {
-                    if (o >= 0) sd[o] = sin[pos];
-                    o++; pos++;
+                    before += (int)len;
                 }
             }
         }
-        run += tot;
-        __syncthreads();
+        run += (int)tot;
     }
+    __syncthreads();
     for (uint32_t b = 0; b < s_nbig; b++) {
-        const int o = (int)s_big[3 * b]; const uint32_t ptr = s_big[3 * b + 1], len = s_big[3 * b + 2];   // o in (-DT-len, DT)
-        const int x0 = max(o, 0), x1 = (int)min((long long)o + len, (long long)tlen);
+        const int o = (int)s_big[3 * b]; const uint32_t ptr = s_big[3 * b + 1], len = s_big[3 * b + 2];
+        const int x0 = max(o, 0), x1 = min(o + (int)len, tlen);
         for (int x = x0 + tid; x < x1; x += DTH) sd[x] = token_desc(x, ptr);
     }
     __syncthreads();
