@@ -277,7 +277,7 @@ __global__ __launch_bounds__(ZB) void k_lzd_gather(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------ L2: tile path
 constexpr int DT = 16384;               // escaped-stream bytes per resolve tile
 constexpr int DTH = 1024;               // threads of the tile kernels: 16 bytes per lane
-constexpr int DGRP = 32;                // tiles per chain group
+constexpr int DGRP = 128;               // tiles per chain group (the serial chain walks E / (DT * DGRP) links)
 constexpr uint32_t D_LOC = 0x4000u;     // descriptor: position inside the tile
 constexpr uint32_t D_EXT = 0x8000u;     // descriptor: position inside the previous tile's tail; otherwise the literal byte
 constexpr uint32_t D_PAY = 0x3FFFu;
@@ -523,20 +523,49 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
 }
 
 // ------------------------------------------------------------------ L4: unescape
+// Every lane takes its 16 bytes with one load; the 5C bytes become a 16-bit mask.
+__device__ __forceinline__ uint32_t load16_esc(const uint8_t *__restrict__ esc, uint32_t E, uint32_t s, uint32_t w[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    if (s + 16 <= E) { const uint4 v = *reinterpret_cast<const uint4 *>(esc + s); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; return 16; }
+    if (s >= E) return 0;
+    const uint32_t len = E - s;
+    for (uint32_t k = 0; k < len; k++) w[k >> 2] |= (uint32_t)esc[s + k] << (8 * (k & 3));
+    return len;
+}
+
+__device__ __forceinline__ uint32_t mask_5c(const uint32_t w[4]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t y = w[k] ^ 0x5C5C5C5Cu;
+        const uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+        m |= pack_bit7(~t & 0x80808080u) << (4 * k);
+    }
+    return m;
+}
+
+// (all bytes are 5C) << 1 | parity of the trailing 5C run, for `len` bytes with 5C mask m
+__device__ __forceinline__ uint32_t run_summary(uint32_t m, uint32_t len) {
+    const uint32_t vm = len >= 16 ? 0xFFFFu : ((1u << len) - 1u);
+    const uint32_t non = ~m & vm;                                         // bytes that are not 5C
+    const uint32_t last = non ? 32u - (uint32_t)__builtin_clz(non) : 0u;  // index past the last of them
+    return (non ? 0u : 2u) | ((len - last) & 1u);
+}
+
 // per-block summary: is the whole block 5C, and the parity of its trailing 5C run
 __global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ esc, uint32_t E, uint8_t *__restrict__ summ) {
     __shared__ uint32_t s_last;          // highest index in the block that is not 5C, +1 (0 = none)
     if (threadIdx.x == 0) s_last = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * ZTILE;
-    const uint32_t s = base + threadIdx.x * 16;
-    uint32_t last = 0;
-    for (uint32_t k = 0; k < 16 && s + k < E; k++) if (esc[s + k] != 0x5C) last = threadIdx.x * 16 + k + 1;
-    if (last) atomicMax(&s_last, last);
+    uint32_t w[4];
+    const uint32_t len = load16_esc(esc, E, base + threadIdx.x * 16, w);
+    const uint32_t non = ~mask_5c(w) & (len >= 16 ? 0xFFFFu : ((1u << len) - 1u));
+    if (non) atomicMax(&s_last, threadIdx.x * 16 + 32u - (uint32_t)__builtin_clz(non));
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t len = min((uint32_t)ZTILE, E - base);
-        summ[blockIdx.x] = (uint8_t)((s_last == 0 ? 2 : 0) | ((len - s_last) & 1));   // bit1: all 5C; bit0: trailing-run parity
+        const uint32_t blen = min((uint32_t)ZTILE, E - base);
+        summ[blockIdx.x] = (uint8_t)((s_last == 0 ? 2 : 0) | ((blen - s_last) & 1));   // bit1: all 5C; bit0: trailing-run parity
     }
 }
 
@@ -568,13 +597,12 @@ __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ 
     }
 }
 
-// shared front end of count/write: the escape state at the start of this lane's 16 bytes
-__device__ __forceinline__ uint32_t lane_in_parity(const uint8_t *__restrict__ esc, uint32_t E, uint32_t base, uint32_t blk_par, uint8_t *s_sum) {
+// shared front end of count/write: loads the lane's bytes and returns the escape state at their start
+__device__ __forceinline__ uint32_t lane_in_parity(const uint8_t *__restrict__ esc, uint32_t E, uint32_t base, uint32_t blk_par, uint8_t *s_sum,
+                                                   uint32_t w[4], uint32_t *len) {
     const int tid = threadIdx.x;
-    const uint32_t s = base + tid * 16;
-    uint32_t last = 0, len = 0;
-    for (uint32_t k = 0; k < 16 && s + k < E; k++) { len++; if (esc[s + k] != 0x5C) last = k + 1; }
-    s_sum[tid] = (uint8_t)((last == 0 ? 2 : 0) | ((len - last) & 1));
+    *len = load16_esc(esc, E, base + tid * 16, w);
+    s_sum[tid] = (uint8_t)run_summary(mask_5c(w), *len);
     __syncthreads();
     uint32_t par = 0;
     int q = tid - 1;
@@ -587,13 +615,13 @@ __global__ __launch_bounds__(ZB) void k_une_count(const uint8_t *__restrict__ es
                                                   unsigned long long *__restrict__ blk_len) {
     __shared__ uint8_t s_sum[ZB];
     __shared__ uint32_t part[ZB / 64];
-    const uint32_t base = blockIdx.x * ZTILE;
-    uint32_t st = lane_in_parity(esc, E, base, in_par[blockIdx.x], s_sum);
-    const uint32_t s = base + threadIdx.x * 16;
+    uint32_t w[4], len;
+    uint32_t st = lane_in_parity(esc, E, blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
     uint32_t cnt = 0;
-    for (uint32_t k = 0; k < 16 && s + k < E; k++) {
-        const uint8_t v = esc[s + k];
-        if (v == 0x5C && !st) st = 1; else { st = 0; cnt++; }     // lzss.go:395-403
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (k < len) { if (v == 0x5C && !st) st = 1; else { st = 0; cnt++; } }     // lzss.go:395-403
     }
     for (int d = 32; d; d >>= 1) cnt += __shfl_down(cnt, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
@@ -601,30 +629,51 @@ __global__ __launch_bounds__(ZB) void k_une_count(const uint8_t *__restrict__ es
     if (threadIdx.x == 0) blk_len[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
 }
 
+// the block's output is contiguous: bytes go to LDS first, then out in 16-byte units
 __global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ esc, uint32_t E, const uint8_t *__restrict__ in_par,
                                                   const unsigned long long *__restrict__ blk_off, uint8_t *__restrict__ out) {
     __shared__ uint8_t s_sum[ZB];
     __shared__ uint32_t wsum[ZB / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[ZTILE / 4 + 8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t base = blockIdx.x * ZTILE;
-    const uint32_t st0 = lane_in_parity(esc, E, base, in_par[blockIdx.x], s_sum);
-    const uint32_t s = base + tid * 16;
+    uint32_t w[4], len;
+    const uint32_t st0 = lane_in_parity(esc, E, blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
     uint32_t st = st0, cnt = 0;
-    for (uint32_t k = 0; k < 16 && s + k < E; k++) { const uint8_t v = esc[s + k]; if (v == 0x5C && !st) st = 1; else { st = 0; cnt++; } }
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (k < len) { if (v == 0x5C && !st) st = 1; else { st = 0; cnt++; } }
+    }
     uint32_t incl = cnt;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    uint32_t pre = 0;
-    for (int k = 0; k < wv; k++) pre += wsum[k];
-    uint8_t *o = out + blk_off[blockIdx.x] + pre + incl - cnt;
+    uint32_t pre = 0, tot = 0;
+    for (int k = 0; k < ZB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
+    uint8_t *so = reinterpret_cast<uint8_t *>(s_out);
+    uint32_t o = pre + incl - cnt;
     st = st0;
-    for (uint32_t k = 0; k < 16 && s + k < E; k++) {
-        const uint8_t v = esc[s + k];
-        if (v == 0xFF && !st) *o++ = 0x3C;                 // EncodedOpening -> '<'
-        else if (v == 0x5C && !st) st = 1;                 // escape marker: emits nothing
-        else { st = 0; *o++ = v; }
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (k < len) {
+            if (v == 0xFF && !st) so[o++] = 0x3C;                         // EncodedOpening -> '<'
+            else if (v == 0x5C && !st) st = 1;                            // escape marker: emits nothing
+            else { st = 0; so[o++] = (uint8_t)v; }
+        }
     }
+    __syncthreads();
+    uint8_t *g = out + blk_off[blockIdx.x];
+    const uint32_t head = min(tot, (uint32_t)((16 - ((uintptr_t)g & 15)) & 15));   // bytes before the first 16-byte boundary
+    if ((uint32_t)tid < head) g[tid] = so[tid];
+    const uint32_t units = (tot - head) / 16;
+    for (uint32_t u = tid; u < units; u += ZB) {
+        uint32_t x[4];
+        load_span(s_out, (int)(head + 16 * u), x);
+        *reinterpret_cast<uint4 *>(g + head + 16 * u) = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    const uint32_t tail0 = head + 16 * units;
+    if (tail0 + tid < tot) g[tail0 + tid] = so[tail0 + tid];
 }
 
 // ======================================================================= host side
