@@ -342,7 +342,7 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
 
 struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback; };
 
-__global__ __launch_bounds__(DTH) void k_lzd_resolve(ResolveArgs a) {
+__global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 waves per SIMD: two blocks per CU
     __shared__ __attribute__((aligned(16))) uint32_t sw[(DT + 128) / 4 + 8];
     __shared__ __attribute__((aligned(16))) uint16_t sd[DT];
     __shared__ uint32_t masks[DTH + 2];
