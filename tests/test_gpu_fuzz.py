@@ -1,0 +1,125 @@
+"""GPU differential fuzzing: random streams through librsn and the CPU oracle must agree byte for
+byte -- or both must reject.  Seeds are fixed; sizes keep the oracle within seconds."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MORE = int(os.environ.get("RSN_FUZZ", "1"))      # RSN_FUZZ=20 runs twenty times the seeds
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from raisin_amd import RsnError, huffman, lz
+    return lz, huffman, RsnError
+
+
+def _token_stream(rng, n_items, *, max_ptr, bad=0.0):
+    """A hand-built LZSS stream: literal runs (never '<') and "<ptr,len>" tokens that are valid for
+    the decoder (len <= ptr <= bytes produced so far), with odd but legal spellings mixed in; with
+    probability `bad` an item is a malformed or out-of-range token."""
+    lit = bytes(b for b in range(256) if b != 0x3C)
+    out = bytearray()
+    produced = 0
+    for _ in range(n_items):
+        r = rng.random()
+        if produced == 0 or r < 0.45:
+            k = rng.choice((1, 1, 2, 3, 7, 15, 16, 17, 40, 300))
+            run = bytes(rng.choice(b">,0123456789\\\xff" if rng.random() < 0.3 else lit) for _ in range(k))
+            out += run
+            produced += k
+            continue
+        if rng.random() < bad:
+            out += rng.choice([b"<", b"<12", b"<12,", b"<,3>", b"<3,>", b"<1x,1>", b"<12,3<", b"<99999999999,1>", b"<5,99999999999>",
+                               b"<%d,1>" % (produced + 1), b"<2,3>", b"<4294967296,1>"])
+            continue
+        ptr = rng.randint(1, min(produced, max_ptr))
+        ln = rng.choice((0, 1, 2, ptr, rng.randint(0, ptr), min(ptr, rng.randint(0, 40))))
+        if produced > 300000:                                  # "<p,p>" doubles the output: keep the stream bounded
+            ln = min(ln, 40)
+        spelling = rng.random()
+        if spelling < 0.1:
+            tok = b"<%010d,%010d>" % (ptr, ln)                 # the longest legal token: 23 bytes
+        elif spelling < 0.2:
+            tok = b"<0%d,00%d>" % (ptr, ln)
+        else:
+            tok = b"<%d,%d>" % (ptr, ln)
+        out += tok
+        produced += ln
+    return bytes(out)
+
+
+@pytest.mark.parametrize("seed", range(12 * MORE))
+def test_lzss_decode_fuzz(mods, oracle, seed):
+    lz, _, RsnError = mods
+    rng = random.Random(1000 + seed)
+    for case in range(6):
+        max_ptr = rng.choice((3, 40, 4096, 9000, 16384, 40000, 1 << 30))
+        bad = 0.0 if case < 4 else 0.02
+        data = _token_stream(rng, rng.choice((5, 60, 800, 6000)), max_ptr=max_ptr, bad=bad)
+        try:
+            want = oracle.lzss_decompress(data)
+        except oracle.OracleError:
+            want = None
+        if want is None:
+            with pytest.raises(RsnError):
+                lz.Decompress(data)
+        else:
+            assert lz.Decompress(data) == want, (seed, case, max_ptr, len(data))
+
+
+def _structured(rng, n):
+    """Bytes with repeats at many scales: the encoder's bucket search, its hand-back to the sweep
+    and the greedy chain all get exercised."""
+    alpha = rng.choice([b"ab", b"abc", b"abcdefgh <\\\xff", bytes(range(32, 127)), bytes(range(256))])
+    pieces = [bytes(rng.choice(alpha) for _ in range(rng.choice((1, 2, 3, 5, 8, 13, 40, 300, 2000)))) for _ in range(12)]
+    out = bytearray()
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.5:
+            out += rng.choice(pieces)
+        elif r < 0.8:
+            out += bytes(rng.choice(alpha) for _ in range(rng.randint(1, 30)))
+        elif out:
+            back = rng.randint(1, min(len(out), 5000))
+            k = rng.randint(1, min(back, 600))
+            out += out[len(out) - back:len(out) - back + k]
+        else:
+            out += b"x"
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(10 * MORE))
+def test_lzss_encode_fuzz(mods, oracle, seed):
+    lz, _, _ = mods
+    rng = random.Random(2000 + seed)
+    for _ in range(3):
+        data = _structured(rng, rng.choice((200, 5000, 17000, 33000)))
+        w = rng.choice((4096, 4096, 4096, 1, 2, 17, 100, 1000, 4095, 5000, 8192))
+        c = lz.CompressAsync(data, False, w)
+        assert c == oracle.lzss_compress(data, w), (seed, len(data), w)
+        assert lz.Decompress(c) == data
+
+
+@pytest.mark.parametrize("seed", range(8 * MORE))
+def test_huffman_fuzz(mods, oracle, seed):
+    _, huffman, _ = mods
+    rng = random.Random(3000 + seed)
+    np_rng = np.random.default_rng(3000 + seed)
+    for _ in range(4):
+        k = rng.choice((1, 2, 3, 5, 17, 60, 128, 200, 256))
+        n = rng.choice((1, 2, 9, 257, 5000, 70000, 300001))
+        syms = rng.sample(range(256), k)
+        p = np_rng.dirichlet(np.full(k, rng.choice((0.05, 0.3, 1.0, 10.0))))
+        data = np.array(syms, dtype=np.uint8)[np_rng.choice(k, size=n, p=p)].tobytes()
+        c = huffman.Compress(data)
+        ref = oracle.huffman_compress(data)
+        assert c == ref, (seed, k, n)
+        try:
+            want = oracle.huffman_decompress(c)
+        except oracle.OracleError:
+            want = None
+        if want is not None:
+            assert huffman.Decompress(c) == want
