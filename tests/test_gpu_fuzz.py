@@ -19,10 +19,13 @@ def mods():
 def _token_stream(rng, n_items, *, max_ptr, bad=0.0):
     """A hand-built LZSS stream: literal runs (never '<') and "<ptr,len>" tokens that are valid for
     the decoder (len <= ptr <= bytes produced so far), with odd but legal spellings mixed in; with
-    probability `bad` an item is a malformed or out-of-range token."""
+    probability `bad` an item is an out-of-range token (both sides reject) or a spelling the
+    reference's error-dropping Atoi lets through but librsn refuses by design.
+    Returns (stream, has_loose_spelling)."""
     lit = bytes(b for b in range(256) if b != 0x3C)
     out = bytearray()
     produced = 0
+    loose = False
     for _ in range(n_items):
         r = rng.random()
         if produced == 0 or r < 0.45:
@@ -32,8 +35,11 @@ def _token_stream(rng, n_items, *, max_ptr, bad=0.0):
             produced += k
             continue
         if rng.random() < bad:
-            out += rng.choice([b"<", b"<12", b"<12,", b"<,3>", b"<3,>", b"<1x,1>", b"<12,3<", b"<99999999999,1>", b"<5,99999999999>",
-                               b"<%d,1>" % (produced + 1), b"<2,3>", b"<4294967296,1>"])
+            if rng.random() < 0.5:
+                out += rng.choice([b"<%d,1>" % (produced + 1), b"<2,3>", b"<4294967296,1>", b"<99999999999,1>", b"<5,99999999999>"])
+            else:
+                out += rng.choice([b"<", b"<12", b"<12,", b"<,3>", b"<3,>", b"<1x,1>", b"<12,3<", b"<+3,1>", b"<3,0x>", b"<00000000003,1>"])
+                loose = True
             continue
         ptr = rng.randint(1, min(produced, max_ptr))
         ln = rng.choice((0, 1, 2, ptr, rng.randint(0, ptr), min(ptr, rng.randint(0, 40))))
@@ -48,7 +54,7 @@ def _token_stream(rng, n_items, *, max_ptr, bad=0.0):
             tok = b"<%d,%d>" % (ptr, ln)
         out += tok
         produced += ln
-    return bytes(out)
+    return bytes(out), loose
 
 
 @pytest.mark.parametrize("seed", range(12 * MORE))
@@ -58,16 +64,19 @@ def test_lzss_decode_fuzz(mods, oracle, seed):
     for case in range(6):
         max_ptr = rng.choice((3, 40, 4096, 9000, 16384, 40000, 1 << 30))
         bad = 0.0 if case < 4 else 0.02
-        data = _token_stream(rng, rng.choice((5, 60, 800, 6000)), max_ptr=max_ptr, bad=bad)
+        data, loose = _token_stream(rng, rng.choice((5, 60, 800, 6000)), max_ptr=max_ptr, bad=bad)
         try:
             want = oracle.lzss_decompress(data)
         except oracle.OracleError:
             want = None
-        if want is None:
-            with pytest.raises(RsnError):
-                lz.Decompress(data)
+        try:
+            got = lz.Decompress(data)
+        except RsnError:
+            got = None
+        if got is None:
+            assert want is None or loose, (seed, case, max_ptr, len(data))      # refusing is only allowed where documented
         else:
-            assert lz.Decompress(data) == want, (seed, case, max_ptr, len(data))
+            assert got == want, (seed, case, max_ptr, len(data))
 
 
 def _structured(rng, n):
