@@ -46,7 +46,8 @@ int rsn_device_set(int device);
 int rsn_device_count(void);
 const char *rsn_last_error(void); /* thread-local, valid until the next call on this thread */
 const char *rsn_version(void);
-void rsn_free(void *p);           /* releases buffers returned through `out` below */
+void rsn_free(void *p);           /* releases buffers returned through `out` below (only rsn_free may: they carry a
+                                     library header; large ones are recycled, RSN_HOST_POOL=0 disables that) */
 
 /* ---- host-buffer entry points (what the cgo shim binds) ----------------
  * Input is borrowed for the duration of the call and never modified.  Output

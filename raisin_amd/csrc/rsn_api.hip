@@ -4,7 +4,10 @@
 #include "codecs.h"
 #include "rsn_common.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <mutex>
 
 namespace rsn {
 
@@ -71,7 +74,60 @@ void prof_collect(Ctx &c) {
 
 namespace {
 
-// Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a malloc'ed result.
+// Result buffers.  A fresh 1 GiB malloc costs ~150 ms of page faults when the D2H copy first
+// touches it -- several times the PCIe transfer itself -- so blocks of 1 MiB and more go back
+// to a small process-wide pool on rsn_free() and the next call of similar size reuses pages
+// that are already mapped (the cgo shim's pattern: call, C.GoBytes, rsn_free).  A 64-byte header
+// in front of the returned pointer carries the capacity.  RSN_HOST_POOL=0 turns the pool off.
+constexpr size_t RES_HDR = 64, POOL_MIN = 1u << 20;
+constexpr size_t POOL_BLOCKS = 4;
+struct ResHdr { unsigned long long magic, cap; };
+constexpr unsigned long long RES_MAGIC = 0x52534E5F52455330ull;
+std::mutex g_pool_mu;
+std::vector<std::pair<size_t, void *>> g_pool;                    // (capacity, base)
+
+bool pool_enabled() { static const bool on = !(getenv("RSN_HOST_POOL") && atoi(getenv("RSN_HOST_POOL")) == 0); return on; }
+
+void *result_alloc(size_t n) {
+    const size_t need = n ? n : 1;
+    if (need >= POOL_MIN && pool_enabled()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].first >= need && g_pool[i].first <= 2 * need + (16u << 20) && (best == g_pool.size() || g_pool[i].first < g_pool[best].first)) best = i;
+        if (best != g_pool.size()) {
+            void *base = g_pool[best].second;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return (uint8_t *)base + RES_HDR;
+        }
+    }
+    const bool big = need >= POOL_MIN;
+    const size_t cap = big ? round_up(need + need / 16, (size_t)2 << 20) : need;   // headroom: the next result is rarely the same size
+    void *base = nullptr;
+    if (posix_memalign(&base, big ? ((size_t)2 << 20) : 64, cap + RES_HDR)) return nullptr;
+    if (big) (void)madvise(base, cap + RES_HDR, MADV_HUGEPAGE);
+    ResHdr *h = (ResHdr *)base;
+    h->magic = RES_MAGIC; h->cap = cap;
+    return (uint8_t *)base + RES_HDR;
+}
+
+void result_free(void *p) {
+    if (!p) return;
+    void *base = (uint8_t *)p - RES_HDR;
+    const ResHdr *h = (const ResHdr *)base;
+    if (h->magic != RES_MAGIC) { fprintf(stderr, "librsn: rsn_free() of a pointer librsn did not return\n"); return; }
+    if (h->cap >= POOL_MIN && pool_enabled()) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < POOL_BLOCKS) { g_pool.emplace_back((size_t)h->cap, base); return; }
+        size_t small = 0;                                              // keep the largest blocks
+        for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].first < g_pool[small].first) small = i;
+        if (g_pool[small].first < h->cap) { void *victim = g_pool[small].second; g_pool[small] = {(size_t)h->cap, base}; base = victim; }
+    }
+    ((ResHdr *)base)->magic = 0;
+    free(base);
+}
+
+// Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a library-owned result.
 template <class Fn>
 int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t bound, Fn fn) {
     Ctx &c = ctx();
@@ -91,8 +147,8 @@ int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t 
         break;
     }
     if (rc) return rc;
-    uint8_t *res = (uint8_t *)malloc(got ? got : 1);
-    if (!res) return c.fail(RSN_ERR_NOMEM, "malloc(%zu) failed", got);
+    uint8_t *res = (uint8_t *)result_alloc(got);
+    if (!res) return c.fail(RSN_ERR_NOMEM, "allocating %zu result bytes failed", got);
     if (got) {
         RSN_HIP(hipMemcpyAsync(res, d_out, got, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -141,7 +197,7 @@ int rsn_device_count(void) {
 
 const char *rsn_last_error(void) { return ctx().err.c_str(); }
 const char *rsn_version(void) { return "librsn 0.1 (gfx950)"; }
-void rsn_free(void *p) { free(p); }
+void rsn_free(void *p) { result_free(p); }
 
 size_t rsn_huffman_compress_bound(size_t n) { return huff_compress_bound(n); }
 size_t rsn_lzss_compress_bound(size_t n) { return lzss_compress_bound(n); }
@@ -210,7 +266,7 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
     for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
     for (size_t i = 0; i < n_chunks; i++) {
         int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
-        if (rc) { for (size_t k = 0; k < i; k++) { free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; } return rc; }
+        if (rc) { for (size_t k = 0; k < i; k++) { rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; } return rc; }
     }
     return RSN_OK;
 }

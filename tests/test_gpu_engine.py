@@ -2,6 +2,7 @@
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -81,3 +82,44 @@ def test_concurrent_callers_are_independent(oracle, samiam):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_result_buffers_are_recycled_safely(oracle):
+    """Results of 1 MiB and more come from a pool refilled by rsn_free(): sizes that grow, shrink
+    and repeat, freed in a different order than they were made, from two threads at once."""
+    import ctypes
+    import threading
+    from raisin_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    datas = [rng.integers(0, 128, size=n, dtype=np.uint8).tobytes() for n in (3 << 20, 1 << 20, 5 << 20, 3 << 20, 700000, 5 << 20)]
+    wants = [oracle.huffman_compress(d) for d in datas]
+    errors = []
+
+    def worker():
+        try:
+            held = []
+            for rnd in range(2):
+                for d, w in zip(datas, wants):
+                    out = ctypes.POINTER(ctypes.c_uint8)()
+                    n = ctypes.c_size_t(0)
+                    _lib.check(L.rsn_huffman_compress(d, len(d), ctypes.byref(out), ctypes.byref(n)))
+                    held.append((out, n.value, w))
+                    if len(held) == 3:                      # free out of order, after checking the bytes are still intact
+                        for o, k, ww in (held[1], held[0], held[2]):
+                            assert ctypes.string_at(o, k) == ww
+                            L.rsn_free(o)
+                        held = []
+            for o, k, ww in held:
+                assert ctypes.string_at(o, k) == ww
+                L.rsn_free(o)
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    L.rsn_free(None)
