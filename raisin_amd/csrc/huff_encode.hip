@@ -680,8 +680,8 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     int rc = dev_buf(c, 1, 256 * 8, &p); if (rc) return rc;
     unsigned long long *d_gh = (unsigned long long *)p;
     RSN_HIP(hipMemsetAsync(d_gh, 0, 256 * 8, s));
-    const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 4096);     // persistent blocks; 8 loads in flight per lane measured best (r01d A/B)
-    RSN_LAUNCH("huff_byte_hist", k_byte_hist<8>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
+    const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 2048);     // persistent blocks (8 loads in flight / other grid sizes: within noise, r01d A/B)
+    RSN_LAUNCH("huff_byte_hist", k_byte_hist<4>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
     void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 8, &hp); if (rc) return rc;
     unsigned long long *h = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h, d_gh, 256 * 8, hipMemcpyDeviceToHost, s));
