@@ -536,12 +536,21 @@ __global__ __launch_bounds__(LB) void k_parse_exit(const uint32_t *__restrict__ 
         nxt[i] = (uint16_t)(i + L);                                   // < PT + MAX_WINDOW <= 65535
     }
     __syncthreads();
-    for (int round = 0; round < 13; round++) {                        // 2^13 = PT: every chain has left the tile
-        for (int i = threadIdx.x; i < PT; i += LB) {
-            const uint32_t j = nxt[i];
-            if (j < PT) nxt[i] = nxt[j];
+    for (int round = 0; round < 13; round++) {                        // 2^13 = PT: every chain has left the tile by then
+        if ((round & 3) == 1) {                                       // every fourth round also asks whether anything is still inside:
+            bool more = false;                                        // long matches leave the tile in a round or two
+            for (int i = threadIdx.x; i < PT; i += LB) {
+                const uint32_t j = nxt[i];
+                if (j < PT) { const uint32_t k = nxt[j]; nxt[i] = (uint16_t)k; more = more || k < PT; }
+            }
+            if (!__syncthreads_or(more)) break;
+        } else {
+            for (int i = threadIdx.x; i < PT; i += LB) {
+                const uint32_t j = nxt[i];
+                if (j < PT) nxt[i] = nxt[j];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     for (int i = threadIdx.x; i < PT; i += LB) if (base + i < E) exit_rel[base + i] = (uint16_t)(nxt[i] - PT);
 }
@@ -665,11 +674,12 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
     for (int i = threadIdx.x; i < PT; i += LB) sx[i] = nxt[i];
     __syncthreads();
     for (int round = 0; round < 7; round++) {                       // 2^7 = SEG hops
+        bool more = false;
         for (int i = threadIdx.x; i < PT; i += LB) {
-            const uint32_t j = sx[i];
-            if (j < (uint32_t)((i / SEG + 1) * SEG)) sx[i] = sx[j];
+            const uint32_t j = sx[i], lim = (uint32_t)((i / SEG + 1) * SEG);
+            if (j < lim) { const uint32_t k = sx[j]; sx[i] = (uint16_t)k; more = more || k < lim; }
         }
-        __syncthreads();
+        if (!__syncthreads_or(more)) break;
     }
     const uint32_t lim = min((uint32_t)PT, E - base);
     if (threadIdx.x == 0) {
@@ -688,12 +698,12 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
         while (i < hi) {                                             // this lane owns the flag words of its segment
             fl[i >> 5] |= 1u << (i & 31);
             const uint32_t j = nxt[i];
-            if (j - i >= 6) need[atomicAdd(&n_need, 1u)] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143)
+            if (j - i >= 6 && (keys[base + i] & 0xFFFFu) == 0) need[atomicAdd(&n_need, 1u)] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143); the bucket search already knows the distance
             i = j;
         }
     }
     __syncthreads();                                                 // sx is dead: the same LDS now receives the byte image
-    {   // full 16-byte units first (loads issued together), then the ragged tail
+    if (n_need) {   // full 16-byte units first (loads issued together), then the ragged tail
         const uint32_t nv = span / 16;
         const uint4 *src = reinterpret_cast<const uint4 *>(fc + org);
         uint4 *dst = reinterpret_cast<uint4 *>(s_bytes);
