@@ -359,7 +359,7 @@ constexpr int HWMAX = 4096;              // largest window this path takes
 constexpr int HLMAX = 256;               // longest common prefix examined before the strip is handed back
 constexpr int HNB = 8192;                // buckets
 constexpr int H_STAGE = HWMAX + HT + HLMAX + 32;
-constexpr uint32_t H_ITER_CAP = (HT / HTH) * 768;   // trips per lane before the strip is handed back (the sweep costs ~W/6 trips per position)
+constexpr uint32_t H_ITER_CAP = (HT / HTH) * 384;   // trips per lane before the strip is handed back (the sweep costs about as much as 250 trips per position)
 static_assert(HWMAX + HT <= 8192, "an entry keeps the staged offset in 13 bits");
 static_assert(MATCH_STRIP % HT == 0, "a strip is a whole number of hash tiles");
 static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH == 0, "round structure");
