@@ -644,6 +644,15 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
     const unsigned long long total_syms = a.n;
     const unsigned long long wbase = (a.base_bits >> 5) + (unsigned long long)chunk * (HB * L);
     const unsigned long long end_word = (a.base_bits + total_syms * L + 31) >> 5;                 // one past the last word holding stream bits
+    if (chunk > 0 && wbase + (unsigned long long)(HB * L) <= end_word) {
+        // interior block: four words per store (the payload is only dword-aligned, which global stores accept)
+        for (int q = tid; q < HB * L / 4; q += HB) {
+            const int i = 4 * q;                                   // 4 | 32: the four words never straddle a swizzle step
+            const uint32_t *sp = s_o + i + (i >> 5);
+            struct __attribute__((packed, aligned(4))) W4 { uint32_t x, y, z, w; };
+            *reinterpret_cast<W4 *>(a.out_words + wbase + i) = W4{sp[0], sp[1], sp[2], sp[3]};
+        }
+    } else
     for (int i = tid; i < HB * L; i += HB) {
         const unsigned long long g = wbase + i;
         if (g >= end_word) break;
