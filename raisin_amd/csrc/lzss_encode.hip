@@ -71,28 +71,51 @@ __global__ __launch_bounds__(LB) void k_esc_count(const uint8_t *__restrict__ in
     if (threadIdx.x == 0) blk_extra[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// A block's output is contiguous: bytes go to an LDS image shifted so that its 16-byte units line
+// up with global memory, then out with 16-byte stores (per-lane byte stores cost 3x the time).
+__device__ __forceinline__ void drain_block(const uint8_t *s_img, uint32_t al, uint32_t total, uint8_t *dst) {
+    // s_img[al .. al+total) is the output, dst - al is 16-byte aligned
+    const uint32_t span = al + total;
+    uint8_t *gbase = dst - al;
+    for (uint32_t u = threadIdx.x; u * 16 < span; u += blockDim.x) {
+        const uint32_t b0 = u * 16;
+        if (b0 >= al && b0 + 16 <= span) *reinterpret_cast<uint4 *>(gbase + b0) = *reinterpret_cast<const uint4 *>(s_img + b0);
+        else for (uint32_t k = max(b0, al); k < min(b0 + 16, span); k++) gbase[k] = s_img[k];
+    }
+}
+
 __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
                                                   uint8_t *__restrict__ fc) {
     __shared__ uint32_t wsum[LB / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[2 * ESC_TILE + 32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t P = (size_t)blockIdx.x * ESC_TILE + tid * 16;
     uint32_t w[4]; int cnt;
     load16(in, n, P, w, &cnt);
     uint32_t c = 0;
-    for (int k = 0; k < cnt; k++) { const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; c += (v == 0x5C || v == 0xFF); }
+    if (cnt == 16) c = count_special16(w);
+    else for (int k = 0; k < cnt; k++) { const uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; c += (v == 0x5C || v == 0xFF); }
     uint32_t incl = c;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    uint32_t pre = 0;
-    for (int k = 0; k < wv; k++) pre += wsum[k];
-    uint8_t *o = fc + P + blk_off[blockIdx.x] + pre + incl - c;
-    for (int k = 0; k < cnt; k++) {
-        uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        if (v == 0x3C) v = 0xFF;                       // '<' -> EncodedOpening (lzss.go:373-377)
-        else if (v == 0xFF || v == 0x5C) *o++ = 0x5C;  // escape byte first (lzss.go:378-379)
-        *o++ = (uint8_t)v;
+    uint32_t pre = 0, extra = 0;
+    for (int k = 0; k < LB / 64; k++) { if (k < wv) pre += wsum[k]; extra += wsum[k]; }
+    uint8_t *dst = fc + (size_t)blockIdx.x * ESC_TILE + blk_off[blockIdx.x];
+    const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
+    const uint32_t total = (uint32_t)min((size_t)ESC_TILE, n - (size_t)blockIdx.x * ESC_TILE) + extra;
+    uint8_t *o = s_img + al + tid * 16 + pre + incl - c;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < cnt) {
+            uint32_t v = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+            if (v == 0x3C) v = 0xFF;                       // '<' -> EncodedOpening (lzss.go:373-377)
+            else if (v == 0xFF || v == 0x5C) *o++ = 0x5C;  // escape byte first (lzss.go:378-379)
+            *o++ = (uint8_t)v;
+        }
     }
+    __syncthreads();
+    drain_block(s_img, al, total, dst);
 }
 
 // ------------------------------------------------------------------ E2: match search
@@ -752,18 +775,64 @@ __device__ __forceinline__ uint8_t *put_dec(uint8_t *o, uint32_t v) {
 __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc, const uint32_t *__restrict__ keys, uint32_t E,
                                                  const uint32_t *__restrict__ flags, const unsigned long long *__restrict__ tile_off,
                                                  uint8_t *__restrict__ out) {
+    constexpr int RP = LB * 16;                                    // positions per round
     __shared__ uint32_t wsum[LB / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[RP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_fc[RP + 16];   // a raw copy of a short match runs at most 10 bytes past the round
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[RP + 64];  // a round emits at most RP + 10 bytes
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t base = blockIdx.x * PT;
     unsigned long long run = tile_off[blockIdx.x];
-    for (int r = 0; r < PT / (LB * 16); r++) {
+    for (int r = 0; r < PT / RP; r++) {
+        const uint32_t rb = base + r * RP;
         // 16 consecutive positions per lane = one half-word of the flag mask
-        const uint32_t i0 = r * (LB * 16) + tid * 16;
-        const uint32_t fw = (flags[(size_t)blockIdx.x * (PT / 32) + (i0 >> 5)] >> (i0 & 31)) & 0xFFFF;
+        const uint32_t i0 = tid * 16;
+        const uint32_t fw = (flags[(size_t)blockIdx.x * (PT / 32) + ((r * RP + i0) >> 5)] >> (i0 & 31)) & 0xFFFF;
+        const int busy = __syncthreads_count(fw != 0);             // lanes with a chain position in their 16
+        if (busy == 0) continue;                                   // inside a long match
+        if (busy < 8) {                                            // a handful of tokens: staging the round would cost more than it saves
+            uint32_t mine = 0;
+            for (uint32_t m = fw; m; m &= m - 1) {
+                const uint32_t k = keys[rb + i0 + __builtin_ctz(m)], L = k >> 16;
+                if (L == 0) mine += 1;
+                else { const uint32_t e = enc_len(k & 0xFFFF, L); mine += e < L ? e : L; }
+            }
+            uint32_t incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for (int k = 0; k < LB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
+            uint8_t *o = out + run + pre + incl - mine;
+            for (uint32_t m = fw; m; m &= m - 1) {
+                const uint32_t p = rb + i0 + __builtin_ctz(m);
+                const uint32_t k = keys[p], L = k >> 16, off = k & 0xFFFF;
+                if (L == 0) { *o++ = fc[p]; continue; }
+                if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
+                else for (uint32_t j = 0; j < L; j++) *o++ = fc[p + j];
+            }
+            run += tot;
+            __syncthreads();
+            continue;
+        }
+        for (int v = tid; v < RP / 4; v += LB) {                   // keys and bytes of the round, 16 bytes per load
+            const uint32_t p = rb + 4 * v;
+            uint4 x = {0, 0, 0, 0};
+            if (p + 4 <= E) x = *reinterpret_cast<const uint4 *>(keys + p);
+            else { if (p < E) x.x = keys[p]; if (p + 1 < E) x.y = keys[p + 1]; if (p + 2 < E) x.z = keys[p + 2]; }
+            reinterpret_cast<uint4 *>(s_keys)[v] = x;
+        }
+        for (int v = tid; v < (RP + 16) / 16; v += LB) {
+            const uint32_t p = rb + 16 * v;
+            uint4 x = {0, 0, 0, 0};
+            if (p + 16 <= E) x = *reinterpret_cast<const uint4 *>(fc + p);
+            else if (p < E) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t k = 0; p + k < E; k++) w[k >> 2] |= (uint32_t)fc[p + k] << (8 * (k & 3)); x = {w[0], w[1], w[2], w[3]}; }
+            reinterpret_cast<uint4 *>(s_fc)[v] = x;
+        }
+        __syncthreads();
         uint32_t mine = 0;
         for (uint32_t m = fw; m; m &= m - 1) {
-            const uint32_t p = base + i0 + __builtin_ctz(m);
-            const uint32_t k = keys[p], L = k >> 16;
+            const uint32_t k = s_keys[i0 + __builtin_ctz(m)], L = k >> 16;
             if (L == 0) mine += 1;
             else { const uint32_t e = enc_len(k & 0xFFFF, L); mine += e < L ? e : L; }
         }
@@ -773,14 +842,18 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
         __syncthreads();
         uint32_t pre = 0, tot = 0;
         for (int k = 0; k < LB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
-        uint8_t *o = out + run + pre + incl - mine;
+        uint8_t *dst = out + run;
+        const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
+        uint8_t *o = s_img + al + pre + incl - mine;
         for (uint32_t m = fw; m; m &= m - 1) {
-            const uint32_t p = base + i0 + __builtin_ctz(m);
-            const uint32_t k = keys[p], L = k >> 16, off = k & 0xFFFF;
-            if (L == 0) { *o++ = fc[p]; continue; }
+            const uint32_t q = i0 + __builtin_ctz(m);
+            const uint32_t k = s_keys[q], L = k >> 16, off = k & 0xFFFF;
+            if (L == 0) { *o++ = s_fc[q]; continue; }
             if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
-            else for (uint32_t j = 0; j < L; j++) *o++ = fc[p + j];
+            else for (uint32_t j = 0; j < L; j++) *o++ = s_fc[q + j];
         }
+        __syncthreads();
+        drain_block(s_img, al, tot, dst);
         run += tot;
         __syncthreads();
     }
