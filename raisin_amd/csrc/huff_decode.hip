@@ -39,6 +39,8 @@ constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int KM = 12;              // index bits of the multi-symbol table (ASCII alphabets with codes <= 11 bits)
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
+constexpr int CHILD_LDS = 1024;     // child[] of a byte alphabet (<= 2 * 255 entries) is staged in LDS: a code longer than K bits
+                                    // costs LDS latency per extra bit instead of a global load (one wavefront in five hits one per step on skewed data)
 constexpr uint32_t BAD_REL = 0xFFFF;
 constexpr uint32_t BAD_POS = 0xFFFFFFFFu;
 
@@ -56,6 +58,7 @@ struct DecArgs {
     unsigned long long *blk_bytes;
     int *changed; int pass;
     const unsigned long long *blk_off; uint8_t *out;   // D3
+    uint32_t child_n;           // entries of child[]
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return j + (j >> 5); }
@@ -176,10 +179,12 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
+    __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     const int tid = threadIdx.x;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);   // once per (persistent) block
+    if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
     if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
@@ -314,10 +319,12 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
+    __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);
+    if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
     if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
@@ -611,7 +618,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
     a.mlut = d_mlut;
-    a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.min_len = codes.min_len;
+    a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.child_n = (uint32_t)child.size(); a.min_len = codes.min_len;
     a.flat_guess = codes.min_len == codes.max_len;
     static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 96; }();
     a.warm = std::min(std::max(warm_env, 0), ORG - 32);
