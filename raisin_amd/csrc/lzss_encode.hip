@@ -5,23 +5,26 @@
 // compaction :134-151.
 //
 //   E1 k_esc_count / k_esc_write   '<'->FF, FF->5C FF, 5C->5C 5C (lzss.go:369-389)
-//   E2 k_match     for EVERY escaped position i: the longest L such that fc[i:i+L]
-//                  occurs entirely inside the window fc[max(0,i-W):i], and the
-//                  distance to its LEFTMOST occurrence (bytes.Index, lzss.go:419).
-//                  key[i] = L<<16 | distance (0 => literal).
-//   E3 k_parse_exit / k_parse_chain / k_parse_mark   the greedy chain of lzss.go:136-151
-//                  (position i is visited iff no earlier visited reference covers it)
+//   E2 match search: for EVERY escaped position i the longest L such that fc[i:i+L] occurs
+//                  entirely inside the window fc[max(0,i-W):i], and the distance to its
+//                  LEFTMOST occurrence (bytes.Index, lzss.go:419).  key[i] = L<<16 | distance
+//                  (0 => literal).
+//        k_match_hash  common case (W <= 4096): bigram buckets in LDS, work proportional to how
+//                      often a bigram recurs in the window; exact, hands pathological strips back
+//        k_match2      general case / hand-backs: diagonal sweep, O(1) per (position, distance)
+//                      pair whatever the data (k_match: the older 32-bit form, A/B only)
+//   E3 k_parse_exit / k_parse_super / k_parse_chain / k_parse_fill / k_parse_mark
+//                  the greedy chain of lzss.go:136-151 (position i is visited iff no earlier
+//                  visited reference covers it), without a serial walk over the stream
 //   E4 k_tok_emit  "<off,len>" if shorter than the match, else the raw bytes (lzss.go:143-149)
 //
-// E2 is the cost: W byte-compares per position is the reference's semantics
-// (leftmost-longest over the whole window), so it is VALU-bound, not HBM-bound.
-// Formulation (DESIGN.md "LZSS match search"): lane = position, step = diagonal.
-// On diagonal d (candidate start i-d) the match length obeys
+// E2 is the cost.  The chain steps over every match, encodable or not, so the exact L is needed
+// wherever the chain can land: no cut-offs.  Diagonal sweep: lane = position,
+// step = diagonal.  On diagonal d (candidate start i-d) the match length obeys
 //     run_d(i) = fc[i]==fc[i-d] ? run_d(i+1)+1 : 0,
-// so a wavefront sweeps 64 consecutive positions against one candidate byte per
-// step (uniform LDS read), the run counters move one lane down per step (DPP
-// wave_shl:1) and every (i,d) pair costs O(1) regardless of the data -- runs of one
-// byte, periodic input and random input all take the same time.
+// so a wavefront sweeps 64 consecutive positions against one candidate byte per step (uniform
+// LDS read), the run counters move one lane down per step (DPP wave_shl:1) and every (i,d)
+// pair costs O(1) regardless of the data.
 #include "codecs.h"
 
 namespace rsn {
