@@ -98,6 +98,37 @@ def test_long_runs(lz, oracle):
         assert lz.Decompress(c) == data
 
 
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 8191, 8192, 8193, 12289, 16383, 16384, 16385, 20481, 32767, 32769, 65537])
+def test_sizes_text_tile_edges(lz, oracle, n):
+    """Text keeps the bucket search on its own path (no hand-back): stream ends at, before and
+    after every tile (4096) and strip (16384) edge; windows that do and do not reach back a tile."""
+    data = text(n, n)
+    for w in (4096, 1000):
+        c = lz.CompressAsync(data, False, w)
+        assert c == oracle.lzss_compress(data, w), (n, w)
+    assert lz.Decompress(c) == data
+
+
+@pytest.mark.parametrize("tiles", [1, 2, 127, 128, 129, 256, 257])
+def test_decode_tile_and_group_edges(lz, oracle, tiles):
+    """Escaped-stream lengths at, before and after the 16 KiB resolve tiles and the 128-tile chain
+    groups, on data whose copies chain across every tile (period) and on text."""
+    rng = np.random.default_rng(tiles)
+    vals = np.array([v for v in range(256) if v not in (0x5C, 0xFF, 0x3C)], dtype=np.uint8)
+    blk = vals[rng.integers(0, len(vals), size=4096)].tobytes()
+    for delta in (-1, 0, 1):
+        n = tiles * 16384 + delta
+        per = (blk * (n // 4096 + 1))[:n]
+        c = lz.CompressAsync(per)
+        assert lz.Decompress(c) == per, (tiles, delta)
+    n = tiles * 16384 + 5
+    t = text(tiles, min(n, 600000))
+    mixed = (t + per)[:n] if len(t) < n else t[:n]
+    c = lz.CompressAsync(mixed)
+    assert c == oracle.lzss_compress(mixed)
+    assert lz.Decompress(c) == oracle.lzss_decompress(c) == mixed
+
+
 def test_bucket_search_hands_strips_back(lz, oracle):
     """The bigram-bucket search gives a strip to the diagonal sweep when a common prefix reaches 256
     bytes or a bucket walk runs too long; both kinds of strip next to ordinary ones must still
