@@ -524,8 +524,9 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
         prel = start ? rel : prel;
         d = start ? dn : d;
         off = start ? 0u : off;
-        // ---- bucket exhausted: L = 0 so far falls back to the first-byte range, anything else is final
-        const bool exh = fetch && !rd;
+        // ---- list exhausted -- noticed in the trip that took the last entry unless that entry starts a
+        //      compare: L = 0 so far falls back to the first-byte range, anything else is final
+        const bool exh = fetch && !start && !search && cur >= end;
         const bool to_byte = exh && !bytemode && best == 0;
         if (exh && !to_byte) { a.keys[ipos] = best; have = false; }
         cur = to_byte ? bcur : cur;
