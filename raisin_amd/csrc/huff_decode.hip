@@ -377,8 +377,8 @@ struct FlatArgs {
     const uint8_t *base; size_t nbytes;
     unsigned long long p0;       // bit position of the first field
     unsigned long long n_sym;
-    const uint8_t *lut;          // 2^L bytes: field value -> symbol
     uint8_t *out;
+    uint8_t lut[128];            // 2^L bytes: field value -> symbol.  In the kernel-argument segment: no upload, no extra stream op
 };
 constexpr int FLAT_LANE_SYMS = 32;
 constexpr int FLAT_SYMS = DB * FLAT_LANE_SYMS;                  // symbols per block
@@ -390,7 +390,10 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     __shared__ uint32_t s_data[WORDS + WORDS / 32 + 2];
     __shared__ uint32_t s_lut[(1 << L) << RL];
     const int tid = threadIdx.x;
-    for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = a.lut[i >> RL];
+    {   // the table is read through the kernel-argument segment pointer: indexing the by-value copy would spill it to scratch
+        const uint8_t *lut = (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FlatArgs, lut);
+        for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = lut[i >> RL];
+    }
     const uint32_t n_chunks = (uint32_t)((a.n_sym + FLAT_SYMS - 1) / FLAT_SYMS);
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // persistent: the table is staged once
     const unsigned long long sym0 = (unsigned long long)chunk * FLAT_SYMS;
@@ -555,14 +558,10 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         const unsigned long long n_sym = max / L;
         *out_n = (size_t)n_sym;
         if (!d_out || n_sym > out_cap) { *out_n = round_up((size_t)n_sym, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %llu bytes, buffer holds %zu", n_sym, out_cap); }
-        void *hl; rc = pinned_buf(c, 256, &hl); if (rc) return rc;
-        uint8_t *lut8 = (uint8_t *)hl;
-        for (uint32_t i = 0; i < tree.n_leaves; i++) lut8[codes.code[i]] = (uint8_t)tree.rune[i];
-        rc = dev_buf(c, 5, 256, &p); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(p, lut8, (size_t)1 << L, hipMemcpyHostToDevice, s));
         FlatArgs fa{};
         fa.base = d_in + A0; fa.nbytes = n - A0; fa.p0 = 8ull * (pay - A0) + diff; fa.n_sym = n_sym;
-        fa.lut = (const uint8_t *)p; fa.out = d_out;
+        fa.out = d_out;
+        for (uint32_t i = 0; i < tree.n_leaves; i++) fa.lut[codes.code[i]] = (uint8_t)tree.rune[i];
         const dim3 grid((uint32_t)std::min<size_t>(ceil_div((size_t)n_sym, FLAT_SYMS), 256 * 8));
         switch (L) {
 #define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(DB), 0, s, fa); break;

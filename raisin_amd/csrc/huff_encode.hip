@@ -18,6 +18,8 @@
 // Bit layout (huffman.go:245-255): out = header || "\\\n" || byte(pad) || bytes(0^pad || S),
 // S MSB-first.  The kernels treat `out` as one big-endian bit string whose first
 // code bit sits at bit 8*(hdr+3)+pad; tile t starts at that plus tile_off[t].
+#include <cstddef>
+
 #include "huff_host.h"
 #include "rsn_common.h"
 
@@ -571,12 +573,14 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
 // stream's start phase (base_bits % 32) is one block-uniform funnel shift against the last
 // word of the lane before.  Every output word has ONE owner (plain stores); only the word
 // that also holds header bytes is merged with atomicOr.
+constexpr int FE_INLINE = 128 + 2304;    // code table + header carried in the kernel-argument segment (no upload, no extra stream op)
 struct FlatEmitArgs {
     const uint8_t *in; size_t n;
-    const uint8_t *codes;                // 128 bytes: symbol -> L-bit code, followed by the header bytes
+    const uint8_t *codes;                // 128 bytes: symbol -> L-bit code, followed by the header bytes; null: they are in `inl`
     unsigned long long base_bits;        // bit position of the first code bit in out
     uint32_t *out_words;
     uint32_t hdr_len;                    // bytes of header || "\\\n" || pad byte, staged behind the code table
+    uint8_t inl[FE_INLINE];
 };
 constexpr int FE_SPL = 32;
 constexpr int FE_SYMS = HB * FE_SPL;     // symbols per block
@@ -587,7 +591,9 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
     __shared__ uint32_t s_o[HB * L + HB * L / 32 + 2];            // block's output words (swizzled), drained coalesced
     __shared__ uint32_t s_last[HB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < 128 * 32; i += HB) s_code[i] = a.codes[i >> 5];
+    // (through the kernel-argument segment pointer: indexing the by-value copy would spill it to scratch)
+    const uint8_t *tab = a.codes ? a.codes : (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FlatEmitArgs, inl);
+    for (int i = tid; i < 128 * 32; i += HB) s_code[i] = tab[i >> 5];
     __syncthreads();
     const uint32_t rep = tid & 31;
     const uint32_t n_chunks = (uint32_t)((a.n + FE_SYMS - 1) / FE_SYMS);
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
         if (g == (a.base_bits >> 5)) {
             // this dword also holds the last header bytes (and the pad bits): merge them in registers
             uint32_t hb = 0;
-            for (uint32_t k = (uint32_t)(g * 4); k < a.hdr_len; k++) hb |= (uint32_t)a.codes[128 + k] << (8 * (k & 3));
+            for (uint32_t k = (uint32_t)(g * 4); k < a.hdr_len; k++) hb |= (uint32_t)tab[128 + k] << (8 * (k & 3));
             a.out_words[g] = val | hb;
         } else a.out_words[g] = val;
     }
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
     if (blockIdx.x == 0) {                                         // header bytes in front of the first payload dword
         const uint32_t whole = (uint32_t)(a.base_bits >> 5) * 4;
         uint8_t *o8 = reinterpret_cast<uint8_t *>(a.out_words);
-        for (uint32_t k = tid; k < whole && k < a.hdr_len; k += HB) o8[k] = a.codes[128 + k];
+        for (uint32_t k = tid; k < whole && k < a.hdr_len; k += HB) o8[k] = tab[128 + k];
     }
 }
 
@@ -760,6 +766,36 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         return RSN_OK;
     }
 
+    // ---- flat code: offsets are arithmetic (decided before any table is uploaded: this path needs none)
+    static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
+    if (ascii && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat_emit) {
+        const unsigned L = codes.max_len;
+        FlatEmitArgs fa{};
+        fa.in = d_in; fa.n = n; fa.base_bits = base_bits; fa.out_words = (uint32_t *)d_out; fa.hdr_len = (uint32_t)H;
+        uint8_t *hcodes = fa.inl;
+        if (128 + H > (size_t)FE_INLINE) {                         // a header too long for the argument segment (10-digit counts): upload
+            void *hp2; rc = pinned_buf(c, 128 + H + 16, &hp2); if (rc) return rc;
+            hcodes = (uint8_t *)hp2;
+            memset(hcodes, 0, 128);
+        }
+        for (uint32_t i = 0; i < tree.n_leaves; i++) hcodes[tree.rune[i]] = (uint8_t)codes.code[i];
+        memcpy(hcodes + 128, hdr.data(), H);
+        if (hcodes != fa.inl) {
+            rc = dev_buf(c, 3, 128 + H + 16, &p); if (rc) return rc;
+            RSN_HIP(hipMemcpyAsync(p, hcodes, 128 + H, hipMemcpyHostToDevice, s));
+            fa.codes = (const uint8_t *)p;
+        }
+        const dim3 grid((uint32_t)std::min<size_t>(ceil_div(n, FE_SYMS), 256 * 8));
+        switch (L) {
+#define RSN_FE(LL) case LL: RSN_LAUNCH("huff_emit", k_emit_flat<LL>, grid, dim3(HB), 0, s, fa); break;
+            RSN_FE(1) RSN_FE(2) RSN_FE(3) RSN_FE(4) RSN_FE(5) RSN_FE(6) RSN_FE(7)
+#undef RSN_FE
+            default: break;
+        }
+        RSN_HIP(hipStreamSynchronize(s));
+        return RSN_OK;
+    }
+
     // ---- code tables
     const int mode = !ascii ? MODE_RUNE : (codes.max_len <= (unsigned)TAB_LEN_SHIFT ? MODE_ASCII : MODE_ASCII_WIDE);
     EmitArgs a{};
@@ -792,28 +828,6 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
     a.len8 = d_len8;
 
-    // ---- flat code: offsets are arithmetic
-    static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
-    if (mode == MODE_ASCII && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat_emit) {
-        const unsigned L = codes.max_len;
-        void *hp2; rc = pinned_buf(c, 128 + H + 16, &hp2); if (rc) return rc;
-        uint8_t *hcodes = (uint8_t *)hp2;
-        memset(hcodes, 0, 128);
-        for (uint32_t i = 0; i < tree.n_leaves; i++) hcodes[tree.rune[i]] = (uint8_t)codes.code[i];
-        memcpy(hcodes + 128, hdr.data(), H);                      // one upload: code table + header
-        rc = dev_buf(c, 3, 128 + H + 16, &p); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(p, hcodes, 128 + H, hipMemcpyHostToDevice, s));
-        FlatEmitArgs fa{d_in, n, (const uint8_t *)p, base_bits, (uint32_t *)d_out, (uint32_t)H};
-        const dim3 grid((uint32_t)std::min<size_t>(ceil_div(n, FE_SYMS), 256 * 8));
-        switch (L) {
-#define RSN_FE(LL) case LL: RSN_LAUNCH("huff_emit", k_emit_flat<LL>, grid, dim3(HB), 0, s, fa); break;
-            RSN_FE(1) RSN_FE(2) RSN_FE(3) RSN_FE(4) RSN_FE(5) RSN_FE(6) RSN_FE(7)
-#undef RSN_FE
-            default: break;
-        }
-        RSN_HIP(hipStreamSynchronize(s));
-        return RSN_OK;
-    }
 
     // ---- tile bit offsets
     rc = dev_buf(c, 4, ((size_t)n_tiles * 2 + 2) * 8, &p); if (rc) return rc;
