@@ -16,6 +16,29 @@ Ctx &ctx() {
     return c;
 }
 
+// A thread that exits leaves its stream, scratch buffers and pinned staging behind for the next
+// thread that needs a context on the same device: nothing leaks when callers come and go (a Go
+// runtime retires OS threads), and no HIP call runs inside a thread-exit or process-exit destructor.
+namespace {
+struct Parked {
+    int device; hipStream_t stream; Ctx::Buf bufs[Ctx::N_BUFS]; void *pinned; size_t pinned_cap; std::vector<hipEvent_t> events;
+};
+std::mutex g_park_mu;
+std::vector<Parked> *g_parked = nullptr;      // heap-allocated and never destroyed: still valid while other threads unwind at exit
+}  // namespace
+
+Ctx::~Ctx() {
+    if (!inited) return;
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    if (!g_parked) g_parked = new std::vector<Parked>();
+    Parked pk;
+    pk.device = device; pk.stream = own_stream; pk.pinned = pinned; pk.pinned_cap = pinned_cap;
+    for (int i = 0; i < N_BUFS; i++) pk.bufs[i] = bufs[i];
+    pk.events = free_events;
+    for (auto &sl : slots) for (auto &pr : sl.pending) { pk.events.push_back(pr.first); pk.events.push_back(pr.second); }
+    g_parked->push_back(std::move(pk));
+}
+
 int ctx_init(Ctx &c) {
     if (c.inited) {
         hipError_t e = hipSetDevice(c.device);
@@ -28,6 +51,20 @@ int ctx_init(Ctx &c) {
         return c.fail(RSN_ERR_DEVICE, "no HIP device available (%s); librsn has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (c.device >= cnt) return c.fail(RSN_ERR_DEVICE, "device %d out of range (%d visible)", c.device, cnt);
     RSN_HIP(hipSetDevice(c.device));
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        if (g_parked)
+            for (size_t i = g_parked->size(); i-- > 0;)
+                if ((*g_parked)[i].device == c.device) {                  // adopt what an earlier thread left behind (most recent first: its buffers are the warm ones)
+                    Parked &pk = (*g_parked)[i];
+                    c.own_stream = pk.stream; c.pinned = pk.pinned; c.pinned_cap = pk.pinned_cap;
+                    for (int k = 0; k < Ctx::N_BUFS; k++) c.bufs[k] = pk.bufs[k];
+                    c.free_events = std::move(pk.events);
+                    g_parked->erase(g_parked->begin() + (long)i);
+                    c.inited = true;
+                    return RSN_OK;
+                }
+    }
     RSN_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.inited = true;
     return RSN_OK;

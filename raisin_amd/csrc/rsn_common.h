@@ -39,6 +39,8 @@ struct Ctx {
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
 
+    ~Ctx();     // parks the device resources for the next thread (rsn_api.hip); makes no HIP call
+
     int fail(int code, const char *fmt, ...) {
         char tmp[512];
         va_list ap; va_start(ap, fmt); vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);

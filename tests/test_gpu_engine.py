@@ -123,3 +123,32 @@ def test_result_buffers_are_recycled_safely(oracle):
         t.join()
     assert not errors, errors
     L.rsn_free(None)
+
+
+def test_short_lived_threads_do_not_leak_device_memory(oracle):
+    """A thread's stream and scratch buffers are parked when it exits and adopted by the next new
+    thread: twenty threads in a row must not cost twenty sets of buffers."""
+    import threading
+    import torch
+    from raisin_amd import huffman
+    data = np.random.default_rng(9).integers(0, 128, size=32 << 20, dtype=np.uint8).tobytes()
+    want_len = []
+
+    def work():
+        want_len.append(len(huffman.Compress(data)))
+
+    def run_one():
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+
+    for _ in range(3):
+        run_one()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        run_one()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert len(set(want_len)) == 1
+    assert free0 - free1 < (64 << 20), (free0, free1)      # one context is ~100 MiB here; a leak would be ~2 GiB
