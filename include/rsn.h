@@ -46,6 +46,10 @@ int rsn_device_set(int device);
 int rsn_device_count(void);
 const char *rsn_last_error(void); /* thread-local, valid until the next call on this thread */
 const char *rsn_version(void);
+/* Releases what the library keeps between calls: the calling thread's device scratch and pinned
+ * staging, the contexts parked by threads that have exited, and the recycled result buffers.
+ * Safe at any time between calls; the next call re-allocates what it needs. */
+void rsn_trim(void);
 void rsn_free(void *p);           /* releases buffers returned through `out` below (only rsn_free may: they carry a
                                      library header; large ones are recycled, RSN_HOST_POOL=0 disables that) */
 

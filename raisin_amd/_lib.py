@@ -26,7 +26,7 @@ class ProfEntry(ctypes.Structure):
 _lib = None
 
 SYMBOLS = [
-    "rsn_device_set", "rsn_device_count", "rsn_last_error", "rsn_version", "rsn_free",
+    "rsn_device_set", "rsn_device_count", "rsn_last_error", "rsn_version", "rsn_free", "rsn_trim",
     "rsn_huffman_compress", "rsn_huffman_decompress", "rsn_lzss_compress", "rsn_lzss_decompress",
     "rsn_huffman_compress_batch",
     "rsn_huffman_compress_bound", "rsn_lzss_compress_bound",
@@ -59,6 +59,8 @@ def lib():
     vp, sz, szp = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)
     L.rsn_last_error.restype = ctypes.c_char_p
     L.rsn_version.restype = ctypes.c_char_p
+    L.rsn_trim.argtypes = []
+    L.rsn_trim.restype = None
     L.rsn_free.argtypes = [vp]
     L.rsn_free.restype = None
     L.rsn_device_set.argtypes = [ctypes.c_int]

@@ -234,6 +234,35 @@ int rsn_device_count(void) {
 
 const char *rsn_last_error(void) { return ctx().err.c_str(); }
 const char *rsn_version(void) { return "librsn 0.1 (gfx950)"; }
+
+void rsn_trim(void) {
+    Ctx &c = ctx();
+    if (c.inited && hipSetDevice(c.device) == hipSuccess) {
+        (void)hipStreamSynchronize(c.own_stream);
+        for (auto &b : c.bufs) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        if (c.pinned) (void)hipHostFree(c.pinned);
+        c.pinned = nullptr; c.pinned_cap = 0;
+    }
+    std::vector<Parked> parked;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        if (g_parked) parked.swap(*g_parked);
+    }
+    for (auto &pk : parked) {
+        if (hipSetDevice(pk.device) != hipSuccess) continue;
+        for (auto &b : pk.bufs) if (b.p) (void)hipFree(b.p);
+        if (pk.pinned) (void)hipHostFree(pk.pinned);
+        for (auto e : pk.events) (void)hipEventDestroy(e);
+        if (pk.stream) (void)hipStreamDestroy(pk.stream);
+    }
+    if (c.inited) (void)hipSetDevice(c.device);
+    std::vector<std::pair<size_t, void *>> pool;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool.swap(g_pool);
+    }
+    for (auto &pr : pool) { ((ResHdr *)pr.second)->magic = 0; free(pr.second); }
+}
 void rsn_free(void *p) { result_free(p); }
 
 size_t rsn_huffman_compress_bound(size_t n) { return huff_compress_bound(n); }

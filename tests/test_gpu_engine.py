@@ -152,3 +152,20 @@ def test_short_lived_threads_do_not_leak_device_memory(oracle):
     free1, _ = torch.cuda.mem_get_info()
     assert len(set(want_len)) == 1
     assert free0 - free1 < (64 << 20), (free0, free1)      # one context is ~100 MiB here; a leak would be ~2 GiB
+
+
+def test_trim_releases_and_the_next_call_recovers(oracle, samiam):
+    import torch
+    from raisin_amd import _lib, huffman, lz
+    data = np.random.default_rng(10).integers(0, 128, size=64 << 20, dtype=np.uint8).tobytes()
+    c = huffman.Compress(data)
+    assert huffman.Decompress(c) == data
+    torch.cuda.synchronize()
+    before, _ = torch.cuda.mem_get_info()
+    _lib.lib().rsn_trim()
+    after, _ = torch.cuda.mem_get_info()
+    assert after - before > (100 << 20), (before, after)          # input + output staging of a 64 MiB call alone is 130 MiB
+    assert huffman.Compress(samiam) == oracle.huffman_compress(samiam)
+    assert lz.Decompress(lz.CompressAsync(samiam)) == samiam
+    _lib.lib().rsn_trim()
+    _lib.lib().rsn_trim()
