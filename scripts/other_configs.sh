@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out
 {
   timeout 300 python3 $R/scripts/quick_bench2.py 1024
   timeout 300 python3 $R/scripts/quick_2b.py 1024
-  for k in text period random; do timeout 300 python3 $R/scripts/quick_lzss.py $k 1024; done
+  for k in text text1 period random; do timeout 300 python3 $R/scripts/quick_lzss.py $k 1024; done
   timeout 300 python3 $R/scripts/quick_layered.py 1024
 } 2>&1 | grep -v amdgpu.ids > $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -22,6 +22,13 @@ def gen(kind, n):
         ranks = rng.zipf(1.3, size=n // 4) % 4096
         buf = b" ".join(vocab[r] for r in ranks)[:n]
         return torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    if kind == "text1":       # the same vocabulary with the classic exponent 1 (p ~ 1/rank): a flatter word distribution
+        rng = np.random.default_rng(0x5EED0004)
+        vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(4096)]
+        p = 1.0 / np.arange(1, 4097)
+        ranks = rng.choice(4096, size=n // 4, p=p / p.sum())
+        buf = b" ".join(vocab[r] for r in ranks)[:n]
+        return torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
     g = torch.Generator(device="cuda").manual_seed(1)
     return torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
 
