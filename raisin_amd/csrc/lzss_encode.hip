@@ -403,6 +403,8 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     __shared__ uint32_t s_cur[HNB / 2];                                  // two 16-bit counters per word: counts, then starts, then ends
     __shared__ uint16_t s_list[HWMAX + HT];                              // staged offset | tag << 13, grouped by bucket
     __shared__ uint32_t s_part[HTH / 64];
+    __shared__ uint16_t s_order[HT];                                     // the tile's positions, longest buckets first
+    __shared__ uint32_t s_cls[4];
     __shared__ uint32_t s_heavy, s_next;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     }
     for (int i = tid; i < HNB / 2; i += HTH) s_cur[i] = 0;
     if (tid == 0) { s_heavy = 0; s_next = 0; }
+    if (tid < 4) s_cls[tid] = 0;
     __syncthreads();
 
     if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match)
@@ -481,13 +484,53 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     //      body (no continue): each lane reads at most one entry and makes at most one 8-byte
     //      compare per trip, so lanes in different states share every trip.
     const uint32_t npos = (uint32_t)min((long long)HT, (long long)E - t0);
+    // Longest buckets first: a position whose bigram fills a bucket walks hundreds of trips, and
+    // handed out last it would leave most of the block's lanes idle behind it.  Four size classes,
+    // counted and scattered with one LDS atomic per wavefront and class.
+    {
+        constexpr int PP = HT / HTH;                                      // positions per lane
+        uint32_t cls[PP];
+#pragma unroll
+        for (int k = 0; k < PP; k++) {
+            const uint32_t kp = tid + k * HTH;
+            uint32_t size = 0;
+            if (kp < npos && kp + 1 < E - (uint32_t)t0) {
+                const uint32_t b0 = sb[HWMAX + kp], b1 = sb[HWMAX + kp + 1], h = (b0 << 5) | (b1 & 31u);
+                size = ends[h] - (h ? ends[h - 1] : 0);
+            }
+            cls[k] = kp >= npos ? 4u : size > 192 ? 0u : size > 64 ? 1u : size > 16 ? 2u : 3u;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const unsigned long long m = __ballot(cls[k] == c);
+                if (lane == 0 && m) atomicAdd(&s_cls[c], (uint32_t)__builtin_popcountll(m));
+            }
+        }
+        __syncthreads();
+        const uint32_t c0 = s_cls[0], c1 = s_cls[1], c2 = s_cls[2];
+        __syncthreads();
+        if (tid == 0) { s_cls[0] = 0; s_cls[1] = c0; s_cls[2] = c0 + c1; s_cls[3] = c0 + c1 + c2; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PP; k++) {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const unsigned long long m = __ballot(cls[k] == c);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_cls[c], (uint32_t)__builtin_popcountll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (cls[k] == c) s_order[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(tid + k * HTH);
+            }
+        }
+        __syncthreads();
+    }
     bool have = false, ext = false, bytemode = false, search = false;
     uint32_t ipos = 0, irel = 0, cur = 0, end = 0, bcur = 0, bend = 0, tag = 0, best = 0, prel = 0, off = 0, capE = 0, d = 0, iters = 0, slo = 0, shi = 0;
     for (;;) {
         if (!have) {                                                      // the only divergent region of a trip
             if (s_heavy) break;
-            const uint32_t kp = atomicAdd(&s_next, 1u);
-            if (kp >= npos) break;
+            const uint32_t kq = atomicAdd(&s_next, 1u);
+            if (kq >= npos) break;
+            const uint32_t kp = s_order[kq];
             ipos = (uint32_t)t0 + kp;
             irel = HWMAX + kp;
             const uint32_t b0 = sb[irel], b1 = sb[irel + 1];
