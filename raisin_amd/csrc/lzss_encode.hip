@@ -525,6 +525,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     }
     bool have = false, ext = false, bytemode = false, search = false;
     uint32_t ipos = 0, irel = 0, cur = 0, end = 0, bcur = 0, bend = 0, tag = 0, best = 0, prel = 0, off = 0, capE = 0, d = 0, iters = 0, slo = 0, shi = 0;
+    uint32_t blk_lo = 0, blk_i = 0;                                      // offset >> HSH of the window start and of the position
     for (;;) {
         if (!have) {                                                      // the only divergent region of a trip
             if (s_heavy) break;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
             cur = bytemode ? bcur : (h ? ends[h - 1] : 0); end = bytemode ? bend : ends[h]; tag = b1 >> 5;
             search = !bytemode && end - cur > 8;                          // long bucket: skip the entries before the window
             slo = cur; shi = end;
+            blk_lo = (irel - W) >> HSH; blk_i = irel >> HSH;
         }
         if (++iters > H_ITER_CAP) { s_heavy = 1; break; }
         // ---- entry step (skipped while a compare is being extended): one entry of the bucket, or one bisection step
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
         const uint32_t e = s_list[rd ? idx : 0];
         const uint32_t rel = e & 8191u;
         const bool s_step = rd && search, w_step = rd && !search;
-        const bool below = (rel >> HSH) < ((irel - W) >> HSH);
+        const uint32_t blk = rel >> HSH;
+        const bool below = blk < blk_lo;
         slo = (s_step && below) ? idx + 1 : slo;
         shi = (s_step && !below) ? idx : shi;
         const bool s_done = s_step && slo >= shi;
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
         const uint32_t dn = irel - rel;
         const bool inwin = dn - 1u < W;                                   // candidate start in [i-W, i)
         const bool byte_hit = w_step && bytemode && inwin;                // the byte occurs in the window: L = 1
-        const bool past = w_step && !bytemode && (rel >> HSH) > (irel >> HSH);      // the rest of the bucket starts after i
+        const bool past = w_step && !bytemode && blk > blk_i;             // the rest of the bucket starts after i
         const bool start = w_step && !bytemode && inwin && (e >> 13) == tag && dn > (best >> 16);   // same bigram, far enough back to beat the best
         best = byte_hit ? (1u << 16) : best;
         cur = (byte_hit || past) ? end : cur;
