@@ -103,21 +103,26 @@ __device__ __forceinline__ uint32_t ltgt_masks(const uint32_t w[4]) {
 // the token whose '<' is staged byte j; sw = dword view, zero past the data, readable 28 bytes past j
 __device__ __forceinline__ Tok parse_tok_w(const uint32_t *sw, int j) {
     const int q = (j + 1) >> 2; const uint32_t sh = (uint32_t)((j + 1) & 3) * 8;
-    uint32_t d[7], a[6];
+    uint32_t a[6];
+    uint32_t cm = 0, gm = 0, dm = 0;                                      // ',' / '>' / digit masks over the bytes after '<'
+    auto classify = [&](int k0, int k1) {                                 // bytes 4*k0 .. 4*k1-1
+        uint32_t d[4];
+        for (int k = k0; k <= k1; k++) d[k - k0] = sw[q + k];
+        for (int k = k0; k < k1; k++) {
+            a[k] = __builtin_amdgcn_alignbit(d[k + 1 - k0], d[k - k0], sh);
+            const uint32_t y = a[k] ^ 0x30303030u;                        // digits -> 00..09, ',' -> 1C, '>' -> 0E
+            const uint32_t td = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;    // bit 7 clear iff 00..09
+            const uint32_t yc = y ^ 0x1C1C1C1Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
+            const uint32_t yg = y ^ 0x0E0E0E0Eu, tg = ((yg & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yg;
+            dm |= pack_bit7(~td & 0x80808080u) << (4 * k);
+            cm |= pack_bit7(~tc & 0x80808080u) << (4 * k);
+            gm |= pack_bit7(~tg & 0x80808080u) << (4 * k);
+        }
+    };
 #pragma unroll
-    for (int k = 0; k < 7; k++) d[k] = sw[q + k];
-    uint32_t cm = 0, gm = 0, dm = 0;                                      // ',' / '>' / digit masks over the 24 bytes after '<'
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        a[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
-        const uint32_t y = a[k] ^ 0x30303030u;                            // digits -> 00..09, ',' -> 1C, '>' -> 0E
-        const uint32_t td = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;        // bit 7 clear iff 00..09
-        const uint32_t yc = y ^ 0x1C1C1C1Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
-        const uint32_t yg = y ^ 0x0E0E0E0Eu, tg = ((yg & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yg;
-        dm |= pack_bit7(~td & 0x80808080u) << (4 * k);
-        cm |= pack_bit7(~tc & 0x80808080u) << (4 * k);
-        gm |= pack_bit7(~tg & 0x80808080u) << (4 * k);
-    }
+    for (int k = 0; k < 6; k++) a[k] = 0;
+    classify(0, 3);                                                       // 12 bytes: every token with numbers up to 9999 ends here
+    if (gm == 0) classify(3, 6);                                          // the rare long spelling: 12 more
     Tok t{0, 0, 0, false};
     const uint32_t pc = (uint32_t)__builtin_ctz(cm | (1u << 24)), pg = (uint32_t)__builtin_ctz(gm | (1u << 24));
     if (pc < 1 || pc > 10 || pg < pc + 2 || pg > pc + 11) return t;     // 1..10 digits, ',', 1..10 digits, '>' (the first one)
