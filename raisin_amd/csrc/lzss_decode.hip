@@ -286,7 +286,7 @@ constexpr int DGRP = 128;               // tiles per chain group (the serial cha
 constexpr uint32_t D_LOC = 0x4000u;     // descriptor: position inside the tile
 constexpr uint32_t D_EXT = 0x8000u;     // descriptor: position inside the previous tile's tail; otherwise the literal byte
 constexpr uint32_t D_PAY = 0x3FFFu;
-constexpr int D_BIG = 32;               // longer tokens are expanded by the whole block
+constexpr int D_BIG = 12;               // longer tokens are expanded by the whole block
 constexpr int D_NBIG = DT / D_BIG + 2;
 static_assert(DT / 16 == DTH && DT <= 16384, "one 16-byte span per lane; 14-bit payload");
 
@@ -427,10 +427,10 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         run += (int)tot;
     }
     __syncthreads();
-    for (uint32_t b = 0; b < s_nbig; b++) {
+    for (uint32_t b = wv; b < s_nbig; b += DTH / 64) {                    // one wavefront per long token
         const int o = (int)s_big[3 * b]; const uint32_t ptr = s_big[3 * b + 1], len = s_big[3 * b + 2];
         const int x0 = max(o, 0), x1 = min(o + (int)len, tlen);
-        for (int x = x0 + tid; x < x1; x += DTH) sd[x] = token_desc(x, ptr);
+        for (int x = x0 + lane; x < x1; x += 64) sd[x] = token_desc(x, ptr);
     }
     __syncthreads();
     for (;;) {                                                            // in-tile pointer jumping, all in LDS
