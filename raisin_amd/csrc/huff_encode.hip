@@ -159,9 +159,18 @@ __device__ __forceinline__ uint32_t classify16(const uint8_t *__restrict__ in, s
 // ---------------------------------------------------------------- K1r: rune histogram
 __global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in, size_t n,
                                                   unsigned long long *__restrict__ ghist) {
-    __shared__ uint32_t h[2048];   // runes < 0x800; the rest go straight to global atomics
+    // runes < 0x800 (ASCII, Latin, Greek, Cyrillic, Hebrew, Arabic ...): dense LDS bins.  The rest: a small
+    // open-addressing table per block -- real text has a handful of them (quotes, dashes, currency signs),
+    // each hot, and a global atomic per occurrence would serialise on a few L2 lines.  A full table (CJK
+    // text: thousands of distinct runes, none of them hot) falls through to global atomics.
+    constexpr uint32_t NS = 512, EMPTY = 0xFFFFFFFFu;
+    __shared__ uint32_t h[2048];
+    __shared__ uint32_t s_key[NS], s_cnt[NS];
+    __shared__ uint32_t s_full;                                        // a probe sequence has failed: stop searching long for newcomers
     const int tid = threadIdx.x;
+    if (tid == 0) s_full = 0;
     for (int i = tid; i < 2048; i += HB) h[i] = 0;
+    for (int i = tid; i < (int)NS; i += HB) { s_key[i] = EMPTY; s_cnt[i] = 0; }
     __syncthreads();
     uint32_t n_err = 0;            // U+FFFD is the hot bin on binary data: count it in a register
     const size_t rounds = (n + ROUND - 1) / ROUND;
@@ -176,11 +185,22 @@ __global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in
             const uint32_t r = rune[k];
             if (r < 0x800) atomicAdd(&h[r], 1u);
             else if (r == kRuneError) n_err++;
-            else atomicAdd(&ghist[r], 1ull);
+            else {
+                uint32_t slot = (r * 0x9E3779B1u) >> 23;                  // 9 bits
+                bool done = false;
+                const int max_probe = s_full ? 2 : 8;
+                for (int probe = 0; probe < max_probe && !done; probe++, slot = (slot + 1) & (NS - 1)) {
+                    uint32_t key = s_key[slot];
+                    if (key == EMPTY) key = atomicCAS(&s_key[slot], EMPTY, r);
+                    if (key == EMPTY || key == r) { atomicAdd(&s_cnt[slot], 1u); done = true; }
+                }
+                if (!done) { s_full = 1; atomicAdd(&ghist[r], 1ull); }
+            }
         }
     }
     __syncthreads();
     for (int i = tid; i < 2048; i += HB) if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+    for (int i = tid; i < (int)NS; i += HB) if (s_cnt[i]) atomicAdd(&ghist[s_key[i]], (unsigned long long)s_cnt[i]);
     for (int d = 32; d; d >>= 1) n_err += __shfl_down(n_err, d);
     if ((tid & 63) == 0 && n_err) atomicAdd(&ghist[kRuneError], (unsigned long long)n_err);
 }
