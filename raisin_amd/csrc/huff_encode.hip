@@ -222,7 +222,10 @@ __global__ __launch_bounds__(HB) void k_tile_bits(const uint32_t *__restrict__ t
 __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict__ in, size_t n, const uint8_t *__restrict__ rlen,
                                                        uint32_t n_tiles, unsigned long long *__restrict__ tile_bits) {
     __shared__ unsigned long long part[HB / 64];
+    __shared__ uint8_t s_len[2048];                                // code lengths of the dense runes: an LDS read instead of a global gather
     const int tid = threadIdx.x;
+    for (int i = tid; i < 2048 / 4; i += HB) reinterpret_cast<uint32_t *>(s_len)[i] = reinterpret_cast<const uint32_t *>(rlen)[i];
+    __syncthreads();
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         unsigned long long s = 0;
         for (int k = 0; k < TILE / ROUND; k++) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict
             uint32_t rune[16];
             const uint32_t m = classify16(in, n, P, rune);
 #pragma unroll
-            for (int j = 0; j < 16; j++) if ((m >> j) & 1) s += rlen[rune[j]];
+            for (int j = 0; j < 16; j++) if ((m >> j) & 1) s += rune[j] < 0x800 ? s_len[rune[j]] : rlen[rune[j]];
         }
         for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
         if ((tid & 63) == 0) part[tid >> 6] = s;
