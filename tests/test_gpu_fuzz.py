@@ -132,3 +132,38 @@ def test_huffman_fuzz(mods, oracle, seed):
             want = None
         if want is not None:
             assert huffman.Decompress(c) == want
+
+
+@pytest.mark.parametrize("seed", range(6 * MORE))
+def test_huffman_rune_fuzz(mods, oracle, seed):
+    """Rune path (huffman.go:309): valid 2/3/4-byte sequences, thousands of distinct sparse runes,
+    invalid and truncated sequences (each U+FFFD for ONE byte), all mixed."""
+    _, huffman, _ = mods
+    rng = random.Random(4000 + seed)
+    pools = {
+        "ascii": [chr(c) for c in range(32, 127)] + ["\n"],
+        "two": [chr(c) for c in range(0x80, 0x800, rng.choice((1, 7)))],
+        "cjk": [chr(rng.randrange(0x4E00, 0xA000)) for _ in range(rng.choice((20, 3000)))],
+        "four": [chr(rng.randrange(0x10000, 0x110000)) for _ in range(rng.choice((3, 400)))],
+        "hot": ["\u201c", "\u201d", "\u2014", "\u20ac"],
+    }
+    bad = [b"\x80", b"\xbf", b"\xc0\x80", b"\xc1", b"\xf5", b"\xff", b"\xe0\x80\x80", b"\xed\xa0\x80", b"\xf0\x80\x80\x80",
+           b"\xf4\x90\x80\x80", b"\xe1\x80", b"\xf1\x80\x80", b"\xc2"]
+    weights = {"ascii": rng.choice((0, 5)), "two": 4, "cjk": rng.choice((0, 3)), "four": 1, "hot": 2}
+    names = [k for k, w in weights.items() for _ in range(w)]
+    out = bytearray()
+    n = rng.choice((50, 3000, 120000, 400000))
+    while len(out) < n:
+        if rng.random() < 0.02:
+            out += rng.choice(bad)
+        else:
+            out += rng.choice(pools[rng.choice(names)]).encode("utf-8")
+    data = bytes(out)
+    c = huffman.Compress(data)
+    assert c == oracle.huffman_compress(data), (seed, n)
+    try:
+        want = oracle.huffman_decompress(c)
+    except oracle.OracleError:
+        want = None
+    if want is not None:
+        assert huffman.Decompress(c) == want
