@@ -170,6 +170,38 @@ def AsyncBenchmarkFile(algorithms, fileString):
         return Result(",".join(algorithms), "failed", 0.0, 0.0, 0.0, False, True)
 
 
+def _suite_order(results):
+    """engine.go:266-276: lossless rows before lossy ones, each group by ascending ratio."""
+    return sorted(results, key=lambda r: (not r.Lossless, r.Ratio))
+
+
+def BenchmarkSuite(files, algorithms, out=None):
+    """engine.go:213-309 without the HTML report: per file one table -- header, finished rows in the
+    reference's order, failed rows as DNF, the File/Size footer -- and the flat list of results."""
+    import sys
+    out = out or sys.stdout
+    all_results = []
+    for i, f in enumerate(files):
+        print("Compressing file %d/%d - %s" % (i + 1, len(files), f), file=out)
+        done, failed = [], []
+        for layer in algorithms:
+            print("Benchmarking", ",".join(layer), file=out)
+            r = AsyncBenchmarkFile(layer, f)
+            (failed if r.Failed else done).append(r)
+        rows = [("engine", "time taken", "compression ratio", "actual entropy", "theoretical entropy", "lossless")]
+        for r in _suite_order(done):
+            rows.append((r.CompressionEngine, r.TimeTaken, "%.2f%%" % r.Ratio, "%.2f" % r.ActualEntropy, "%.2f" % r.Entropy, str(r.Lossless).lower()))
+            all_results.append(r)
+        for r in failed:
+            rows.append((r.CompressionEngine, r.TimeTaken, "DNF", "DNF", "DNF", str(r.Lossless).lower()))
+            all_results.append(r)
+        rows.append(("File", f, "Size", ByteCountSI(os.path.getsize(f)), "", ""))
+        width = [max(len(row[c]) for row in rows) for c in range(6)]
+        for row in rows:
+            print(" | ".join(cell.ljust(w) for cell, w in zip(row, width)).rstrip(), file=out)
+    return all_results
+
+
 def parseAlgorithms(s):
     """cmd/cli.go:203-231: "a,[b,c]" -> [[a],[b,c]]"""
     algorithms, buf, layer, in_layer = [], "", [], False

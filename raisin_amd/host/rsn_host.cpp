@@ -91,6 +91,16 @@ static Result BenchmarkFile(const std::vector<std::string> &algorithms, const st
 }
 }  // namespace engine
 
+// engine/util.go: ByteCountSI (decimal units, one fractional digit)
+static std::string ByteCountSI(long long b) {
+    const long long unit = 1000;
+    if (b < unit) return std::to_string(b) + " B";
+    long long div = unit; int exp = 0;
+    for (long long n = b / unit; n >= unit; n /= unit) { div *= unit; exp++; }
+    char buf[32]; snprintf(buf, sizeof buf, "%.1f %cB", (double)b / (double)div, "kMGTPE"[exp]);
+    return buf;
+}
+
 static std::vector<std::string> split(const std::string &s, char sep) {
     std::vector<std::string> out; std::string cur;
     for (char ch : s) { if (ch == sep) { out.push_back(cur); cur.clear(); } else if (ch != ' ') cur += ch; }
@@ -155,14 +165,30 @@ int main(int argc, char **argv) {
             if (!has_delete || del) for (auto &f : files) remove(f.c_str());                       // -delete defaults to true (cli.go:150)
         } else {
             if (algorithm.empty()) algorithm = "lzss,huffman,[lzss,huffman]";
-            for (auto &f : files) {
-                printf("%-24s %-12s %10s %9s %9s %s\n", "engine", "time", "ratio", "entropy", "actual", "lossless");
+            // engine.go:213-309 (BenchmarkSuite) without the HTML report
+            for (size_t fi = 0; fi < files.size(); fi++) {
+                const std::string &f = files[fi];
+                printf("Compressing file %zu/%zu - %s\n", fi + 1, files.size(), f.c_str());
+                std::vector<engine::Result> done, failed;
                 for (auto &algs : parseAlgorithms(algorithm)) {
+                    std::string n; for (auto &a : algs) n += (n.empty() ? "" : ",") + a;
+                    printf("Benchmarking %s\n", n.c_str());
                     engine::Result r;
                     try { r = engine::BenchmarkFile(algs, f); }
-                    catch (const std::exception &e) { std::string n; for (auto &a : algs) n += (n.empty() ? "" : ",") + a; r = {n, "failed", 0, 0, 0, false, true}; }   // engine.go:315-328
-                    printf("%-24s %-12s %9.2f%% %9.2f %9.2f %s\n", r.engine.c_str(), r.timeTaken.c_str(), r.ratio, r.entropy, r.actualEntropy, r.failed ? "DNF" : r.lossless ? "true" : "false");
+                    catch (const std::exception &e) { r = {n, "failed", 0, 0, 0, false, true}; }   // recover(), engine.go:315-328
+                    (r.failed ? failed : done).push_back(r);
                 }
+                std::stable_sort(done.begin(), done.end(), [](const engine::Result &a, const engine::Result &b) {   // engine.go:266-276
+                    if (a.lossless != b.lossless) return a.lossless;
+                    return a.ratio < b.ratio;
+                });
+                printf("%-24s | %-12s | %-17s | %-14s | %-19s | %s\n", "engine", "time taken", "compression ratio", "actual entropy", "theoretical entropy", "lossless");
+                for (auto &r : done) {
+                    char ratio[32]; snprintf(ratio, sizeof ratio, "%.2f%%", r.ratio);
+                    printf("%-24s | %-12s | %-17s | %-14.2f | %-19.2f | %s\n", r.engine.c_str(), r.timeTaken.c_str(), ratio, r.actualEntropy, r.entropy, r.lossless ? "true" : "false");
+                }
+                for (auto &r : failed) printf("%-24s | %-12s | %-17s | %-14s | %-19s | %s\n", r.engine.c_str(), r.timeTaken.c_str(), "DNF", "DNF", "DNF", "false");
+                printf("%-24s | %-12s | %-17s | %s\n", "File", f.c_str(), "Size", ByteCountSI((long long)read_file(f).size()).c_str());
             }
         }
     } catch (const std::exception &e) {

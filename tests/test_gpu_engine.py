@@ -49,6 +49,21 @@ def test_cpp_host_cli(tmp_path, oracle, samiam):
     assert src.read_bytes() == samiam and not rsn.exists()  # -delete defaults to true (cli.go:150)
     out = subprocess.check_output([exe, "-benchmark", str(src), "-algorithm=huffman,[lzss,huffman],dmc"]).decode()
     assert out.count("true") == 2 and "DNF" in out
+    rows = [ln.split("|")[0].strip() for ln in out.splitlines() if "|" in ln]
+    assert rows == ["engine", "lzss,huffman", "huffman", "dmc", "File"]      # engine.go:266-289: by ratio, failed rows, footer
+    assert "3.5 kB" in out and "Benchmarking lzss,huffman" in out
+
+
+def test_benchmark_suite_table(tmp_path, samiam):
+    import io
+    from raisin_amd import engine
+    src = tmp_path / "sam.txt"
+    src.write_bytes(samiam)
+    buf = io.StringIO()
+    res = engine.BenchmarkSuite([str(src)], engine.parseAlgorithms("huffman,lzss,[lzss,huffman],arithmetic"), out=buf)
+    assert [r.CompressionEngine for r in res] == ["lzss,huffman", "lzss", "huffman", "arithmetic"]   # 39.64 % < 55.04 % < 58.68 %, then DNF
+    text = buf.getvalue()
+    assert "compression ratio" in text and text.count("DNF") == 3 and "File" in text and "3.5 kB" in text
 
 
 def test_concurrent_callers_are_independent(oracle, samiam):
