@@ -78,7 +78,8 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
  * is a hipStream_t (NULL = the thread's own stream).  The call returns after
  * the result size is known on the host; d_out is complete once `stream` has
  * been synchronised (the calls below synchronise it before returning).
- * d_out must be 16-byte aligned and hold rsn_*_bound() bytes.              */
+ * d_out must be 16-byte aligned and hold rsn_*_bound() bytes; [d_in, d_in+n)
+ * and [d_out, d_out+out_cap) must not overlap (RSN_ERR_ARG).                */
 size_t rsn_huffman_compress_bound(size_t n);
 size_t rsn_lzss_compress_bound(size_t n);
 int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);

@@ -194,6 +194,13 @@ int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t 
     return RSN_OK;
 }
 
+// the codecs read d_in while they write d_out: the two ranges must not overlap
+bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
+    if (!a || !b || !na || !nb) return false;
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + nb && y < x + na;
+}
+
 int dev_prologue(Ctx &c, void *stream, hipStream_t *s) {
     int rc = ctx_init(c); if (rc) return rc;
     *s = stream ? (hipStream_t)stream : c.own_stream;
@@ -271,6 +278,7 @@ size_t rsn_lzss_compress_bound(size_t n) { return lzss_compress_bound(n); }
 int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if (!d_in || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
     int rc = dev_prologue(c, stream, &s); if (rc) return rc;
     return huff_encode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n, nullptr, nullptr);
 }
@@ -278,6 +286,7 @@ int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out
 int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if (!d_in || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
     int rc = dev_prologue(c, stream, &s); if (rc) return rc;
     return huff_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
 }
@@ -285,6 +294,7 @@ int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t o
 int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if ((!d_in && n) || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
     int rc = dev_prologue(c, stream, &s); if (rc) return rc;
     return lzss_encode_dev(c, s, (const uint8_t *)d_in, n, window, (uint8_t *)d_out, out_cap, out_n);
 }
@@ -292,6 +302,7 @@ int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_ou
 int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if ((!d_in && n) || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
+    if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
     int rc = dev_prologue(c, stream, &s); if (rc) return rc;
     return lzss_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
 }

@@ -184,3 +184,13 @@ def test_trim_releases_and_the_next_call_recovers(oracle, samiam):
     assert lz.Decompress(lz.CompressAsync(samiam)) == samiam
     _lib.lib().rsn_trim()
     _lib.lib().rsn_trim()
+
+
+def test_overlapping_device_ranges_are_refused():
+    import torch
+    from raisin_amd import RsnError, huffman, lz
+    buf = torch.randint(0, 100, (1 << 20,), dtype=torch.uint8, device="cuda")
+    for fn in (huffman.compress_tensor, lz.compress_tensor):
+        with pytest.raises(RsnError) as e:
+            fn(buf[: 1 << 16], out=buf[1 << 15:])
+        assert e.value.code == -1 and "overlap" in str(e.value)
