@@ -75,6 +75,17 @@ __device__ __forceinline__ size_t skip_open_token(const uint8_t *__restrict__ in
 // '>' among the 22 bytes before it.
 __device__ __forceinline__ uint32_t pack_bit7(uint32_t z) { return ((z >> 7) * 0x00204081u >> 21) & 0xFu; }   // bit 7 of each byte -> 4 bits
 
+__device__ __forceinline__ uint32_t mask_5c(const uint32_t w[4]) {                             // 16-bit mask of the 5C bytes
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t y = w[k] ^ 0x5C5C5C5Cu;
+        const uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+        m |= pack_bit7(~t & 0x80808080u) << (4 * k);
+    }
+    return m;
+}
+
 __device__ __forceinline__ void load_span(const uint32_t *sw, int sbyte, uint32_t w[4]) {      // 16 staged bytes from any offset
     const int q = sbyte >> 2; const uint32_t sh = (uint32_t)(sbyte & 3) * 8;
     uint32_t d[5];
@@ -488,11 +499,15 @@ __global__ __launch_bounds__(DTH) void k_lzd_chain(const uint16_t *__restrict__ 
 }
 
 // the bytes of every tile of a group, tile after tile: a literal, or a byte of the previous tile's tail
+// Also leaves the unescape stage its per-block summaries (k_une_summary's output) while the bytes
+// are still in registers: one pass over the escaped stream less.
 __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t E,
-                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc) {
+                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
+    __shared__ uint32_t s_last[2][DT / ZTILE];                           // per ZTILE block of the tile: index past its last non-5C byte (by tile parity)
     uint8_t *prev = dsm, *nxt = dsm + TL;
     const uint32_t g = blockIdx.x;
+    if (threadIdx.x < 2 * DT / ZTILE) (&s_last[0][0])[threadIdx.x] = 0;
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = g ? gtail[(size_t)(g - 1) * TL + j] : 0;
     const uint32_t x0 = threadIdx.x * 16;
     auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {
@@ -520,8 +535,16 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
             if (x0 + 16 > DT - TL) {                                      // this span overlaps the tile's tail
                 for (uint32_t q = 0; q < 16; q++) { const uint32_t x = x0 + q; if (x >= DT - TL) nxt[x - (DT - TL)] = (uint8_t)(o[q >> 2] >> (8 * (q & 3))); }
             }
+            const uint32_t nv = min(16u, len - x0);
+            const uint32_t non = ~mask_5c(o) & (nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u));
+            if (non) atomicMax(&s_last[t & 1][x0 / ZTILE], (x0 % ZTILE) + 32u - (uint32_t)__builtin_clz(non));
         }
         __syncthreads();
+        if (threadIdx.x < DT / ZTILE && threadIdx.x * ZTILE < len) {
+            const uint32_t blen = min((uint32_t)ZTILE, len - threadIdx.x * ZTILE), last = s_last[t & 1][threadIdx.x];
+            summ[ts / ZTILE + threadIdx.x] = (uint8_t)((last == 0 ? 2 : 0) | ((blen - last) & 1));   // bit1: all 5C; bit0: trailing-run parity
+            s_last[t & 1][threadIdx.x] = 0;                               // two tiles (and two barriers) later it is used again
+        }
         uint8_t *sw = prev; prev = nxt; nxt = sw;
         d0 = e0; d1 = e1;
     }
@@ -536,17 +559,6 @@ __device__ __forceinline__ uint32_t load16_esc(const uint8_t *__restrict__ esc, 
     const uint32_t len = E - s;
     for (uint32_t k = 0; k < len; k++) w[k >> 2] |= (uint32_t)esc[s + k] << (8 * (k & 3));
     return len;
-}
-
-__device__ __forceinline__ uint32_t mask_5c(const uint32_t w[4]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t y = w[k] ^ 0x5C5C5C5Cu;
-        const uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
-        m |= pack_bit7(~t & 0x80808080u) << (4 * k);
-    }
-    return m;
 }
 
 // (all bytes are 5C) << 1 | parity of the trailing 5C run, for `len` bytes with 5C mask m
@@ -707,6 +719,10 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (E == 0) return RSN_OK;
     rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_esc = (uint8_t *)p;
+    const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);                 // unescape blocks
+    rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)n_ub * 2 + 64, &p); if (rc) return rc;
+    unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
+    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + n_ub;
     // ---- L2
     const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), n_groups = (uint32_t)ceil_div(n_tiles, DGRP);
     rc = dev_buf(c, 19, (size_t)n_tiles * 8 + 64, &p); if (rc) return rc;
@@ -739,7 +755,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, d_comp);
             RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_groups - 1, d_gtail);
         }
-        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, d_esc);
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, d_esc, d_summ);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (hflag[3]) tile_path = false;                                  // a tile's input did not fit (zero-length tokens): redo with the general path
@@ -760,11 +776,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         RSN_LAUNCH("lzss_dec_gather", k_lzd_gather, dim3(grid), dim3(ZB), 0, s, d_src, d_esc, E);
     }
     // ---- unescape
-    const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);
-    rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)n_ub * 2 + 64, &p); if (rc) return rc;
-    unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
-    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + n_ub;
-    RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);
+    if (!tile_path) RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);   // the tile path's emit kernel wrote them
     RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(1024), 0, s, d_summ, n_ub, d_inpar);
     RSN_LAUNCH("lzss_une_count", k_une_count, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_inpar, d_ulen);
     RSN_LAUNCH("lzss_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_ulen, d_uoff, n_ub, d_utot);
