@@ -592,12 +592,17 @@ __global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ summ, uint32_t n_blk, uint8_t *__restrict__ in_par) {
     __shared__ uint8_t s_chunk[1024];
     __shared__ uint8_t s_in[1024];
-    const uint32_t per = (n_blk + 1023) / 1024;
+    const uint32_t per = ((n_blk + 1023) / 1024 + 15) & ~15u;           // a multiple of 16: chunks are read and written in 16-byte units
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, n_blk);
+    auto fold = [](uint32_t &all, uint32_t &par, uint32_t v) { if (v & 2) par ^= v & 1; else { all = 0; par = v & 1; } };
     uint32_t all = 2, par = 0;                       // summary of this lane's chunk, same encoding as summ[]
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t v = summ[b];
-        if (v & 2) par ^= v & 1; else { all = 0; par = v & 1; }
+    for (uint32_t b = b0; b < b1; b += 16) {
+        if (b + 16 <= n_blk) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(summ + b);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) fold(all, par, (w[k >> 2] >> (8 * (k & 3))) & 0xFF);
+        } else for (uint32_t q = b; q < b1; q++) fold(all, par, summ[q]);
     }
     s_chunk[threadIdx.x] = (uint8_t)(all | par);
     __syncthreads();
@@ -607,10 +612,19 @@ __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ 
     }
     __syncthreads();
     uint32_t p = s_in[threadIdx.x];
-    for (uint32_t b = b0; b < b1; b++) {
-        in_par[b] = (uint8_t)p;
-        const uint32_t v = summ[b];
-        p = (v & 2) ? p ^ (v & 1) : (v & 1);
+    for (uint32_t b = b0; b < b1; b += 16) {
+        if (b + 16 <= n_blk) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(summ + b);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                o[k >> 2] |= p << (8 * (k & 3));
+                const uint32_t x = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                p = (x & 2) ? p ^ (x & 1) : (x & 1);
+            }
+            *reinterpret_cast<uint4 *>(in_par + b) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else for (uint32_t q = b; q < b1; q++) { in_par[q] = (uint8_t)p; const uint32_t x = summ[q]; p = (x & 2) ? p ^ (x & 1) : (x & 1); }
     }
 }
 
@@ -720,9 +734,9 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_esc = (uint8_t *)p;
     const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);                 // unescape blocks
-    rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)n_ub * 2 + 64, &p); if (rc) return rc;
+    rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)round_up(n_ub, 16) * 2 + 64, &p); if (rc) return rc;
     unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
-    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + n_ub;
+    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + round_up(n_ub, 16);   // both 16-byte aligned
     // ---- L2
     const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), n_groups = (uint32_t)ceil_div(n_tiles, DGRP);
     rc = dev_buf(c, 19, (size_t)n_tiles * 8 + 64, &p); if (rc) return rc;
