@@ -569,7 +569,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
         cur = (byte_hit || past) ? end : cur;
         prel = start ? rel : prel;
         d = start ? dn : d;
-        off = start ? 0u : off;
+        off = start ? 2u : off;                                           // the bigram itself is known to match: compare from the third byte
         // ---- list exhausted -- noticed in the trip that took the last entry unless that entry starts a
         //      compare: L = 0 so far falls back to the first-byte range, anything else is final
         const bool exh = fetch && !start && !search && cur >= end;
