@@ -393,9 +393,9 @@ static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH ==
 struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; };
 
 __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint32_t rel) {
-    const uint32_t q = rel >> 2, sh = (rel & 3) * 8;
+    const uint32_t q = rel >> 2;
     const uint32_t w0 = sw[q], w1 = sw[q + 1], w2 = sw[q + 2];
-    return (unsigned long long)__builtin_amdgcn_alignbit(w1, w0, sh) | ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+    return (unsigned long long)__builtin_amdgcn_alignbyte(w1, w0, rel) | ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, rel) << 32);   // v_alignbyte uses rel[1:0]
 }
 
 __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
