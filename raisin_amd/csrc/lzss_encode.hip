@@ -390,7 +390,11 @@ static_assert(HWMAX + HT <= 8192, "an entry keeps the staged offset in 13 bits")
 static_assert(MATCH_STRIP % HT == 0, "a strip is a whole number of hash tiles");
 static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH == 0, "round structure");
 
-struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; };
+struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; const uint32_t *only; unsigned long long *stats; uint32_t *dense; };
+
+#ifndef RSN_CS
+#define RSN_CS 128
+#endif
 
 __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint32_t rel) {
     const uint32_t q = rel >> 2;
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     __shared__ uint32_t s_heavy, s_next;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
+    if (a.only && !a.only[blockIdx.x / (MATCH_STRIP / HT)]) return;     // fix-up round: only the strips where the chain met an unevaluated position
     const long long t0 = (long long)blockIdx.x * HT;
     const long long r0 = t0 - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
@@ -592,6 +597,300 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / HT)] = 1;
 }
 
+// ------------------------------------------------------------------ E2''': the bucket search, evaluated only where a greedy chain lands
+// The output depends on key[i] only at the positions the greedy chain from 0 visits (lzss.go:136-151:
+// a reference skips size-1 positions): about one position in five on text, and the cheap ones (after
+// a match the chain tends to land where few candidates share the bigram).  Which positions those are
+// is only known serially, but greedy chains merge: two chains that ever visit the same position
+// coincide from there on, and from an arbitrary start a chain meets the true one after a match or
+// two (measured on the Zipf text: merge distance p50 7, p99 39 positions).  So a block walks chains:
+//   * one WAVEFRONT per chain.  The 64 lanes examine 64 candidates of the chain's current position at
+//     once (entry, window and tag tests, 8-byte compares against the position's bytes, which every
+//     lane reads from the same LDS address), a DPP/readlane maximum gives the exact key
+//     L<<16 | distance, lane 0 stores it, claims the landing position i + max(1, L) in an LDS bitmap
+//     and the wavefront goes on from there -- all control flow is wave-uniform;
+//   * chains start every CS positions of the tile (handed out from a shared counter) and stop when
+//     they land on a position somebody has claimed: that owner walks the rest;
+//   * one more chain starts CH positions BEFORE the tile: where the true chain enters the tile
+//     depends on every earlier tile, so the block walks a warm-up chain instead, which has merged
+//     with the true one long before it reaches the tile.
+// Every key written is exact; what is speculative is only WHICH positions get one.  All others keep
+// KEY_UNKNOWN; if the true chain ever lands on one (k_parse_mark notices), that strip is redone for
+// all positions by k_match_hash and the parse is repeated -- correctness never rests on the merge,
+// only the speed does.
+template <int CT_, int CTH_, int CS_>
+struct ChainCfg {
+    static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
+    static constexpr int CSH = 8;                           // a bucket's entries are ordered by staged offset >> CSH
+    static constexpr int CH = 256;                          // warm-up positions before the tile
+    static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
+    static constexpr int OFFB = NS <= 8192 ? 13 : NS <= 16384 ? 14 : 15;   // bits of a staged offset in a list entry
+    static constexpr int TAGB = 16 - OFFB;                  // the rest carries bits 5.. of the second byte
+    static constexpr int OFF0 = TAGB >= 3 ? 2 : 1;          // bytes known equal when bucket and tag agree
+    static constexpr int STAGE = NS + HLMAX + 32;
+    static constexpr int NBLK = (NS + (1 << CSH) - 1) >> CSH;
+    static constexpr uint32_t ROUND_CAP = 1u << 16;         // candidate rounds per wavefront before the strip is handed back
+    static_assert(CTH % (1 << CSH) == 0 && (HNB / 2) % CTH == 0 && NS <= 32768 && NBLK <= 64, "round structure");
+    static_assert(MATCH_STRIP % CT == 0 && CT % 32 == 0 && CH % 32 == 0 && STAGE % 16 == 0, "tile structure");
+};
+
+#define RSN_DPP_QUAD_XOR1 0xB1
+#define RSN_DPP_QUAD_XOR2 0x4E
+#define RSN_DPP_ROW_HALF_MIRROR 0x141
+#define RSN_DPP_ROW_MIRROR 0x140
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {       // the maximum over the 64 lanes, wave-uniform
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR1, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR2, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_MIRROR, 0xF, 0xF, true));   // every lane: maximum of its row of 16
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <class C>
+__global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
+    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = C::CS, CH = C::CH, NS = C::NS;
+    constexpr uint32_t OFFM = (1u << C::OFFB) - 1, TAGM = (1u << C::TAGB) - 1;
+    __shared__ __attribute__((aligned(16))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream
+    __shared__ uint32_t s_cur[HNB / 2];                                   // two 16-bit counters per word: counts, then starts, then ends
+    __shared__ uint16_t s_list[NS];                                       // staged offset | tag << OFFB, grouped by bucket
+    __shared__ uint32_t s_claim[(CH + CT) / 32];                          // positions somebody has taken, relative to t0 - CH
+    __shared__ unsigned long long s_present[256];                         // per byte value: the 2^CSH-position blocks of the stage it occurs in
+    __shared__ uint32_t s_part[CTH / 64];
+    __shared__ uint32_t s_heavy, s_next, s_dense;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t E = a.E, W = a.W;
+    const long long t0 = (long long)blockIdx.x * CT;
+    const long long r0 = t0 - CH - HWMAX;
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
+#ifdef RSN_CHAIN_STATS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    uint32_t n_evals = 0, n_rounds = 0, n_ext = 0;
+#endif
+    for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
+        const long long P = r0 + 16ll * v;
+        uint4 x = {0, 0, 0, 0};
+        if (P >= 0 && P + 16 <= (long long)E) x = *reinterpret_cast<const uint4 *>(a.fc + P);
+        else if (P + 16 > 0 && P < (long long)E) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)E) w[k >> 2] |= (uint32_t)a.fc[q] << (8 * (k & 3)); }
+            x = {w[0], w[1], w[2], w[3]};
+        }
+        reinterpret_cast<uint4 *>(sw)[v] = x;
+    }
+    for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
+    for (int i = tid; i < (CH + CT) / 32; i += CTH) s_claim[i] = 0;
+    for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
+    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; }
+    __syncthreads();
+
+    constexpr uint32_t T0 = HWMAX + CH;                                   // staged offset of the tile's first position
+    if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match)
+        bool ok = true;
+        const uint32_t qn = (uint32_t)min((long long)(CT + HLMAX), (long long)E - t0);
+        for (uint32_t q = tid; q < qn; q += CTH) ok = ok && sb[T0 + q] == sb[T0 + q - W];
+        if (__syncthreads_and(ok)) {
+            const long long q_end = min(t0 + (long long)CT + (long long)W - 1, (long long)E);
+            for (long long q = t0 + CT + HLMAX + tid; q < q_end; q += CTH) ok = ok && a.fc[q] == a.fc[q - W];
+            if (__syncthreads_and(ok)) {
+                for (long long p = t0 + tid; p < min(t0 + (long long)CT, (long long)E); p += CTH)
+                    a.keys[p] = ((uint32_t)min((long long)W, (long long)E - p) << 16) | W;
+                return;
+            }
+        }
+    }
+
+    // ---- group the staged positions by bigram (as k_match_hash): candidates are [rlo, rhi)
+    const long long q0 = max(0ll, t0 - CH);                               // the warm-up chain starts here
+    const uint32_t zrel = (uint32_t)max(0ll, -r0);                        // staged offset of stream position 0 (or of r0)
+    const uint32_t rlo = (uint32_t)(max(0ll, q0 - (long long)W) - r0), rhi = (uint32_t)(min((long long)E - 1, t0 + (long long)CT) - r0);
+    for (uint32_t rel = tid; rel < (uint32_t)NS; rel += CTH) {
+        if (rel < rlo || rel >= rhi) continue;
+        const uint32_t b0 = sb[rel], h = (b0 << 5) | (sb[rel + 1] & 31u);
+        atomicAdd(&s_cur[h >> 1], 1u << (16 * (h & 1)));
+        const unsigned long long bit = 1ull << (rel >> CSH);
+        if (!(s_present[b0] & bit)) atomicOr(&s_present[b0], bit);
+    }
+    __syncthreads();
+    {
+        constexpr int PER = HNB / 2 / CTH;                                // counter words per thread
+        uint32_t sum = 0;
+        for (int k = 0; k < PER; k++) { const uint32_t x = s_cur[tid * PER + k]; sum += (x & 0xFFFF) + (x >> 16); }
+        uint32_t incl = sum;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int k = 0; k < wv; k++) run += s_part[k];
+        for (int k = 0; k < PER; k++) {
+            const uint32_t x = s_cur[tid * PER + k], c0 = x & 0xFFFF, c1 = x >> 16;
+            s_cur[tid * PER + k] = run | ((run + c0) << 16);
+            run += c0 + c1;
+        }
+    }
+    __syncthreads();
+    // scatter in rounds of 2^CSH consecutive offsets with a barrier between them: inside a bucket the
+    // entries end up ordered by offset >> CSH, which is all the window bisection below needs
+    for (uint32_t base = 0; base < (uint32_t)NS; base += CTH) {
+        const uint32_t rel = base + tid;
+#pragma unroll
+        for (int g = 0; g < (CTH >> CSH); g++) {
+            if ((tid >> CSH) == g && rel >= rlo && rel < rhi) {
+                const uint32_t b1 = sb[rel + 1];
+                const uint32_t h = ((uint32_t)sb[rel] << 5) | (b1 & 31u), sh = 16 * (h & 1);
+                const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
+                s_list[slot] = (uint16_t)(rel | (((b1 >> 5) & TAGM) << C::OFFB));
+            }
+            __syncthreads();
+        }
+    }
+    const uint16_t *ends = reinterpret_cast<const uint16_t *>(s_cur);    // ends[h]; the bucket starts at ends[h-1]
+#ifdef RSN_CHAIN_STATS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- chains.  Positions are counted from t0 - CH (kp); staged offset = HWMAX + kp.  Everything
+    //      named u_* is the same in all 64 lanes.
+    const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0);
+    const uint32_t kp_end = CH + npos;                                    // a chain stops when it leaves the tile
+    const uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                 // the warm-up start (CH in tile 0: the true start)
+    const uint32_t nitems = 1 + (npos + CS - 1) / CS;
+    // a wavefront that gives up (s_heavy) also pushes the start counter past every item: the others
+    // finish the chain they are on (at most CS-odd positions) and find nothing more to start
+    constexpr uint32_t GIVE_UP = 0x40000000u;
+    // Nearly incompressible data (chain steps of one or two positions) is the one case where walking
+    // chains loses: almost every position is visited, and a whole wavefront per visit costs more than
+    // k_match_hash's one lane per position with its near-empty buckets.  A wavefront whose chain
+    // advanced less than two positions per visit hands the strip to k_match_hash.
+    constexpr uint32_t DENSE_EVALS = 32;
+    bool heavy = false, longm = false;
+    uint32_t u_next = 0xFFFFFFFFu, rounds = 0, visits = 0, from_kp = 0, last_kp = 0;   // visits of the chain in hand, its first and latest position
+    for (;;) {
+        if (heavy) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_heavy = 1; } break; }
+        uint32_t u_kp = uni(u_next);
+        if (u_kp >= kp_end) {
+            if (visits >= DENSE_EVALS && last_kp - from_kp < 2 * visits) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; } break; }
+            uint32_t kq = 0;
+            if (lane == 0) kq = atomicAdd(&s_next, 1u);
+            kq = uni(kq);
+            if (kq >= nitems) break;
+            u_kp = kq == 0 ? kp_first : CH + (kq - 1) * CS;
+            visits = 0; from_kp = u_kp;
+        }
+        {
+            uint32_t old = 0;
+            if (lane == 0) old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
+            old = uni(old);
+            u_next = 0xFFFFFFFFu;
+            if ((old >> (u_kp & 31)) & 1) continue;                       // somebody else's already: that wavefront walks the rest
+        }
+        const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
+        const uint32_t u_b0 = uni(sb[u_irel]), u_b1 = uni(sb[u_irel + 1]);
+        uint32_t best = 0;
+        if (u_capE >= 2) {
+            const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
+            uint32_t u_lo = uni(u_h ? ends[u_h - 1] : 0);
+            const uint32_t u_hi = uni(ends[u_h]);
+            const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
+            const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);      // the position's own bytes: one address for all lanes
+            while (u_hi - u_lo > 64) {                                    // skip the entries before the window, 64-ary
+                const uint32_t n = u_hi - u_lo, stride = (n + 63) >> 6;
+                const uint32_t idx = min(u_lo + (uint32_t)lane * stride, u_hi - 1);
+                const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
+                const unsigned long long in = __ballot(blk >= u_blk_lo);
+                const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
+                if (first <= 1) break;
+                u_lo = min(u_lo + (first - 1) * stride, u_hi - 1);
+                if (stride == 1) break;
+            }
+            for (uint32_t base = u_lo; base < u_hi; base += 64) {
+#ifdef RSN_CHAIN_STATS
+                n_rounds++;
+#endif
+                if (++rounds > C::ROUND_CAP) { heavy = true; break; }
+                const uint32_t idx = base + (uint32_t)lane;
+                const bool valid = idx < u_hi;
+                const uint32_t e = s_list[valid ? idx : u_lo];
+                const uint32_t rel = e & OFFM, dn = u_irel - rel;
+                const bool ok = valid && dn - 1u < W && (e >> C::OFFB) == u_tag;   // candidate start in [i-W, i), same bigram up to the tag
+                const bool last = __ballot(valid && (rel >> CSH) > u_blk_i) != 0; // the rest of the bucket starts after i
+                if (__ballot(ok)) {
+                    const uint32_t cap = min(dn, u_capE);                  // entirely inside the window, and inside the stream
+                    uint32_t off = C::OFF0;
+                    unsigned long long x = lds_load8(sw, rel + off) ^ pat0;
+                    uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                    bool more = ok && n == 8 && off + 8 < cap;
+                    while (__ballot(more)) {                               // longer than eight bytes: the lanes concerned go on, eight at a time
+#ifdef RSN_CHAIN_STATS
+                        n_ext++;
+#endif
+                        if (more) {
+                            off += 8;
+                            x = lds_load8(sw, rel + off) ^ lds_load8(sw, u_irel + off);
+                            n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                            more = n == 8 && off + 8 < cap;
+                        }
+                        if (__ballot(more && off + 8 >= HLMAX)) { longm = true; break; }
+                    }
+                    uint32_t len = min(off + n, cap);
+                    if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
+                    best = max(best, (ok && len) ? (len << 16) | dn : 0u); // longest, then farthest back (bytes.Index, lzss.go:419)
+                }
+                if (last) break;
+            }
+            best = wave_max_u32(best);
+        }
+        if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
+                       // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
+            longm = false;
+            const uint32_t Lp = min(W, u_capE);
+            bool eq = u_ipos >= W;
+            if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
+            if (__ballot(!eq)) heavy = true;
+            else best = (Lp << 16) | W;
+        }
+        if (heavy) continue;
+        if (best == 0) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
+            if (visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) {   // (the density test sits on this path because dense data comes through here all the time, text rarely)
+                if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; }
+                break;
+            }
+            const uint32_t ws = max(u_irel - min(W, u_irel), zrel);       // the window is staged [ws, irel)
+            const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
+            bool hit = false;
+            if (fb_lo < fb_hi) {
+                const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
+                hit = (s_present[u_b0] & m) != 0;
+            }
+            if (!hit) {                                                   // the two ragged ends, byte by byte
+                const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
+                bool f = false;
+                for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
+                for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
+                hit = __ballot(f) != 0;
+            }
+            best = hit ? (1u << 16) : 0u;
+        }
+        if (lane == 0) a.keys[u_ipos] = best;
+        u_next = u_kp + max(1u, best >> 16);                              // lzss.go:139-142: a reference skips size-1 positions
+        visits++; last_kp = u_kp;
+#ifdef RSN_CHAIN_STATS
+        n_evals++;
+#endif
+    }
+#ifdef RSN_CHAIN_STATS
+    if (a.stats && lane == 0) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();       // this wavefront is done
+        atomicAdd(&a.stats[0], (unsigned long long)n_rounds); atomicAdd(&a.stats[1], (unsigned long long)n_evals); atomicAdd(&a.stats[2], (unsigned long long)n_ext);
+        atomicAdd(&a.stats[4], st1 - st0); atomicAdd(&a.stats[5], st2 - st1); atomicAdd(&a.stats[6], 1ull);
+    }
+#endif
+    __syncthreads();
+    if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / CT)] = 1;
+    if (tid == 0 && s_dense && !s_heavy) a.dense[blockIdx.x / (MATCH_STRIP / CT)] = 1;
+}
+
 // ------------------------------------------------------------------ E3: greedy chain
 __device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len) {   // len("<off,len>"), lzss.go:318-320
     auto digits = [](uint32_t v) { return v < 10 ? 1u : v < 100 ? 2u : v < 1000 ? 3u : v < 10000 ? 4u : 5u; };
@@ -605,7 +904,7 @@ __global__ __launch_bounds__(LB) void k_parse_exit(const uint32_t *__restrict__ 
     for (int i = threadIdx.x; i < PT; i += LB) {
         const uint32_t p = base + i;
         uint32_t L = p < E ? keys[p] >> 16 : 1;
-        if (L == 0) L = 1;
+        if (L == 0 || L == 0xFFFFu) L = 1;                            // literal; or not evaluated (k_match_chain): k_parse_mark reports it if the chain gets there
         nxt[i] = (uint16_t)(i + L);                                   // < PT + MAX_WINDOW <= 65535
     }
     __syncthreads();
@@ -719,7 +1018,8 @@ __device__ __forceinline__ uint32_t leftmost_distance(const uint8_t *sb, uint32_
 // visited positions whose match is long enough to become a token, count the output bytes
 __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ fc, uint32_t *__restrict__ keys, uint32_t E, uint32_t W,
                                                    const uint32_t *__restrict__ entry, uint32_t *__restrict__ flags,
-                                                   unsigned long long *__restrict__ tile_bytes) {
+                                                   unsigned long long *__restrict__ tile_bytes, uint32_t *__restrict__ redo,
+                                                   unsigned long long *__restrict__ n_redo) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_bytes[];   // fc[base-W, base+PT+W): window before, longest match after
     __shared__ uint16_t nxt[PT];
     __shared__ uint32_t fl[PT / 32];
@@ -727,17 +1027,21 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
     __shared__ uint16_t need[PT / 6 + 8];             // chain positions whose distance is still unknown (matches of >= 6: at most PT/6)
     __shared__ uint32_t n_need;
     __shared__ uint16_t seg_entry[PT / 128];
+    __shared__ unsigned long long unk[PT / 64];       // positions without a key (k_match_chain evaluates only where chains land)
+    __shared__ uint32_t s_bad;
     const uint32_t base = blockIdx.x * PT;
     const uint32_t org = (base >= W ? base - W : 0) & ~15u;        // 16-byte aligned start of the tile image
     const uint32_t span = min(base + PT + W, E) - org;
     for (int i = threadIdx.x; i < PT; i += LB) {
         const uint32_t p = base + i;
         uint32_t L = p < E ? keys[p] >> 16 : 1;
-        if (L == 0) L = 1;
+        const unsigned long long um = __ballot(L == 0xFFFFu);      // 64 consecutive positions per wavefront
+        if ((threadIdx.x & 63) == 0) unk[i >> 6] = um;
+        if (L == 0 || L == 0xFFFFu) L = 1;
         nxt[i] = (uint16_t)(i + L);
     }
     for (int i = threadIdx.x; i < PT / 32; i += LB) fl[i] = 0;
-    if (threadIdx.x == 0) n_need = 0;
+    if (threadIdx.x == 0) { n_need = 0; s_bad = 0; }
     __syncthreads();
     // The chain inside the tile, without a serial walk over up to PT positions: (1) pointer jumping
     // gives, for every position, where its chain leaves its 128-position segment; (2) one lane
@@ -770,6 +1074,7 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
         const uint32_t hi = min((threadIdx.x + 1) * SEG, lim);
         while (i < hi) {                                             // this lane owns the flag words of its segment
             fl[i >> 5] |= 1u << (i & 31);
+            if ((unk[i >> 6] >> (i & 63)) & 1) s_bad = 1;            // the chain is on a position nobody evaluated: this strip is redone
             const uint32_t j = nxt[i];
             if (j - i >= 6 && (keys[base + i] & 0xFFFFu) == 0) need[atomicAdd(&n_need, 1u)] = (uint16_t)i;   // shortest encodable match is 6 bytes (lzss.go:318-320,143); the bucket search already knows the distance
             i = j;
@@ -811,7 +1116,10 @@ __global__ __launch_bounds__(LB) void k_parse_mark(const uint8_t *__restrict__ f
     for (int d = 32; d; d >>= 1) bytes += __shfl_down(bytes, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bytes;
     __syncthreads();
-    if (threadIdx.x == 0) tile_bytes[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        tile_bytes[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+        if (s_bad) { redo[blockIdx.x / (MATCH_STRIP / PT)] = 1; atomicAdd(n_redo, 1ull); }
+    }
 }
 
 // ------------------------------------------------------------------ E4: token emit
@@ -943,21 +1251,20 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     rc = dev_buf(c, 9, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_fc = (uint8_t *)p;
     RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
-    // ---- E2
+    // ---- E2 + E3.  Chain mode (default, W <= 4096): keys only where greedy chains land, everything else
+    //      KEY_UNKNOWN; if the parse finds the true chain on an unknown position, those strips are
+    //      searched at every position and the parse runs again (never more rounds than strips).
     rc = dev_buf(c, 10, (size_t)E * 4 + 64, &p); if (rc) return rc;
     uint32_t *d_keys = (uint32_t *)p;
-    MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, nullptr};
+    const uint32_t n_strips = (uint32_t)ceil_div(E, MATCH_STRIP);
+    rc = dev_buf(c, 18, (size_t)n_strips * 12 + 64, &p); if (rc) return rc;
+    uint32_t *d_heavy = (uint32_t *)p, *d_redo = d_heavy + n_strips, *d_dense = d_redo + n_strips;
     static const bool brute = getenv("RSN_LZSS_BRUTE") != nullptr || getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: sweep every strip
-    if (W <= HWMAX && !brute) {
-        const uint32_t n_strips = (uint32_t)ceil_div(E, MATCH_STRIP);
-        rc = dev_buf(c, 18, (size_t)n_strips * 4 + 64, &p); if (rc) return rc;
-        uint32_t *d_heavy = (uint32_t *)p;
-        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 4, s));
-        HashArgs ha{d_fc, E, W, d_keys, d_heavy};
-        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
-        ma.only = d_heavy;
-    }
-    {
+    static const bool allpos = getenv("RSN_LZSS_ALLPOS") != nullptr;                                            // A/B switch: bucket search at every position
+    const bool hashed = W <= HWMAX && !brute;
+    const bool chain_mode = hashed && !allpos;
+    auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 (or k_match) on every strip, or on the flagged ones
+        MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, only};
         const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
         const size_t shmem = (size_t)((MATCH_STRIP + WUB + W4 + 15) & ~15u) + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;
         static thread_local size_t attr_set = 0;
@@ -967,7 +1274,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         }
         static const bool unpacked = getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: the 32-bit (length+distance) sweep
         if (unpacked) {
-            RSN_LAUNCH("lzss_match", k_match, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(LB), shmem, s, ma);
+            RSN_LAUNCH("lzss_match", k_match, dim3(n_strips), dim3(LB), shmem, s, ma);
         } else {
             MatchArgs m2 = ma;
             m2.DW = (W + MW2 - 1) / MW2;
@@ -978,36 +1285,79 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
                 attr2_set = shmem2;
             }
-            RSN_LAUNCH("lzss_match", k_match2, dim3((uint32_t)ceil_div(E, MATCH_STRIP)), dim3(MW2 * 64), shmem2, s, m2);
+            RSN_LAUNCH("lzss_match", k_match2, dim3(n_strips), dim3(MW2 * 64), shmem2, s, m2);
         }
+        return RSN_OK;
+    };
+    if (chain_mode) {
+        static const int cs_env = getenv("RSN_LZSS_CS") ? atoi(getenv("RSN_LZSS_CS")) : 128;   // tuning switch
+        RSN_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)E * 4, s));
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy, nullptr, nullptr, d_dense};
+#ifdef RSN_CHAIN_STATS
+        void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
+        RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
+        ha.stats = (unsigned long long *)stp;
+#endif
+        if (cs_env == 64) { using CC = ChainCfg<8192, 1024, 64>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
+        else if (cs_env == 256) { using CC = ChainCfg<8192, 1024, 256>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
+        else if (cs_env == 512) { using CC = ChainCfg<8192, 512, 128>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
+        else { using CC = ChainCfg<8192, 1024, 128>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
+#ifdef RSN_CHAIN_STATS
+        {
+            unsigned long long hs[8];
+            RSN_HIP(hipMemcpyAsync(hs, stp, 64, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "chain stats: rounds %llu evals %llu (%.3f per position) ext-steps %llu | waves %llu | cycles/wave: setup %.0f walk %.0f | rounds/eval %.2f\n",
+                    hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1]);
+        }
+#endif
+        HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense, nullptr, d_dense};
+        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
+        rc = sweep(d_heavy); if (rc) return rc;
+    } else if (hashed) {
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy, nullptr, nullptr, d_dense};
+        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
+        rc = sweep(d_heavy); if (rc) return rc;
+    } else {
+        RSN_HIP(hipMemsetAsync(d_redo, 0, (size_t)n_strips * 4, s));
+        rc = sweep(nullptr); if (rc) return rc;
     }
     // ---- E3
     const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
     rc = dev_buf(c, 11, (size_t)E * 2 + 64, &p); if (rc) return rc;
     uint16_t *d_exit = (uint16_t *)p;
     rc = dev_buf(c, 12, (size_t)n_pt * 4 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 2) * 8 + 64, &p); if (rc) return rc;
-    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;
+    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;   // d_ttot[1]: strips to redo
     uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
     uint32_t *d_flags = d_entry + n_pt;
-    RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
-    {
-        const uint32_t n_groups = (uint32_t)ceil_div(n_pt, SUPER);
-        void *q; rc = dev_buf(c, 17, (size_t)n_groups * PT * 4 + (size_t)n_groups * 8 + 64, &q); if (rc) return rc;
-        uint32_t *d_super = (uint32_t *)q;
-        unsigned long long *d_gentry = (unsigned long long *)(d_super + (size_t)n_groups * PT);
+    const uint32_t n_groups = (uint32_t)ceil_div(n_pt, SUPER);
+    void *q; rc = dev_buf(c, 17, (size_t)n_groups * PT * 4 + (size_t)n_groups * 8 + 64, &q); if (rc) return rc;
+    uint32_t *d_super = (uint32_t *)q;
+    unsigned long long *d_gentry = (unsigned long long *)(d_super + (size_t)n_groups * PT);
+    const size_t mark_sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
+    static thread_local size_t mark_attr = 0;
+    if (mark_sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mark_sh)); mark_attr = mark_sh; }
+    for (uint32_t round = 0;; round++) {
+        RSN_HIP(hipMemsetAsync(d_ttot + 1, 0, 8, s));
+        RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
         RSN_LAUNCH("lzss_parse_super", k_parse_super, dim3(n_groups), dim3(LB), 0, s, d_exit, n_pt, E, d_super);
         RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry);
         RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
+        RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), mark_sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, d_redo, d_ttot + 1);
+        RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+        RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        if (h64[1] == 0) break;
+        if (!chain_mode || round > n_strips) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: the parse met an unevaluated position outside chain mode");
+        // the true chain landed where no speculative chain had been: search those strips at every position
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 4, s));
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy, d_redo, nullptr, d_dense};
+        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
+        rc = sweep(d_heavy); if (rc) return rc;
+        RSN_HIP(hipMemsetAsync(d_redo, 0, (size_t)n_strips * 4, s));
     }
-    {
-        const size_t sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
-        static thread_local size_t mark_attr = 0;
-        if (sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); mark_attr = sh; }
-        RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes);
-    }
-    RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
-    RSN_HIP(hipMemcpyAsync(h64, d_ttot, 8, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipStreamSynchronize(s));
     const size_t total = (size_t)h64[0];
     *out_n = total;
     if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
