@@ -200,3 +200,101 @@ def test_device_resident_16MiB(lz, oracle):
     d = lz.decompress_tensor(c)
     assert torch.equal(d, src)
     assert bytes(c.cpu().numpy()) == oracle.lzss_compress(data)
+
+
+# ---- chain walk (k_match_chain): keys only where greedy chains land -------------------------
+def long_copies(seed, n, seg=(90, 240)):
+    """Matches of 90..240 bytes from up to 3000 back, one fresh byte between them: a chain step is
+    about as long as the 256-position warm-up, so the warm-up chain often has NOT merged with the
+    true chain when it reaches its tile and the parse lands on unevaluated positions."""
+    rng = np.random.default_rng(seed)
+    out = bytearray(rng.integers(97, 123, size=4096, dtype=np.uint8).tobytes())
+    while len(out) < n:
+        ln = int(rng.integers(seg[0], seg[1]))
+        back = int(rng.integers(ln + 1, 3000))
+        start = len(out) - back
+        out += out[start:start + ln]
+        out.append(int(rng.integers(65, 91)))
+    return bytes(out[:n])
+
+
+def _prof(lz_mod, data, w=4096):
+    from raisin_amd import _lib
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    c = lz_mod.CompressAsync(data, False, w)
+    p = _lib.prof_get()
+    _lib.prof_enable(False)
+    return c, p
+
+
+def test_chain_redo_round(lz, oracle):
+    """The true chain meets a position no speculative chain evaluated: those strips are searched at
+    every position and the parse is repeated -- same bytes as the oracle.  A 200-periodic stream
+    under a 300-byte window has L = 200 everywhere, so chains of different phase never merge."""
+    blk = rnd(5, 200, bytes(range(97, 123)))
+    redone = 0
+    for n, w in ((60000, 300), (100001, 250), (50000, 201)):
+        data = (blk * (n // 200 + 1))[:n]
+        c, p = _prof(lz, data, w)
+        assert c == oracle.lzss_compress(data, w)
+        assert lz.Decompress(c) == data
+        redone += p["lzss_parse_exit"][0] > 1
+    assert redone == 3, "the redo round was not exercised"
+    for seed in (1, 2):                      # long copies with natural re-synchronisation points
+        data = long_copies(seed, 120000)
+        assert lz.CompressAsync(data) == oracle.lzss_compress(data)
+
+
+def test_chain_dense_and_mixed(lz, oracle):
+    """Incompressible stretches are handed to the all-positions search strip by strip."""
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()
+    mixed = text(21, 50000) + noise + text(22, 40000) + b"ab" * 9000 + noise[:33000] + long_copies(9, 30000)
+    for data in (noise, mixed):
+        c, p = _prof(lz, data)
+        assert p["lzss_match_chain"][0] == 1
+        assert c == oracle.lzss_compress(data)
+        assert lz.Decompress(c) == data
+
+
+def test_chain_tile_edges(lz, oracle):
+    """Sizes around the 8192-position chain tile, its 256-position warm-up and the 16384 strip."""
+    base = text(31, 40000)
+    for n in (8191, 8192, 8193, 8192 + 255, 8192 + 256, 8192 + 257, 16383, 16384, 16385, 24576 + 1, 32768):
+        data = base[:n]
+        assert lz.CompressAsync(data) == oracle.lzss_compress(data), n
+
+
+def test_chain_period_inside_first_tile(lz, oracle):
+    """A W-periodic stretch that starts inside a tile (config 3's first tile): answered position by
+    position (nothing beats L = W at distance W) instead of going to the sweep."""
+    blk = rnd(77, 4096, bytes(v for v in range(256) if v not in (0x5C, 0xFF, 0x3C)))
+    data = blk * 9 + b"tail" + blk[:1000]
+    c, p = _prof(lz, data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
+    for w in (1000, 4095):
+        data = blk[:w] * 12
+        assert lz.CompressAsync(data, False, w) == oracle.lzss_compress(data, w)
+
+
+def test_chain_vs_allpos_switch(oracle):
+    """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes: separate process,
+    the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from raisin_amd import lz\n"
+            "import hashlib\n"
+            "from tests.test_gpu_lzss import text, long_copies\n"
+            "d = text(5, 150000) + long_copies(4, 60000)\n"
+            "print(hashlib.sha256(lz.CompressAsync(d)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"RSN_LZSS_ALLPOS": "1"}):
+        e = dict(os.environ); e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
+    import hashlib
+    d = text(5, 150000) + long_copies(4, 60000)
+    assert outs[0] == outs[1] == hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
