@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: BASELINE.json configs[1] (config 5 when --gpus > 1).
+"""bench.py -- headline benchmark: BASELINE.json configs[1] (config 5's per-GPU chunk when --gpus > 1).
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (per GPU): `-algorithm=huffman` on a 1 GiB uniform-random buffer (bytes
-uniform over 0x00..0x7F so that the reference's rune-level Huffman is lossless,
-SURVEY.md 8d "2a"; seed 0x5EED0002, rank r uses 0x5EED0050+r when N > 1).
-A step is what the reference's BenchmarkFile times (engine/engine.go:379-406):
-compress, then decompress, of one buffer, input already resident in HBM.
+Timed workload (per GPU): `-algorithm=huffman` on a 1 GiB uniform-random buffer (config "2a": bytes uniform
+over 0x00..0x7F so that the reference's rune-level Huffman is lossless; splitmix64 seed 0x5EED0002, rank r
+uses 0x5EED0050+r when N > 1 -- workloads.py).  A step is what the reference's BenchmarkFile times
+(engine/engine.go:379-406): compress, then decompress, of one buffer, input already resident in HBM.
 value = uncompressed MB (1e6 B) through encode+decode per second, whole job.
 
-Timing of the kernels comes from HIP events recorded by librsn on its own launch
-stream (rsn_prof_*), live inside the timed region.  The CPU baseline is the
-oracle (oracle/, a C restatement of the reference: the reference is Go and cannot
-run here) timed on a bounded sample on rank 0.
+After the timed region (N = 1 only) every other BASELINE config runs at the same size and is reported under
+`other_configs`: 2b (uniform 0x00..0xFF: the rune path, lossy exactly like the reference), `skewed` (unequal code
+lengths: the general Huffman kernels), 3 (`lzss`, 4096-periodic), 4 (`lzss,huffman` on Zipf text) -- each with
+encode/decode ms, ratio, lossless, a bit-exact check against the oracle on a sample, the dominant kernel, the
+algorithmic-byte fractions of the HBM peak and its own threaded CPU baseline.
+
+Kernel timings come from HIP events recorded by librsn on its own launch stream (rsn_prof_*), live inside the
+timed region.  The CPU baseline is oracle/cpu_baseline.c -- the C restatement of the reference (the reference is
+Go and cannot run here: kind "port") on all host cores, on a bounded sample, on rank 0.
 """
 import argparse
 import json
@@ -27,31 +31,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def make_input(torch, n, seed, device, hi=128):
-    g = torch.Generator(device=device).manual_seed(seed)
-    return torch.randint(0, hi, (n,), dtype=torch.uint8, device=device, generator=g)
-
-
-def cpu_baseline(sample):
-    """Oracle encode+decode on a bounded sample, single thread."""
-    from oracle import oracle as O
-    O.build()
-    t0 = time.perf_counter()
-    c = O.huffman_compress(sample)
-    t1 = time.perf_counter()
-    d = O.huffman_decompress(c)
-    t2 = time.perf_counter()
-    assert d == sample
-    return c, {
-        "value": round(len(sample) / 1e6 / (t2 - t0), 3), "unit": "MB/s", "cores": 1, "kind": "port",
-        "sample": "%d MiB prefix of the same buffer, encode %.2f s + decode %.2f s, oracle/ (C restatement) on 1 host core of %d"
-                  % (len(sample) >> 20, t1 - t0, t2 - t1, os.cpu_count()),
-        "encode_MBps": round(len(sample) / 1e6 / (t1 - t0), 3), "decode_MBps": round(len(sample) / 1e6 / (t2 - t1), 3),
-    }
-
-
 def load_traffic():
-    """HBM bytes per launch from the committed PMC profile, if present (scripts/profile.sh)."""
+    """HBM bytes per launch from the newest committed PMC profile (scripts/profile.sh): a constant of that
+    profile, not a measurement of this run."""
     import glob
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
@@ -62,14 +44,201 @@ def load_traffic():
     return best or {}
 
 
+# ---------------------------------------------------------------------------------------------- CPU baselines
+def _timed(fn):
+    t0 = time.perf_counter()
+    r = fn()
+    return r, time.perf_counter() - t0
+
+
+def _grow(run, sizes_mib, target_s):
+    """Runs `run(mib)` on growing samples until one takes long enough to be a measurement (or the list ends)."""
+    res = None
+    for mib in sizes_mib:
+        res = run(mib)
+        if res["seconds"] >= target_s / 4:
+            break
+    return res
+
+
+def cpu_huffman(make_sample, cores, target_s=10.0):
+    """Threaded oracle: encode + decode of one buffer (engine.go:379-406 times both together)."""
+    from oracle import oracle as O
+
+    def run(mib):
+        s = make_sample(mib << 20)
+        c, te = _timed(lambda: O.huffman_compress_mt(s, cores))
+        d, td = _timed(lambda: O.huffman_decompress_mt(c, cores))
+        return {"value": round(len(s) / 1e6 / (te + td), 2), "unit": "MB/s", "cores": cores, "kind": "port",
+                "sample": "%d MiB prefix of the same buffer: oracle/cpu_baseline.c on %d threads, encode %.2f s + decode %.2f s"
+                          % (mib, cores, te, td),
+                "encode_MBps": round(len(s) / 1e6 / te, 2), "decode_MBps": round(len(s) / 1e6 / td, 2),
+                "seconds": te + td, "_c": c, "_s": s}
+    return _grow(run, (32, 128, 512), target_s)
+
+
+def cpu_lzss(make_sample, cores, window=4096, target_s=10.0, sizes=(2, 8, 32, 128)):
+    """Threaded oracle in the reference's own shape (a Reference for every position in parallel, serial compaction,
+    lzss.go:117-151), serial decode (lzss.go:323-364); plus the lazy single-thread form for context."""
+    from oracle import oracle as O
+
+    def run(mib):
+        s = make_sample(mib << 20)
+        c, te = _timed(lambda: O.lzss_compress_mt(s, window, cores, 4096))
+        d, td = _timed(lambda: O.lzss_decompress(c))
+        return {"value": round(len(s) / 1e6 / (te + td), 2), "unit": "MB/s", "cores": cores, "kind": "port",
+                "sample": "%d MiB prefix of the same buffer: every-position match table on %d threads + serial compaction "
+                          "%.2f s, serial decode %.2f s" % (mib, cores, te, td),
+                "encode_MBps": round(len(s) / 1e6 / te, 2), "decode_MBps": round(len(s) / 1e6 / td, 2),
+                "seconds": te + td, "_c": c, "_s": s}
+    return _grow(run, sizes, target_s)
+
+
+def cpu_lzss_per_position(make_sample, cores, mib=1):
+    """The reference's goroutine-per-byte shape taken literally: one task per position (lzss.go:117-130)."""
+    from oracle import oracle as O
+    s = make_sample(mib << 20)
+    _, t = _timed(lambda: O.lzss_compress_mt(s, 4096, cores, 1))
+    _, tl = _timed(lambda: O.lzss_compress(s, 4096))
+    return {"one_task_per_position_MBps": round(len(s) / 1e6 / t, 2), "lazy_single_thread_MBps": round(len(s) / 1e6 / tl, 2),
+            "sample_MiB": mib, "cores": cores}
+
+
+def _public(d):
+    return {k: v for k, v in d.items() if not k.startswith("_") and k != "seconds"}
+
+
+# ---------------------------------------------------------------------------------------------- other configs
+ALG_NOTE = "algorithmic HBM bytes (SURVEY.md 8d): huffman encode 2N+C, decode C+N_out; lzss encode N+C, decode C+N"
+
+
+def run_other_configs(torch, device, n, cores, with_cpu, names):
+    import workloads as W
+    from oracle import oracle as O
+    from raisin_amd import _lib, huffman, lz
+    out = {}
+
+    def gpu_bytes(t):
+        return bytes(t.cpu().numpy())
+
+    for name in names:
+        src = W.config_input("4" if name == "4" else name, n, device)
+        layers = {"2b": ["huffman"], "skewed": ["huffman"], "3": ["lzss"], "4": ["lzss", "huffman"]}[name]
+        enc = {"huffman": huffman.compress_tensor, "lzss": lz.compress_tensor}
+        dec = {"huffman": huffman.decompress_tensor, "lzss": lz.decompress_tensor}
+
+        ebuf, dbuf = {}, {}                                 # output buffers, sized by the warm-up pass and reused by the timed passes
+
+        def compress(x, bufs=None):                         # engine.go:443-452: layers in order
+            sizes = []
+            for i, a in enumerate(layers):
+                x = enc[a](x, out=bufs.get(i) if bufs else None)
+                sizes.append(int(x.numel()))
+            return x, sizes
+
+        def decompress(x, bufs=None):                       # engine.go:454-479: layers in reverse
+            outs = []
+            for i, a in enumerate(reversed(layers)):
+                x = dec[a](x, out=bufs.get(i) if bufs else None)
+                outs.append(int(x.numel()))
+            return x, outs
+
+        c, wsz = compress(src)                              # warm-up: scratch arenas grow here, not in the timed pass
+        d, dsz = decompress(c)
+        del c, d
+        for i, m in enumerate(wsz):
+            ebuf[i] = torch.empty(m + (1 << 16), dtype=torch.uint8, device=device)
+        for i, m in enumerate(dsz):
+            dbuf[i] = torch.empty(m + (1 << 16), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        _lib.prof_enable(True)
+        reps = 2
+        te = td = 0.0
+        prof_e, prof_d = {}, {}
+        for _ in range(reps):
+            _lib.prof_reset()
+            (c, sizes), t = _timed(lambda: compress(src, ebuf))   # the C ABI calls return after their stream has been synchronised
+            te += t
+            prof_e = _lib.prof_get()
+            _lib.prof_reset()
+            (d, _), t = _timed(lambda: decompress(c, dbuf))
+            td += t
+            prof_d = _lib.prof_get()
+        _lib.prof_enable(False)
+        te, td = te / reps * 1e3, td / reps * 1e3
+        C, n_out = int(c.numel()), int(d.numel())
+        lossless = bool(n_out == n and torch.equal(d, src))
+        # algorithmic bytes of the whole call(s)
+        if name == "4":
+            l1 = sizes[0]
+            alg_e, alg_d = (n + l1) + (2 * l1 + C), (C + l1) + (l1 + n)
+        elif layers == ["lzss"]:
+            alg_e, alg_d = n + C, C + n
+        else:
+            alg_e, alg_d = 2 * n + C, C + n_out
+        ent = {
+            "algorithm": ",".join(layers), "bytes": n, "encode_ms": round(te, 3), "decode_ms": round(td, 3),
+            "round_trip_MBps": round(n / 1e6 / ((te + td) / 1e3), 1), "ratio_pct": round(100.0 * C / n, 3), "lossless": lossless,
+            "decoded_bytes": n_out,
+            "encode_frac_of_hbm_peak": round(alg_e / (te / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+            "decode_frac_of_hbm_peak": round(alg_d / (td / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+            "kernels_encode_ms": {k: round(v[1], 3) for k, v in sorted(prof_e.items())},
+            "kernels_decode_ms": {k: round(v[1], 3) for k, v in sorted(prof_d.items())},
+        }
+        if name == "4":
+            ent["layer_sizes"] = sizes
+        allk = {**{k: v[1] for k, v in prof_e.items()}, **{k: v[1] for k, v in prof_d.items()}}
+        dom = max(allk, key=allk.get)
+        kalg = {"huff_byte_hist": n, "huff_rune_hist": n, "huff_tile_bits_rune": n, "huff_emit": n + C, "huff_emit_rune": n + C,
+                "huff_dec_sync": C, "huff_dec_emit": C + n_out, "huff_dec_flat": C + n_out}
+        if name in ("3", "4"):
+            kalg.update({"lzss_match_chain": n, "lzss_match_hash": n, "lzss_match": n})   # reads the (escaped) stream once
+        ent["dominant_kernel"] = {"name": dom, "ms": round(allk[dom], 3)}
+        if dom in kalg and name != "4":
+            ent["dominant_kernel"]["algorithmic_bytes"] = kalg[dom]
+            ent["dominant_kernel"]["frac_of_hbm_peak"] = round(kalg[dom] / (allk[dom] / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)
+        # bit-exact against the oracle on a sample (prefix of the same buffer), through the same layers
+        smp = {"2b": 32 << 20, "skewed": 32 << 20, "3": 2 << 20, "4": 8 << 20}[name]
+        smp = min(smp, n)
+        pre = src[:smp].contiguous()
+        got, _ = compress(pre)
+        ref = gpu_bytes(pre)
+        for a in layers:
+            ref = O.huffman_compress(ref) if a == "huffman" else O.lzss_compress(ref, 4096)
+        ent["bit_exact_vs_oracle_on_sample"] = bool(gpu_bytes(got) == ref)
+        ent["oracle_sample_MiB"] = smp >> 20
+        if with_cpu:
+            def make(k, src=src):
+                return gpu_bytes(src[:min(k, n)])
+            if layers == ["huffman"]:
+                ent["cpu_baseline"] = _public(cpu_huffman(make, cores, target_s=6.0))
+            elif layers == ["lzss"]:
+                ent["cpu_baseline"] = _public(cpu_lzss(make, cores, sizes=(1, 4, 16), target_s=6.0))
+            else:                                          # layered: lzss on the sample, huffman on ITS output, both timed
+                r1 = cpu_lzss(make, cores, target_s=6.0)
+                l1c = r1["_c"]
+                c2, t2e = _timed(lambda: O.huffman_compress_mt(l1c, cores))
+                _, t2d = _timed(lambda: O.huffman_decompress_mt(c2, cores))
+                tot = r1["seconds"] + t2e + t2d
+                ent["cpu_baseline"] = {"value": round(len(r1["_s"]) / 1e6 / tot, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+                                       "sample": r1["sample"] + "; huffman layer on its output: encode %.2f s + decode %.2f s" % (t2e, t2d),
+                                       "lzss_layer_MBps": r1["value"]}
+                ent["cpu_lzss_shape"] = cpu_lzss_per_position(make, cores)
+        out[name] = ent
+        del src, c, d, ebuf, dbuf
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mib", type=int, default=1024, help="buffer size per GPU (default: the 1 GiB of BASELINE.json)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=128)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs after the timed region")
+    ap.add_argument("--others", default="2b,skewed,3,4")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
@@ -77,6 +246,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); for N > 1 run under "
+              "`python -m torch.distributed.run --nproc-per-node N`" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -86,19 +259,17 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.gpus > 1:
-        print("bench.py: --gpus %d needs the torch.distributed launcher (WORLD_SIZE unset)" % args.gpus, file=sys.stderr)
-        sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    import workloads as W
     from raisin_amd import _lib, huffman
+    from raisin_amd import shard as _shard
     _lib.check(_lib.lib().rsn_device_set(local_rank))
 
     n = args.mib << 20
-    from raisin_amd import shard as _shard
     seed = _shard.chunk_seed(rank, world)
-    src = make_input(torch, n, seed, device)
+    src = W.uniform_bytes(n, seed, 128, device)
     comp_buf = torch.empty(n + n // 8 + (1 << 20), dtype=torch.uint8, device=device)
     dec_buf = torch.empty(n + (1 << 20), dtype=torch.uint8, device=device)
 
@@ -133,8 +304,7 @@ def main():
 
     t_max = elapsed
     if dist is not None:
-        from raisin_amd import shard
-        t_max = shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
+        t_max = _shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
 
     lossless = bool(d.numel() == n and torch.equal(d, src))   # checked BEFORE anything else touches dec_buf
     comp_n = int(c.numel())
@@ -155,12 +325,10 @@ def main():
     copy_gbps = _rate(lambda: dec_buf[:n].copy_(src), 2 * n)
     read_gbps = _rate(lambda: src.view(torch.int64).sum(), n)
 
-
     gather_ms = None
     gather_stuck = False
     if dist is not None:
         # config 5: compressed segments to rank 0 over RCCL, timed on its own (not part of `value`)
-        from raisin_amd import shard
         seg = c.clone() if args.dist_backend == "nccl" else c.cpu()
         fence()
         # The gather is extra information: it runs under a watchdog so that a stuck collective can
@@ -171,7 +339,7 @@ def main():
         def _gather():
             torch.cuda.set_device(device)
             g0 = time.perf_counter()
-            got = shard.gather_segments(dist, seg, 0)
+            got = _shard.gather_segments(dist, seg, 0)
             torch.cuda.synchronize(device)
             box["ms"] = (time.perf_counter() - g0) * 1e3
             box["ok"] = rank != 0 or (len(got) == world and got[0].numel() == comp_n)
@@ -212,8 +380,8 @@ def main():
             "metric": "encode+decode MB/s", "value": round(world * K * n / 1e6 / t_max, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(t_max / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "huffman encode+decode, %d MiB uniform-random bytes 0x00-0x7F per GPU (BASELINE configs[%d])"
-                                   % (args.mib, 1 if world == 1 else 4),
+            "config": {"workload": "huffman encode+decode, %d MiB uniform-random bytes 0x00-0x7F per GPU (BASELINE configs[%d]), "
+                                   "splitmix64 seed 0x%X" % (args.mib, 1 if world == 1 else 4, seed),
                        "algorithm": "huffman", "bytes_per_gpu": n, "chunks": world},
             "encode_MBps": round(n / 1e6 / (enc_ms / 1e3), 1), "decode_MBps": round(n / 1e6 / (dec_ms / 1e3), 1),
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
@@ -226,19 +394,33 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 3)
-        if world == 1 and not args.no_cpu:
-            sample = bytes(src[: min(n, args.cpu_sample_mib << 20)].cpu().numpy())
-            ref_c, cb = cpu_baseline(sample)
-            gpu_c = bytes(huffman.compress_tensor(src[: len(sample)].contiguous()).cpu().numpy())
-            out["bit_exact_vs_oracle_on_sample"] = bool(gpu_c == ref_c)
-            out["cpu_baseline"] = cb
         if dist is not None and gather_ms is None:
             out["gather_ms"] = None
             out["gather_note"] = "segment gather did not complete within 120 s" if gather_stuck else "segment gather failed its size check"
+        if world == 1:
+            from oracle import oracle as O
+            O.build()
+            cores = O.host_cores()
+            if not args.no_cpu:
+                def make(k):
+                    return bytes(src[:min(k, n)].cpu().numpy())
+                cb = cpu_huffman(make, cores)
+                smp = cb["_s"]
+                pre = min(len(smp), 32 << 20)              # the threaded baseline's bytes on the whole sample, the plain oracle's on a prefix
+                ok = bytes(huffman.compress_tensor(src[:len(smp)].contiguous()).cpu().numpy()) == cb["_c"]
+                ok = ok and bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy()) == O.huffman_compress(smp[:pre])
+                out["bit_exact_vs_oracle_on_sample"] = bool(ok)
+                out["cpu_baseline"] = _public(cb)
+            del comp_buf, dec_buf
+            torch.cuda.empty_cache()
+            if not args.no_others:
+                names = [x for x in args.others.split(",") if x]
+                out["other_configs"] = run_other_configs(torch, device, n, cores, not args.no_cpu, names)
+                out["other_configs_note"] = ALG_NOTE + "; one warm-up pass, then the mean of 2 timed passes per config"
         print(json.dumps(out), flush=True)
     if dist is not None:
         if gather_stuck:
-            os._exit(0)                 # a collective is still pending: leave without waiting for it
+            os._exit(3)                 # a collective is still pending: leave without waiting for it, and say so
         dist.destroy_process_group()
 
 

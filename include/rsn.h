@@ -65,6 +65,11 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
  * (the engine path: Writer.Write lzss.go:53-57).  window <= 0 = unbounded
  * search buffer (lzss.go:125).  The progress-bar argument has no equivalent. */
 int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
+/* replaces lz.Compress([]byte, bool, int) []byte      lzss.go:224 -- the older synchronous encoder.
+ * Not on the .rsn path (the engine calls CompressAsync) and not accelerated: a host-side
+ * restatement for API completeness, quirks included (every-second-byte FindReverse :425-431,
+ * offsets computed from the unsliced buffer :249-257, `<=` token threshold :272).  Needs no device. */
+int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
 /* replaces lz.Decompress([]byte, bool) []byte         lzss.go:323 */
 int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 

@@ -360,3 +360,46 @@ int rsn_oracle_huffman_decompress(const uint8_t *in, size_t n, int strict_ref_li
     *out = b.p; *out_n = b.n;
     return RSN_ORACLE_OK;
 }
+
+/* ---- helpers for oracle/cpu_baseline.c (the threaded CPU baseline; same semantics, same code) ---- */
+
+/* Header, codes and lengths for a BYTE histogram (every symbol < 0x80, so rune == byte): what
+ * Compress derives from symFreqs (huffman.go:312-318, buildTree :58, printCodes :110). */
+int rsn_oracle_huffman_plan_bytes(const uint64_t hist[256], uint64_t code[256], uint8_t len[256], uint8_t **hdr, size_t *hdr_n) {
+    leaf_t by_rune[256]; uint32_t a = 0;
+    for (uint32_t r = 0; r < 256; r++) if (hist[r]) { by_rune[a].rune = r; by_rune[a].freq = hist[r]; a++; }
+    if (a == 0) { rsn_oracle_set_error("huffman: empty input"); return RSN_ORACLE_ERR; }
+    buf_t b = {0};
+    emit_header(&b, by_rune, a);
+    leaf_t lv[256]; memcpy(lv, by_rune, a * sizeof *lv);
+    tree_t t;
+    if (build_tree(lv, a, &t)) { free(b.p); return RSN_ORACLE_ERR; }
+    uint64_t *c = calloc(t.n_nodes, sizeof *c); uint8_t *l = calloc(t.n_nodes, 1);
+    int rc = assign_codes(&t, c, l, NULL);
+    memset(code, 0, 256 * sizeof *code); memset(len, 0, 256);
+    if (!rc) for (uint32_t i = 0; i < a; i++) { code[t.rune[i]] = c[i]; len[t.rune[i]] = l[i]; }
+    free(c); free(l); tree_free(&t);
+    if (rc) { free(b.p); return RSN_ORACLE_ERR; }
+    *hdr = b.p; *hdr_n = b.n;
+    return RSN_ORACLE_OK;
+}
+
+/* decode's framing and decodeTree (huffman.go:258-297,196-227): the tree as child arrays (left < 0: leaf),
+ * where the payload starts, the pad.  The arrays are released with rsn_oracle_free. */
+int rsn_oracle_huffman_parse(const uint8_t *in, size_t n, size_t *payload_off, unsigned *pad, int32_t **left, int32_t **right,
+                             uint32_t **rune, int32_t *root, uint32_t *n_nodes) {
+    size_t sep = (size_t)-1;
+    for (size_t i = 0; i + 1 < n; i++) if (in[i] == 0x5C && in[i + 1] == 0x0A) { sep = i; break; }
+    if (sep == (size_t)-1) { rsn_oracle_set_error("huffman: no separator"); return RSN_ORACLE_ERR; }
+    uint32_t a;
+    leaf_t *lv = parse_header(in, sep, &a);
+    if (!lv) return RSN_ORACLE_ERR;
+    tree_t t;
+    if (build_tree(lv, a, &t)) { free(lv); return RSN_ORACLE_ERR; }
+    free(lv);
+    *payload_off = sep + 3; *pad = n > sep + 2 ? in[sep + 2] : 0;
+    *left = t.left; *right = t.right; *rune = t.rune; *root = t.root; *n_nodes = t.n_nodes;
+    free(t.freq);
+    return RSN_ORACLE_OK;
+}
+

@@ -106,6 +106,20 @@ int rsn_oracle_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_
     *out = o.p; *out_n = o.n; return RSN_ORACLE_OK;
 }
 
+/* positions [lo, hi) only: the unit of work of oracle/cpu_baseline.c's threads */
+int rsn_oracle_lzss_matches_range(const uint8_t *esc, size_t e, int64_t window, size_t lo, size_t hi, uint32_t *off, uint32_t *size) {
+    for (size_t i = lo; i < hi && i < e; i++) { size_t o, s; match_at(esc, e, i, window, &o, &s); off[i] = (uint32_t)o; size[i] = (uint32_t)s; }
+    return RSN_ORACLE_OK;
+}
+
+/* compaction lzss.go:134-151 over a finished match table */
+int rsn_oracle_lzss_compact(const uint8_t *esc, size_t e, const uint32_t *off, const uint32_t *size, uint8_t **out, size_t *out_n) {
+    buf_t o = {0};
+    for (size_t i = 0; i < e; ) { compact_emit(&o, esc, i, off[i], size[i]); i += size[i] ? size[i] : 1; }
+    if (!o.p) o.p = malloc(1);
+    *out = o.p; *out_n = o.n; return RSN_ORACLE_OK;
+}
+
 int rsn_oracle_lzss_matches(const uint8_t *esc, size_t e, int64_t window, uint32_t *off, uint32_t *size) {
     for (size_t i = 0; i < e; i++) { size_t o, s; match_at(esc, e, i, window, &o, &s); off[i] = (uint32_t)o; size[i] = (uint32_t)s; }
     return RSN_ORACLE_OK;

@@ -12,7 +12,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("huffman_oracle.c", "lzss_oracle.c", "rsn_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("huffman_oracle.c", "lzss_oracle.c", "cpu_baseline.c", "rsn_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return _SO
@@ -56,6 +56,12 @@ def lib():
         L.rsn_oracle_utf8_runes.restype = ctypes.c_size_t
         L.rsn_oracle_utf8_runes.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         L.rsn_oracle_lzss_matches.restype = ctypes.c_int
+        for name in ("rsn_baseline_huffman_compress_mt", "rsn_baseline_huffman_decompress_mt"):
+            f = getattr(L, name)
+            f.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, outp, szp]
+            f.restype = ctypes.c_int
+        L.rsn_baseline_lzss_compress_mt.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, outp, szp]
+        L.rsn_baseline_lzss_compress_mt.restype = ctypes.c_int
         L.rsn_oracle_lzss_matches.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -105,6 +111,27 @@ def lzss_escape(data):
 
 def lzss_unescape(data):
     return _call(lib().rsn_oracle_lzss_unescape, data)
+
+
+# ---- the threaded CPU baseline (oracle/cpu_baseline.c): same bytes as the functions above, on `threads` host cores
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def huffman_compress_mt(data, threads):
+    return _call(lib().rsn_baseline_huffman_compress_mt, data, int(threads))
+
+
+def huffman_decompress_mt(data, threads):
+    return _call(lib().rsn_baseline_huffman_decompress_mt, data, int(threads))
+
+
+def lzss_compress_mt(data, window=4096, threads=1, grain=4096):
+    """grain = positions per task; 1 = one task per position, the reference's goroutine-per-byte shape (lzss.go:117-130)."""
+    return _call(lib().rsn_baseline_lzss_compress_mt, data, window, int(threads), int(grain))
 
 
 def lzss_matches(escaped, window=4096):

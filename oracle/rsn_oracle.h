@@ -80,6 +80,13 @@ int rsn_oracle_lzss_unescape(const uint8_t *in, size_t n, uint8_t **out, size_t 
  * means literal; otherwise (off[i], size[i]).  Arrays hold e entries. */
 int rsn_oracle_lzss_matches(const uint8_t *esc, size_t e, int64_t window, uint32_t *off, uint32_t *size);
 
+/* ---- oracle/cpu_baseline.c: the same functions on `threads` host cores (bench.py's cpu_baseline).
+ * Same bytes out as the single-threaded forms above (tests/test_oracle.py). */
+int rsn_baseline_huffman_compress_mt(const uint8_t *in, size_t n, int threads, uint8_t **out, size_t *out_n);
+int rsn_baseline_huffman_decompress_mt(const uint8_t *in, size_t n, int threads, uint8_t **out, size_t *out_n);
+/* grain = positions per task (1 = one task per position, lzss.go:117-130) */
+int rsn_baseline_lzss_compress_mt(const uint8_t *in, size_t n, int64_t window, int threads, size_t grain, uint8_t **out, size_t *out_n);
+
 void rsn_oracle_free(void *p);
 const char *rsn_oracle_last_error(void);
 

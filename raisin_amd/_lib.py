@@ -27,7 +27,7 @@ _lib = None
 
 SYMBOLS = [
     "rsn_device_set", "rsn_device_count", "rsn_last_error", "rsn_version", "rsn_free", "rsn_trim",
-    "rsn_huffman_compress", "rsn_huffman_decompress", "rsn_lzss_compress", "rsn_lzss_decompress",
+    "rsn_huffman_compress", "rsn_huffman_decompress", "rsn_lzss_compress", "rsn_lzss_decompress", "rsn_lzss_compress_legacy",
     "rsn_huffman_compress_batch",
     "rsn_huffman_compress_bound", "rsn_lzss_compress_bound",
     "rsn_huffman_compress_dev", "rsn_huffman_decompress_dev", "rsn_lzss_compress_dev", "rsn_lzss_decompress_dev",
@@ -67,6 +67,7 @@ def lib():
     for name in ("rsn_huffman_compress", "rsn_huffman_decompress", "rsn_lzss_decompress"):
         getattr(L, name).argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(u8p), szp]
     L.rsn_lzss_compress.argtypes = [ctypes.c_char_p, sz, ctypes.c_int64, ctypes.POINTER(u8p), szp]
+    L.rsn_lzss_compress_legacy.argtypes = [ctypes.c_char_p, sz, ctypes.c_int64, ctypes.POINTER(u8p), szp]
     L.rsn_huffman_compress_bound.argtypes = [sz]
     L.rsn_huffman_compress_bound.restype = sz
     L.rsn_lzss_compress_bound.argtypes = [sz]

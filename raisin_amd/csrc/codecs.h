@@ -2,6 +2,7 @@
 #pragma once
 
 #include "huff_host.h"
+#include "lzss_legacy.h"
 #include "rsn_common.h"
 
 namespace rsn {

@@ -330,6 +330,19 @@ int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out
                      });
 }
 
+int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+    Ctx &c = ctx();
+    if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
+    *out = nullptr; *out_n = 0;
+    std::string res;
+    lzss_compress_legacy_host(in, n, window, res);
+    uint8_t *buf = (uint8_t *)result_alloc(res.size());
+    if (!buf) return c.fail(RSN_ERR_NOMEM, "allocating %zu result bytes failed", res.size());
+    memcpy(buf, res.data(), res.size());
+    *out = buf; *out_n = res.size();
+    return RSN_OK;
+}
+
 int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     return host_call(in, n, out, out_n, 8 * n + (1 << 16),
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {

@@ -12,6 +12,12 @@ def CompressAsync(fileContents, useProgressBar=False, maxSearchBufferLength=Defa
     return _lib.call_host(_lib.lib().rsn_lzss_compress, fileContents, int(maxSearchBufferLength))
 
 
+def Compress(fileContents, useProgressBar=False, maxSearchBufferLength=DefaultWindowSize):
+    """lzss.go:224 Compress([]byte, bool, int) []byte -- the older synchronous encoder (not the .rsn
+    path; host-side, quirks included: see include/rsn.h)."""
+    return _lib.call_host(_lib.lib().rsn_lzss_compress_legacy, fileContents, int(maxSearchBufferLength))
+
+
 def Decompress(fileContents, useProgressBar=False):
     """lzss.go:323 Decompress([]byte, bool) []byte"""
     return _lib.call_host(_lib.lib().rsn_lzss_decompress, fileContents)

@@ -125,3 +125,21 @@ def test_engine_mirror_host_side(built):
     with pytest.raises(ValueError):
         lz.NewWriterLevel(None, -1)                                                     # lzss.go:43-45
     assert lz.DefaultWindowSize == 4096
+
+
+def test_legacy_lz_compress_host_only(built, oracle, samiam, known):
+    """(f)#4: lz.Compress (lzss.go:224) lives in librsn as host code of its own -- README's 21-byte answer
+    (README.md:165), the ai/data.json sizes, and the oracle's independent restatement; needs no device."""
+    from raisin_amd import lz
+    ref = known["reference"]
+    assert lz.Compress(b"abc" * 8 + b"\n") == b"abcabca<6,6>b<12,10>\n"
+    assert len(lz.Compress(b"abc" * 8 + b"\n")) == ref["lzss_legacy_abc_size"]
+    assert len(lz.Compress(b"a" * 100000)) == ref["lzss_legacy_aaa_100000_size"]
+    assert len(lz.Compress((b"abcdefghijklmnopqrstuvwxyz" * 3847)[:100000])) == ref["lzss_legacy_alphabet_100000_size"]
+    assert lz.Compress(b"a") == b"a" and lz.Compress(b"") == b""
+    rng = np.random.default_rng(3)
+    cases = [samiam, samiam * 3, b"Hello world!\n", bytes(rng.integers(0, 256, 9000, dtype=np.uint8)),
+             bytes(rng.integers(60, 64, 9000, dtype=np.uint8)), b"<\\\xff" * 700, b"ab" * 5000]
+    for d in cases:
+        for w in (4096, 8192, 100, 0):
+            assert lz.Compress(d, False, w) == oracle.lzss_compress_legacy(d, w)

