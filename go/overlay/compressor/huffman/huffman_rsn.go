@@ -1,9 +1,14 @@
 //go:build rsn
 
-// Overlay for go-compression/raisin compressor/huffman: Compress/Decompress backed by
-// librsn (include/rsn.h).  Drop next to huffman.go and give the pure-Go Compress/Decompress
-// the tag `//go:build !rsn`.  Written without a Go toolchain (none exists in the build
-// image): see INTEGRATION.md.
+// Overlay for go-compression/raisin compressor/huffman: Compress/Decompress backed by librsn
+// (include/rsn.h).  Build tags select whole FILES, and huffman.go also defines Writer, Reader,
+// NewWriter, NewReader and the helpers the engine type-asserts (engine.go:69,121) -- so huffman.go
+// itself must stay untagged.  Integration is therefore two steps (INTEGRATION.md):
+//   1. move the bodies of Compress (huffman.go:299-325) and Decompress (:327-330) -- and nothing
+//      else -- out of huffman.go into a new huffman_purego.go that starts with `//go:build !rsn`;
+//   2. drop this file next to it.
+// Written without a Go toolchain (none exists in the build image); tests/abi_shim_test.c replays
+// this file's exact call sequence against librsn in C.
 package huffman
 
 /*
@@ -24,7 +29,7 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 	defer runtime.UnlockOSThread()
 	var p *C.uint8_t
 	if len(in) > 0 {
-		p = (*C.uint8_t)(unsafe.Pointer(&in[0]))
+		p = (*C.uint8_t)(unsafe.Pointer(&in[0])) // borrowed for the call only; cgo pins it
 	}
 	var out *C.uint8_t
 	var n C.size_t
@@ -32,7 +37,13 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 		panic("librsn: " + C.GoString(C.rsn_last_error())) // the reference panics via check(e)
 	}
 	defer C.rsn_free(unsafe.Pointer(out))
-	return C.GoBytes(unsafe.Pointer(out), C.int(n))
+	// Not C.GoBytes: its length is a C.int, and results reach 2 GiB and more (librsn takes 5 GiB
+	// Huffman calls).  unsafe.Slice takes an int (64-bit here); Go >= 1.17.
+	res := make([]byte, int(n))
+	if n > 0 {
+		copy(res, unsafe.Slice((*byte)(unsafe.Pointer(out)), int(n)))
+	}
+	return res
 }
 
 // Compress replaces huffman.go:299.

@@ -1,8 +1,15 @@
 //go:build rsn
 
-// Overlay for go-compression/raisin compressor/lz: CompressAsync/Decompress backed by librsn
-// (include/rsn.h).  Drop next to lzss.go and give the pure-Go CompressAsync/Decompress the
-// tag `//go:build !rsn`.  Written without a Go toolchain: see INTEGRATION.md.
+// Overlay for go-compression/raisin compressor/lz: CompressAsync / Compress / Decompress backed by
+// librsn (include/rsn.h).  lzss.go also defines Writer, Reader, NewWriter, NewWriterLevel,
+// NewReader, EncodeOpeningSymbols, ... and must stay untagged; integration is two steps
+// (INTEGRATION.md):
+//   1. move the bodies of CompressAsync (lzss.go:109-154, with its workers :156-184), Compress
+//      (:224-316) and Decompress (:323-364) out of lzss.go into a new lzss_purego.go that starts
+//      with `//go:build !rsn`;
+//   2. drop this file next to it.
+// Go packages cannot share unexported helpers, so rsnCall is repeated from the huffman overlay.
+// Written without a Go toolchain; tests/abi_shim_test.c replays this call sequence in C.
 package lz
 
 /*
@@ -31,7 +38,11 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 		panic("librsn: " + C.GoString(C.rsn_last_error()))
 	}
 	defer C.rsn_free(unsafe.Pointer(out))
-	return C.GoBytes(unsafe.Pointer(out), C.int(n))
+	res := make([]byte, int(n)) // not C.GoBytes: C.int truncates results of 2 GiB and more
+	if n > 0 {
+		copy(res, unsafe.Slice((*byte)(unsafe.Pointer(out)), int(n)))
+	}
+	return res
 }
 
 // CompressAsync replaces lzss.go:109 (the engine path, Writer.Write lzss.go:53-57).
@@ -39,6 +50,13 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 func CompressAsync(fileContents []byte, useProgressBar bool, maxSearchBufferLength int) []byte {
 	return rsnCall(fileContents, func(p *C.uint8_t, n C.size_t, o **C.uint8_t, on *C.size_t) C.int {
 		return C.rsn_lzss_compress(p, n, C.int64_t(maxSearchBufferLength), o, on)
+	})
+}
+
+// Compress replaces lzss.go:224, the older synchronous encoder (host code in librsn, quirks kept).
+func Compress(fileContents []byte, useProgressBar bool, maxSearchBufferLength int) []byte {
+	return rsnCall(fileContents, func(p *C.uint8_t, n C.size_t, o **C.uint8_t, on *C.size_t) C.int {
+		return C.rsn_lzss_compress_legacy(p, n, C.int64_t(maxSearchBufferLength), o, on)
 	})
 }
 

@@ -88,8 +88,12 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
 size_t rsn_huffman_compress_bound(size_t n);
 size_t rsn_lzss_compress_bound(size_t n);
 int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
-/* Output size is only known after the header is parsed: call with d_out=NULL
- * to get the exact size in *out_n, or pass a buffer with out_cap >= that.   */
+/* The decoded size is only known after the header is parsed.  When the buffer is too small -- or
+ * d_out is NULL / out_cap 0, the size query -- the call returns RSN_ERR_CAPACITY, sets the error
+ * string, and stores in *out_n a capacity that WOULD suffice (the exact size rounded up to 16, plus
+ * 16: not the exact size); call again with a buffer of at least that many bytes, the second call
+ * returns RSN_OK and the exact size.  rsn_lzss_decompress_dev and the two compress_dev calls follow
+ * the same contract.                                                                            */
 int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
 int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream);
 int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);

@@ -288,8 +288,9 @@ static leaf_t *parse_header(const uint8_t *h, size_t hn, uint32_t *a_out) {
         uint8_t c = h[i];
         if (c != '|') {
             if (c >= '0' && c <= '9') { /* strconv.Atoi(string(tree[i])) succeeds only for a digit (:203) */
-                if (digits >= 18) { free(freq); free(present); rsn_oracle_set_error("huffman: frequency exceeds 18 digits (oracle limit)"); return NULL; }
-                acc = acc * 10 + (c - '0'); digits++;
+                /* Atoi of the collected digits: leading zeros are fine, a value past 2^63-1 comes back as MaxInt64 (ErrRange dropped, :207) */
+                const uint64_t kmax = 0x7FFFFFFFFFFFFFFFull, dg = (uint64_t)(c - '0');
+                acc = (acc > (kmax - dg) / 10) ? kmax : acc * 10 + dg; digits++;
             }
         } else {
             uint64_t f = acc; /* Atoi("") -> 0, error ignored (:207) */

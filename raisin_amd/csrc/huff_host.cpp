@@ -239,8 +239,11 @@ bool parse_header(const uint8_t *h, size_t n, std::vector<HuffSym> &syms, std::s
         const uint8_t ch = h[i];
         if (ch != '|') {
             if (ch >= '0' && ch <= '9') {             // only single digits pass strconv.Atoi (huffman.go:203)
-                if (++digits > 18) { msg = "huffman: frequency has more than 18 digits"; return false; }
-                acc = acc * 10 + (ch - '0');
+                // strconv.Atoi of the digit string: any number of leading zeros, values up to 2^63-1 (19 digits); beyond
+                // that Atoi returns MaxInt64 with an ErrRange the reference drops (huffman.go:207)
+                const uint64_t kMax = 0x7FFFFFFFFFFFFFFFull, d = (uint64_t)(ch - '0');
+                acc = (acc > (kMax - d) / 10) ? kMax : acc * 10 + d;
+                (void)digits;
             }
             continue;
         }

@@ -7,7 +7,9 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 namespace rsn {
 
@@ -57,6 +59,7 @@ int ctx_init(Ctx &c) {
             for (size_t i = g_parked->size(); i-- > 0;)
                 if ((*g_parked)[i].device == c.device) {                  // adopt what an earlier thread left behind (most recent first: its buffers are the warm ones)
                     Parked &pk = (*g_parked)[i];
+                    if (c.pinned) (void)hipHostFree(c.pinned);              // a context that switched devices kept its staging: do not leak it
                     c.own_stream = pk.stream; c.pinned = pk.pinned; c.pinned_cap = pk.pinned_cap;
                     for (int k = 0; k < Ctx::N_BUFS; k++) c.bufs[k] = pk.bufs[k];
                     c.free_events = std::move(pk.events);
@@ -350,13 +353,47 @@ int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
                      });
 }
 
+// Independent chunks, one complete .rsn segment each (engine.CompressFiles: one file per input,
+// engine.go:150-154).  A single host call is PCIe-bound -- ~19 ms per GiB each way against < 1 ms
+// of kernels -- and PCIe is full duplex, so the batch runs two lanes, each a host thread with its
+// own context (stream, scratch, staging): while one lane copies chunk k's result down, the other
+// copies chunk k+1 up and runs its kernels.  RSN_BATCH_LANES=1 gives the serial loop (A/B).
 int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
     Ctx &c = ctx();
     if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
     for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
-    for (size_t i = 0; i < n_chunks; i++) {
-        int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
-        if (rc) { for (size_t k = 0; k < i; k++) { rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; } return rc; }
+    int rc0 = ctx_init(c); if (rc0) return rc0;
+    static const int lanes_env = getenv("RSN_BATCH_LANES") ? atoi(getenv("RSN_BATCH_LANES")) : 2;
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)(lanes_env > 0 ? lanes_env : 2), n_chunks));
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{RSN_OK};
+    std::mutex err_mu; std::string err_msg;
+    const int device = c.device;
+    auto lane = [&](bool own_thread) {
+        if (own_thread && rsn_device_set(device) != RSN_OK) {
+            int exp = RSN_OK;
+            if (first_rc.compare_exchange_strong(exp, RSN_ERR_DEVICE)) { std::lock_guard<std::mutex> lk(err_mu); err_msg = rsn_last_error(); }
+            return;
+        }
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_chunks || first_rc.load() != RSN_OK) break;
+            const int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
+            if (rc != RSN_OK) {
+                int exp = RSN_OK;
+                if (first_rc.compare_exchange_strong(exp, rc)) { std::lock_guard<std::mutex> lk(err_mu); err_msg = rsn_last_error(); }
+                break;
+            }
+        }
+    };
+    std::vector<std::thread> helpers;
+    for (size_t l = 1; l < lanes; l++) helpers.emplace_back(lane, true);
+    lane(false);                                                     // the caller is lane 0
+    for (auto &t : helpers) t.join();
+    const int rc = first_rc.load();
+    if (rc != RSN_OK) {
+        for (size_t k = 0; k < n_chunks; k++) { if (outs[k]) rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; }
+        return c.fail(rc, "%s", err_msg.c_str());
     }
     return RSN_OK;
 }

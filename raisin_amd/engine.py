@@ -96,7 +96,8 @@ def DecompressFile(algorithms, path, output):
     data = open(path, "rb").read()
     print("Decompressing...")
     out = decompress(data, algorithms)
-    open(output, "wb").write(out)
+    with open(output, "wb") as fh:                                 # check(err) after WriteFile (engine.go:196-197): raises before any caller deletes the input
+        fh.write(out)
     return out
 
 
@@ -175,19 +176,51 @@ def _suite_order(results):
     return sorted(results, key=lambda r: (not r.Lossless, r.Ratio))
 
 
-def BenchmarkSuite(files, algorithms, out=None):
-    """engine.go:213-309 without the HTML report: per file one table -- header, finished rows in the
-    reference's order, failed rows as DNF, the File/Size footer -- and the flat list of results."""
+BenchmarkTimeout = 60.0   # engine.go:216 `timeout := 1 * time.Minute`
+
+
+def _go_duration(seconds):
+    """time.Duration.String() for the timeout row (engine.go:258: ">1m0s")."""
+    if seconds >= 60:
+        m, sec = divmod(seconds, 60)
+        return "%dm%gs" % (m, sec)
+    return "%gs" % seconds if seconds >= 1 else "%gms" % (seconds * 1e3)
+
+
+def BenchmarkSuite(files, algorithms, out=None, timeout=None):
+    """engine.go:213-309 without the HTML report.  As in the reference, every algorithm entry of a
+    file runs CONCURRENTLY on its own thread (one goroutine each, :235-244; librsn keeps one device
+    context per calling thread), the suite waits at most `timeout` (1 minute, :216,246, util.go:15)
+    and every entry that has not delivered by then gets a ">1m0s" DNF row (:256-263) while its
+    thread is left running.  Per file one table: header, finished rows in the reference's order,
+    failed rows as DNF, the File/Size footer.  Returns the flat list of results."""
     import sys
+    import threading
     out = out or sys.stdout
+    timeout = BenchmarkTimeout if timeout is None else timeout
     all_results = []
     for i, f in enumerate(files):
         print("Compressing file %d/%d - %s" % (i + 1, len(files), f), file=out)
-        done, failed = [], []
+        file_size = os.path.getsize(f)                          # ioutil.ReadFile + check(err) before anything starts (:223-225)
+        slots, threads = {}, []
         for layer in algorithms:
-            print("Benchmarking", ",".join(layer), file=out)
-            r = AsyncBenchmarkFile(layer, f)
-            (failed if r.Failed else done).append(r)
+            name = ",".join(layer)
+            print("Benchmarking", name, file=out)
+            box = []
+            slots[name] = box                                   # resultChans[algorithmsString] (:240): a repeated entry shares its slot
+            t = threading.Thread(target=lambda layer=layer, box=box: box.append(AsyncBenchmarkFile(layer, f)), daemon=True)
+            t.start()
+            threads.append(t)
+        deadline = time.monotonic() + timeout                   # waitTimeout(&wg, timeout)
+        for t in threads:
+            t.join(max(0.0, deadline - time.monotonic()))
+        done, failed = [], []
+        for name, box in slots.items():
+            if box:
+                r = box[0]
+                (failed if r.Failed else done).append(r)
+            else:                                               # select default: nothing delivered in time
+                failed.append(Result(name, ">" + _go_duration(timeout), 0.0, 0.0, 0.0, False, True))
         rows = [("engine", "time taken", "compression ratio", "actual entropy", "theoretical entropy", "lossless")]
         for r in _suite_order(done):
             rows.append((r.CompressionEngine, r.TimeTaken, "%.2f%%" % r.Ratio, "%.2f" % r.ActualEntropy, "%.2f" % r.Entropy, str(r.Lossless).lower()))
@@ -195,7 +228,7 @@ def BenchmarkSuite(files, algorithms, out=None):
         for r in failed:
             rows.append((r.CompressionEngine, r.TimeTaken, "DNF", "DNF", "DNF", str(r.Lossless).lower()))
             all_results.append(r)
-        rows.append(("File", f, "Size", ByteCountSI(os.path.getsize(f)), "", ""))
+        rows.append(("File", f, "Size", ByteCountSI(file_size), "", ""))
         width = [max(len(row[c]) for row in rows) for c in range(6)]
         for row in rows:
             print(" | ".join(cell.ljust(w) for cell, w in zip(row, width)).rstrip(), file=out)

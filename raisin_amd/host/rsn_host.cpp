@@ -7,11 +7,17 @@
 //   rsn -compress   <file[,file..]> [-algorithm=lzss,huffman] [-out=F | -outext=rsn] [-delete]
 //   rsn -decompress <file[,file..]> [-algorithm=lzss,huffman] [-out=F | -outext=E]   [-delete=false]
 //   rsn -benchmark  <file[,file..]> [-algorithm=lzss,huffman,[lzss,huffman]]
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <fstream>
 #include <functional>
 #include <map>
@@ -28,9 +34,25 @@ static Bytes read_file(const std::string &p) {
     if (!f) throw std::runtime_error("Could not open file (likely does not exist): " + p);   // cli.go:95
     return Bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
+// ioutil.WriteFile + check(err) (engine.go:194-197): a failed open, write or close is an error BEFORE
+// any input is deleted (the reference panics in DecompressFile ahead of deleteFiles, cli.go:165-167)
 static void write_file(const std::string &p, const Bytes &b) {
-    std::ofstream f(p, std::ios::binary);
+    if (p.empty()) throw std::runtime_error("refusing to write to an empty output path");
+    std::ofstream f(p, std::ios::binary | std::ios::trunc);
+    if (!f) throw std::runtime_error("could not open output file: " + p);
     f.write((const char *)b.data(), (std::streamsize)b.size());
+    f.flush();
+    if (!f) throw std::runtime_error("could not write output file: " + p);
+    f.close();
+    if (f.fail()) throw std::runtime_error("could not close output file: " + p);
+}
+// strings.TrimSuffix(f, filepath.Ext(f)) (cli.go:141-143, engine.go:177-180): the extension is the suffix from the
+// final dot of the LAST path element; no dot there -> nothing is trimmed
+static std::string trim_ext(const std::string &f) {
+    const size_t slash = f.find_last_of('/');
+    const size_t dot = f.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return f;
+    return f.substr(0, dot);
 }
 
 // check(e) -> panic in the reference; an exception here (caught per row in -benchmark, engine.go:315-328)
@@ -101,6 +123,15 @@ static std::string ByteCountSI(long long b) {
     return buf;
 }
 
+// time.Duration.String() for the timeout row (engine.go:258: ">1m0s")
+static std::string go_duration(long long ms) {
+    char buf[48];
+    if (ms >= 60000) snprintf(buf, sizeof buf, "%lldm%gs", ms / 60000, (double)(ms % 60000) / 1e3);
+    else if (ms >= 1000) snprintf(buf, sizeof buf, "%gs", (double)ms / 1e3);
+    else snprintf(buf, sizeof buf, "%lldms", ms);
+    return buf;
+}
+
 static std::vector<std::string> split(const std::string &s, char sep) {
     std::vector<std::string> out; std::string cur;
     for (char ch : s) { if (ch == sep) { out.push_back(cur); cur.clear(); } else if (ch != ' ') cur += ch; }
@@ -122,6 +153,8 @@ static std::vector<std::vector<std::string>> parseAlgorithms(const std::string &
 
 int main(int argc, char **argv) {
     std::string app = argv[0], cmd, file, algorithm, out, outext; bool has_delete = false, del = false;
+    long long timeout_ms = 60000;                                   // engine.go:216; RSN_BENCH_TIMEOUT_MS shortens it for tests
+    if (const char *t = getenv("RSN_BENCH_TIMEOUT_MS")) timeout_ms = atoll(t);
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const char *k) -> const char * { const size_t n = strlen(k); if (a.compare(0, n, k) == 0 && a.size() > n && a[n] == '=') return argv[i] + n + 1; return nullptr; };
@@ -156,13 +189,14 @@ int main(int argc, char **argv) {
             if (algorithm.empty()) algorithm = "lzss,huffman";
             const auto algs = split(algorithm, ',');
             for (auto &f : files) {
-                std::string o = f.substr(0, f.find_last_of('.'));                                   // cli.go:141-143
+                std::string o = trim_ext(f);                                                        // cli.go:141-143
                 if (files.size() == 1 && !out.empty()) o = out;
                 if (files.size() > 1 && !outext.empty()) o = f + "." + outext;
+                if (o.empty() || o == f) throw std::runtime_error("output path '" + o + "' is empty or is the input itself (" + f + "): give -out / -outext");
                 printf("Decompressing...\n");
                 write_file(o, engine::decompress(read_file(f), algs));
             }
-            if (!has_delete || del) for (auto &f : files) remove(f.c_str());                       // -delete defaults to true (cli.go:150)
+            if (!has_delete || del) for (auto &f : files) remove(f.c_str());                       // -delete defaults to true (cli.go:150); only reached when every output was written
         } else {
             if (algorithm.empty()) algorithm = "lzss,huffman,[lzss,huffman]";
             // engine.go:213-309 (BenchmarkSuite) without the HTML report
@@ -170,13 +204,37 @@ int main(int argc, char **argv) {
                 const std::string &f = files[fi];
                 printf("Compressing file %zu/%zu - %s\n", fi + 1, files.size(), f.c_str());
                 std::vector<engine::Result> done, failed;
-                for (auto &algs : parseAlgorithms(algorithm)) {
+                // engine.go:235-263: one thread per algorithm entry (goroutine), wait at most one minute, an entry that has
+                // not delivered by then is a ">1m0s" DNF row and its thread is left running (detached)
+                struct Slot { std::string name; bool ready = false; engine::Result r; };
+                struct Shared { std::mutex mu; std::condition_variable cv; std::vector<Slot> slots; size_t pending = 0; };
+                auto sh = std::make_shared<Shared>();
+                const auto entries = parseAlgorithms(algorithm);
+                read_file(f);                                                                       // ReadFile + check(err) before anything starts
+                for (auto &algs : entries) {
                     std::string n; for (auto &a : algs) n += (n.empty() ? "" : ",") + a;
                     printf("Benchmarking %s\n", n.c_str());
-                    engine::Result r;
-                    try { r = engine::BenchmarkFile(algs, f); }
-                    catch (const std::exception &e) { r = {n, "failed", 0, 0, 0, false, true}; }   // recover(), engine.go:315-328
-                    (r.failed ? failed : done).push_back(r);
+                    size_t slot = sh->slots.size();
+                    for (size_t k = 0; k < sh->slots.size(); k++) if (sh->slots[k].name == n) slot = k;   // resultChans is keyed by name (:240)
+                    if (slot == sh->slots.size()) { sh->slots.emplace_back(); sh->slots.back().name = n; }
+                    sh->pending++;
+                    std::thread([sh, slot, algs, f, n]() {
+                        engine::Result r;
+                        try { r = engine::BenchmarkFile(algs, f); }
+                        catch (const std::exception &e) { r = {n, "failed", 0, 0, 0, false, true}; }   // recover(), engine.go:315-328
+                        std::lock_guard<std::mutex> lk(sh->mu);
+                        if (!sh->slots[slot].ready) { sh->slots[slot].r = r; sh->slots[slot].ready = true; }
+                        sh->pending--;
+                        sh->cv.notify_all();
+                    }).detach();
+                }
+                {
+                    std::unique_lock<std::mutex> lk(sh->mu);
+                    sh->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return sh->pending == 0; });   // waitTimeout
+                    for (auto &sl : sh->slots) {
+                        if (sl.ready) (sl.r.failed ? failed : done).push_back(sl.r);
+                        else failed.push_back({sl.name, ">" + go_duration(timeout_ms), 0, 0, 0, false, true});
+                    }
                 }
                 std::stable_sort(done.begin(), done.end(), [](const engine::Result &a, const engine::Result &b) {   // engine.go:266-276
                     if (a.lossless != b.lossless) return a.lossless;
@@ -193,7 +251,9 @@ int main(int argc, char **argv) {
         }
     } catch (const std::exception &e) {
         fprintf(stderr, "panic: %s\n", e.what());
-        return 2;
+        fflush(stdout); fflush(stderr);
+        _exit(2);                        // benchmark threads that missed the deadline may still be running (the reference's goroutines die with main too)
     }
-    return 0;
+    fflush(stdout); fflush(stderr);
+    _exit(0);
 }

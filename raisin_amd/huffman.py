@@ -128,7 +128,8 @@ def compress_bound(n):
 
 
 def compress_tensor(src, out=None, stream=None):
-    """src: uint8 CUDA tensor.  Returns a uint8 view of `out` holding the .rsn bytes."""
+    """src: uint8 CUDA tensor.  Returns a uint8 tensor holding the .rsn bytes: a view of `out` when it was large
+    enough, otherwise (RSN_ERR_CAPACITY) a view of a fresh tensor of the capacity the library asked for."""
     import torch
     n = src.numel()
     if out is None:

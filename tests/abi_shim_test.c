@@ -1,0 +1,122 @@
+/*
+ * abi_shim_test.c -- the cgo overlay's call sequence (go/overlay/compressor/{huffman,lz}/*_rsn.go), replayed in C.
+ * The overlay cannot be compiled here (no Go toolchain), so the contract it relies on is compiled and run in this
+ * file instead, against the same header and library a cgo build would bind:
+ *   rsnCall:  input BORROWED for the call (never modified, may be freed right after), output owned by the library,
+ *             COPIED by the caller, then released with rsn_free(); a non-zero return code and rsn_last_error()
+ *             (thread-local) carry what the Go side turns into panic();
+ *   engine:   eight goroutines = eight OS threads calling concurrently (engine.go:235-244), each through its own
+ *             per-thread context, with results that must not depend on the interleaving.
+ * Exit code 0 = every check passed.  `abi_shim_test nodev` runs only the part that needs no device (symbols link,
+ * the host-only entry points work, device entry points fail cleanly with RSN_ERR_DEVICE).
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rsn.h"
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s (last error: %s)\n", __FILE__, __LINE__, #c, rsn_last_error()); exit(1); } } while (0)
+
+typedef int (*codec_fn)(const uint8_t *, size_t, uint8_t **, size_t *);
+static int lz_c(const uint8_t *p, size_t n, uint8_t **o, size_t *on) { return rsn_lzss_compress(p, n, RSN_LZSS_DEFAULT_WINDOW, o, on); }
+static int lz_legacy(const uint8_t *p, size_t n, uint8_t **o, size_t *on) { return rsn_lzss_compress_legacy(p, n, RSN_LZSS_DEFAULT_WINDOW, o, on); }
+
+/* rsnCall of the overlay: returns a malloc'ed COPY (the Go slice), or NULL with *rc set (the panic) */
+static uint8_t *rsn_call(codec_fn f, const uint8_t *in, size_t n, size_t *out_n, int *rc) {
+    uint8_t *borrowed = malloc(n ? n : 1);                  /* the pinned Go slice */
+    memcpy(borrowed, in, n);
+    uint8_t *out = NULL; size_t on = 0;
+    *rc = f(n ? borrowed : NULL, n, &out, &on);
+    if (*rc == 0) CHECK(memcmp(borrowed, in, n) == 0);      /* input never modified */
+    memset(borrowed, 0xA5, n); free(borrowed);              /* the borrow ends with the call */
+    if (*rc != 0) { CHECK(out == NULL && on == 0); return NULL; }
+    uint8_t *copy = malloc(on ? on : 1);
+    memcpy(copy, out, on);                                  /* copy(res, unsafe.Slice(out, n)) */
+    rsn_free(out);                                          /* defer C.rsn_free(out) */
+    *out_n = on;
+    return copy;
+}
+
+static uint8_t *make_text(size_t n, unsigned seed) {
+    static const char *w[] = {"the", "quick", "brown", "fox", "jumps", "over", "lazy", "dog", "raisin", "huffman", "lzss", "window"};
+    uint8_t *b = malloc(n + 16); size_t k = 0;
+    while (k < n) { seed = seed * 1103515245u + 12345u; const char *s = w[(seed >> 16) % 12]; size_t l = strlen(s); memcpy(b + k, s, l); k += l; b[k++] = ' '; }
+    return b;
+}
+
+typedef struct { int id; int rounds; int ok; } job_t;
+static void *worker(void *p) {                               /* one goroutine of engine.BenchmarkSuite: compress, decompress, compare */
+    job_t *j = p;
+    const size_t n = 200000 + 1000 * (size_t)j->id;
+    uint8_t *src = make_text(n, 17u * (unsigned)j->id + 1);
+    for (int r = 0; r < j->rounds; r++) {
+        int rc; size_t cn, dn, c2n, d2n;
+        uint8_t *c = rsn_call(j->id & 1 ? lz_c : rsn_huffman_compress, src, n, &cn, &rc); CHECK(rc == 0);
+        uint8_t *d = rsn_call(j->id & 1 ? rsn_lzss_decompress : rsn_huffman_decompress, c, cn, &dn, &rc); CHECK(rc == 0);
+        CHECK(dn == n && memcmp(d, src, n) == 0);
+        /* layered, as `-algorithm=lzss,huffman` (engine.go:443-479) */
+        uint8_t *l1 = rsn_call(lz_c, src, n, &cn, &rc); CHECK(rc == 0);
+        uint8_t *l2 = rsn_call(rsn_huffman_compress, l1, cn, &c2n, &rc); CHECK(rc == 0);
+        uint8_t *b1 = rsn_call(rsn_huffman_decompress, l2, c2n, &d2n, &rc); CHECK(rc == 0 && d2n == cn && memcmp(b1, l1, cn) == 0);
+        uint8_t *b0 = rsn_call(rsn_lzss_decompress, b1, d2n, &dn, &rc); CHECK(rc == 0 && dn == n && memcmp(b0, src, n) == 0);
+        /* a failing call on THIS thread: its message is this thread's own */
+        size_t xn; uint8_t *x = rsn_call(rsn_huffman_decompress, (const uint8_t *)"no separator here", 17, &xn, &rc);
+        CHECK(x == NULL && rc == RSN_ERR_FORMAT && strlen(rsn_last_error()) > 0);
+        free(c); free(d); free(l1); free(l2); free(b1); free(b0);
+    }
+    free(src);
+    j->ok = 1;
+    return NULL;
+}
+
+int main(int argc, char **argv) {
+    const int nodev = argc > 1 && strcmp(argv[1], "nodev") == 0;
+    int rc; size_t n;
+    CHECK(strlen(rsn_version()) > 0);
+    /* host-only entry point: README.md:165's 21-byte answer of the legacy encoder, no device needed */
+    uint8_t *g = rsn_call(lz_legacy, (const uint8_t *)"abcabcabcabcabcabcabcabc\n", 25, &n, &rc);
+    CHECK(rc == 0 && n == 21 && memcmp(g, "abcabca<6,6>b<12,10>\n", 21) == 0);
+    free(g);
+    if (nodev) {
+        if (rsn_device_count() <= 0) {                       /* no GPU: every codec call fails loudly, none computes on the CPU */
+            uint8_t *x = rsn_call(rsn_huffman_compress, (const uint8_t *)"abc", 3, &n, &rc);
+            CHECK(x == NULL && rc == RSN_ERR_DEVICE && strstr(rsn_last_error(), "no CPU fallback"));
+            x = rsn_call(lz_c, (const uint8_t *)"abc", 3, &n, &rc);
+            CHECK(x == NULL && rc == RSN_ERR_DEVICE);
+        }
+        printf("abi shim (no device): ok\n");
+        return 0;
+    }
+    /* known answers through the shim sequence */
+    uint8_t *c = rsn_call(rsn_huffman_compress, (const uint8_t *)"ab", 2, &n, &rc);
+    CHECK(rc == 0 && n == 10 && memcmp(c, "1|a1|b\\\n\x06\x01", 10) == 0); free(c);
+    c = rsn_call(lz_c, (const uint8_t *)"abcabcabcabcabcabcabcabc\n", 25, &n, &rc);
+    CHECK(rc == 0 && n == 19 && memcmp(c, "abcabc<6,6><12,12>\n", 19) == 0); free(c);
+    c = rsn_call(lz_c, NULL, 0, &n, &rc); CHECK(rc == 0 && n == 0); free(c);          /* CompressAsync(empty) == empty */
+    c = rsn_call(rsn_huffman_compress, NULL, 0, &n, &rc);                              /* reference panics in heap.Pop (huffman.go:102) */
+    CHECK(c == NULL && rc == RSN_ERR_EMPTY && strstr(rsn_last_error(), "empty"));
+    c = rsn_call(rsn_lzss_decompress, (const uint8_t *)"ab<9,2>", 7, &n, &rc);        /* pointer past the decoded data */
+    CHECK(c == NULL && rc == RSN_ERR_FORMAT);
+    /* rsn_last_error() is per thread and survives until the next call on this thread */
+    CHECK(strlen(rsn_last_error()) > 0);
+    /* eight concurrent callers */
+    enum { T = 8 };
+    pthread_t th[T]; job_t jobs[T];
+    for (int i = 0; i < T; i++) { jobs[i] = (job_t){i, 3, 0}; CHECK(pthread_create(&th[i], NULL, worker, &jobs[i]) == 0); }
+    for (int i = 0; i < T; i++) { pthread_join(th[i], NULL); CHECK(jobs[i].ok); }
+    /* batch form: one .rsn segment per chunk, each identical to the single call */
+    enum { NC = 5 };
+    const uint8_t *ins[NC]; size_t lens[NC]; uint8_t *outs[NC]; size_t out_lens[NC]; uint8_t *bufs[NC];
+    for (int i = 0; i < NC; i++) { lens[i] = 300000 + 77777 * (size_t)i; bufs[i] = make_text(lens[i], 1000u + (unsigned)i); ins[i] = bufs[i]; }
+    CHECK(rsn_huffman_compress_batch(NC, ins, lens, outs, out_lens) == 0);
+    for (int i = 0; i < NC; i++) {
+        size_t sn; uint8_t *single = rsn_call(rsn_huffman_compress, bufs[i], lens[i], &sn, &rc);
+        CHECK(rc == 0 && sn == out_lens[i] && memcmp(single, outs[i], sn) == 0);
+        free(single); rsn_free(outs[i]); free(bufs[i]);
+    }
+    rsn_trim();
+    printf("abi shim: ok\n");
+    return 0;
+}

@@ -66,6 +66,62 @@ def test_benchmark_suite_table(tmp_path, samiam):
     assert "compression ratio" in text and text.count("DNF") == 3 and "File" in text and "3.5 kB" in text
 
 
+def test_benchmark_suite_runs_entries_concurrently_with_a_deadline(tmp_path, samiam):
+    """engine.go:235-263: one goroutine per algorithm entry, a one-minute deadline, ">1m0s" DNF rows for the stragglers."""
+    import io
+    import threading
+    from raisin_amd import engine
+    assert engine._go_duration(60.0) == "1m0s" and engine.BenchmarkTimeout == 60.0
+    src = tmp_path / "sam.txt"
+    src.write_bytes(samiam * 50)
+    seen = []
+    real = engine.AsyncBenchmarkFile
+
+    def spy(layer, f):
+        seen.append(threading.get_ident())
+        return real(layer, f)
+    engine.AsyncBenchmarkFile = spy
+    try:
+        algos = engine.parseAlgorithms("huffman,lzss,[lzss,huffman],[huffman,lzss]")
+        res = engine.BenchmarkSuite([str(src)], algos, out=io.StringIO())
+        assert len(set(seen)) == 4 and threading.get_ident() not in seen      # four entries, four threads, none the caller's
+        assert all(r.Lossless and not r.Failed for r in res) and len(res) == 4
+        buf = io.StringIO()
+        res = engine.BenchmarkSuite([str(src)], algos, out=buf, timeout=0.0)   # nothing can deliver in time
+        assert all(r.Failed and r.TimeTaken == ">0ms" for r in res) and buf.getvalue().count("DNF") == 12
+    finally:
+        engine.AsyncBenchmarkFile = real
+    time_left = [t for t in threading.enumerate() if t.daemon and t.is_alive()]
+    for t in time_left:
+        t.join(30)                                                           # the stragglers finish on their own
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    out = subprocess.check_output([exe, "-benchmark", str(src), "-algorithm=huffman,[lzss,huffman]"], env=dict(os.environ, RSN_BENCH_TIMEOUT_MS="0")).decode()
+    assert out.count(">0ms") == 2 and out.count("DNF") == 6
+    out = subprocess.check_output([exe, "-benchmark", str(src), "-algorithm=huffman,lzss,[lzss,huffman],[huffman,lzss]"]).decode()
+    assert out.count("true") == 4 and "DNF" not in out
+
+
+def test_cpp_host_never_deletes_an_input_it_could_not_replace(tmp_path, samiam):
+    """a failed or misdirected write must not be followed by the -delete default of -decompress (cli.go:150,165)."""
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    d = tmp_path / "out.d"
+    d.mkdir()
+    src = d / "archive"                                              # no extension in the last path element: filepath.Ext == ""
+    plain = tmp_path / "sam.txt"
+    plain.write_bytes(samiam)
+    subprocess.check_call([exe, "-compress", str(plain), "-algorithm=huffman", "-out=" + str(src)])
+    r = subprocess.run([exe, "-decompress", str(src), "-algorithm=huffman"], capture_output=True)
+    assert r.returncode != 0 and src.exists()                       # output name == input name: refused, nothing deleted
+    r = subprocess.run([exe, "-decompress", str(src), "-algorithm=huffman", "-out=" + str(tmp_path / "no_such_dir" / "x")], capture_output=True)
+    assert r.returncode != 0 and src.exists()                       # unwritable output: error before the delete
+    subprocess.check_call([exe, "-decompress", str(src), "-algorithm=huffman", "-out=" + str(tmp_path / "back.txt")])
+    assert (tmp_path / "back.txt").read_bytes() == samiam and not src.exists()
+
+
 def test_concurrent_callers_are_independent(oracle, samiam):
     """The engine runs codecs from concurrent goroutines (engine.go:235-244); librsn keeps all
     state per calling thread, so parallel host threads must not disturb each other."""
