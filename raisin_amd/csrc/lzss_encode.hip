@@ -30,6 +30,7 @@
 namespace rsn {
 
 __global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
+int lzss_encode_big(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint32_t W, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
 constexpr int LB = 256;                 // threads per block
 constexpr int ESC_TILE = LB * 16;       // input bytes per escape block
@@ -1240,17 +1241,14 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     if (E64 >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: escaped stream too large for one call");
     const uint32_t E = (uint32_t)E64;
     uint32_t W;
-    if (window <= 0) {                                                // unbounded search buffer (lzss.go:125)
-        if (E > MAX_WINDOW) return c.fail(RSN_ERR_LIMIT, "lzss: unbounded window on %u escaped bytes exceeds the %u-byte window limit", E, MAX_WINDOW);
-        W = E;
-    } else {
-        if ((uint64_t)window > MAX_WINDOW && E > MAX_WINDOW) return c.fail(RSN_ERR_LIMIT, "lzss: window %lld exceeds the %u-byte limit", (long long)window, MAX_WINDOW);
-        W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);        // a window longer than the stream never binds
-    }
+    if (window <= 0) W = E;                                           // unbounded search buffer (lzss.go:125)
+    else W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);       // a window longer than the stream never binds
     if (W == 0) W = 1;
     rc = dev_buf(c, 9, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_fc = (uint8_t *)p;
+    RSN_HIP(hipMemsetAsync(d_fc + E, 0, 64, s));                      // readable padding behind the stream
     RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+    if (W > MAX_WINDOW) return lzss_encode_big(c, s, d_fc, E, W, d_out, out_cap, out_n);   // lzss_big.hip: exact at any window, not fast
     // ---- E2 + E3.  Chain mode (default, W <= 4096): keys only where greedy chains land, everything else
     //      KEY_UNKNOWN; if the parse finds the true chain on an unknown position, those strips are
     //      searched at every position and the parse runs again (never more rounds than strips).

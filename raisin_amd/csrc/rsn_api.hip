@@ -120,7 +120,7 @@ namespace {
 // that are already mapped (the cgo shim's pattern: call, C.GoBytes, rsn_free).  A 64-byte header
 // in front of the returned pointer carries the capacity.  RSN_HOST_POOL=0 turns the pool off.
 constexpr size_t RES_HDR = 64, POOL_MIN = 1u << 20;
-constexpr size_t POOL_BLOCKS = 4;
+constexpr size_t POOL_BLOCKS = 12;      // a batch of 8 chunks holds 8 results at once
 struct ResHdr { unsigned long long magic, cap; };
 constexpr unsigned long long RES_MAGIC = 0x52534E5F52455330ull;
 std::mutex g_pool_mu;

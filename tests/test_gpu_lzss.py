@@ -69,6 +69,30 @@ def test_windows(lz, oracle, w):
     assert lz.Decompress(c) == data
 
 
+@pytest.mark.parametrize("w", [0, 8193, 16384, 100000])
+def test_windows_above_8192_and_unbounded(lz, oracle, w):
+    """L2: NewWriterLevel(w, level) takes any level >= 0 and CompressAsync treats <= 0 as "the whole prefix"
+    (lzss.go:42-51,123-127): exact at any window, through the large-window path (lzss_big.hip)."""
+    data = text(w + 5, 320000) + long_copies(w + 1, 40000)
+    c = lz.CompressAsync(data, False, w)
+    assert c == oracle.lzss_compress(data, w)
+    assert lz.Decompress(c) == data
+    if w in (0, 100000):                                      # distances and lengths beyond 16 bits
+        far = rnd(3, 70000, bytes(range(97, 123))) 
+        data = far + rnd(4, 150000, b"xyz") + far
+        c = lz.CompressAsync(data, False, w)
+        assert c == oracle.lzss_compress(data, w) and lz.Decompress(c) == data
+        assert (b"<220000,70000>" in c) == (w == 0)               # only the unbounded window reaches 220000 back
+
+
+def test_large_window_refuses_pathological_runs_cleanly(lz):
+    from raisin_amd import RsnError
+    with pytest.raises(RsnError) as e:
+        lz.CompressAsync(b"a" * 3000000, False, 0)
+    assert e.value.code == -6 and "work budget" in str(e.value)
+    assert lz.Decompress(lz.CompressAsync(b"a" * 300000)) == b"a" * 300000     # the default window has no such limit
+
+
 def test_unbounded_window_small(lz, oracle):
     data = text(3, 6000)
     assert lz.CompressAsync(data, False, 0) == oracle.lzss_compress(data, 0)   # lzss.go:125: <=0 means no limit
