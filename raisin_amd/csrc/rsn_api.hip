@@ -363,8 +363,8 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
     if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
     for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
     int rc0 = ctx_init(c); if (rc0) return rc0;
-    static const int lanes_env = getenv("RSN_BATCH_LANES") ? atoi(getenv("RSN_BATCH_LANES")) : 2;
-    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)(lanes_env > 0 ? lanes_env : 2), n_chunks));
+    static const int lanes_env = getenv("RSN_BATCH_LANES") ? atoi(getenv("RSN_BATCH_LANES")) : 4;
+    const size_t lanes = std::max<size_t>(1, std::min<size_t>((size_t)(lanes_env > 0 ? lanes_env : 4), n_chunks));
     std::atomic<size_t> next{0};
     std::atomic<int> first_rc{RSN_OK};
     std::mutex err_mu; std::string err_msg;
