@@ -391,11 +391,20 @@ static_assert(HWMAX + HT <= 8192, "an entry keeps the staged offset in 13 bits")
 static_assert(MATCH_STRIP % HT == 0, "a strip is a whole number of hash tiles");
 static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH == 0, "round structure");
 
-struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; const uint32_t *only; unsigned long long *stats; uint32_t *dense; };
+struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; const uint32_t *only; };
+struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's chain enters its tile / first lands beyond it (stream positions)
+// k_match_chain's arguments.  What only the prologue and the epilogue need sits in `tail` and is read from the
+// kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
+// 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
+// in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
+struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; };
+struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };
+__device__ __forceinline__ ChainTail chain_tail() {
+    return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
+}
 
-#ifndef RSN_CS
-#define RSN_CS 128
-#endif
+__device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len);
+
 
 __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint32_t rel) {
     const uint32_t q = rel >> 2;
@@ -631,6 +640,7 @@ struct ChainCfg {
     static constexpr int STAGE = NS + HLMAX + 32;
     static constexpr int NBLK = (NS + (1 << CSH) - 1) >> CSH;
     static constexpr uint32_t ROUND_CAP = 1u << 16;         // candidate rounds per wavefront before the strip is handed back
+    static constexpr int DUMP_BYTES = ((CH + CT) / 8 + 15) / 16 * 16;   // k_match_chain's record of a tile for k_chain_tail: the claim bitmap
     static_assert(CTH % (1 << CSH) == 0 && (HNB / 2) % CTH == 0 && NS <= 32768 && NBLK <= 64, "round structure");
     static_assert(MATCH_STRIP % CT == 0 && CT % 32 == 0 && CH % 32 == 0 && STAGE % 16 == 0, "tile structure");
 };
@@ -650,18 +660,20 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {       // the maxi
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <class C>
-__global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
+__global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = C::CS, CH = C::CH, NS = C::NS;
     constexpr uint32_t OFFM = (1u << C::OFFB) - 1, TAGM = (1u << C::TAGB) - 1;
     __shared__ __attribute__((aligned(16))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream
-    __shared__ uint32_t s_cur[HNB / 2];                                   // two 16-bit counters per word: counts, then starts, then ends
-    __shared__ uint16_t s_list[NS];                                       // staged offset | tag << OFFB, grouped by bucket
-    __shared__ uint32_t s_claim[(CH + CT) / 32];                          // positions somebody has taken, relative to t0 - CH
+    __shared__ __attribute__((aligned(16))) uint8_t s_pool[(HNB / 2) * 4 + NS * 2];   // the bucket index; later the two jump arrays of the in-tile parse
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_pool);              // two 16-bit counters per word: counts, then starts, then ends
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_pool + (HNB / 2) * 4);   // staged offset | tag << OFFB, grouped by bucket
+    __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];   // positions somebody has taken, relative to t0 - CH
     __shared__ unsigned long long s_present[256];                         // per byte value: the 2^CSH-position blocks of the stage it occurs in
     __shared__ uint32_t s_part[CTH / 64];
     __shared__ uint32_t s_heavy, s_next, s_dense;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
+    if (a.redo && chain_tail().tchain[blockIdx.x].walked) return;                    // second launch: only the tiles that gave up as "dense" the first time
     const long long t0 = (long long)blockIdx.x * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
     for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
-    for (int i = tid; i < (CH + CT) / 32; i += CTH) s_claim[i] = 0;
+    for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) s_claim[i] = 0;
     for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
     if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; }
     __syncthreads();
@@ -697,6 +709,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
             if (__syncthreads_and(ok)) {
                 for (long long p = t0 + tid; p < min(t0 + (long long)CT, (long long)E); p += CTH)
                     a.keys[p] = ((uint32_t)min((long long)W, (long long)E - p) << 16) | W;
+                if (tid == 0) chain_tail().tchain[blockIdx.x] = TileChain{0, 0, 0, 0};   // every position has a key here, no chain was walked: the general parse takes over
                 return;
             }
         }
@@ -766,12 +779,12 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
     // advanced less than two positions per visit hands the strip to k_match_hash.
     constexpr uint32_t DENSE_EVALS = 32;
     bool heavy = false, longm = false;
-    uint32_t u_next = 0xFFFFFFFFu, rounds = 0, visits = 0, from_kp = 0, last_kp = 0;   // visits of the chain in hand, its first and latest position
+    uint32_t u_next = 0xFFFFFFFFu, rounds = 0, visits = 0, from_kp = 0, last_kp = 0;   // the start in hand; visits of its chain, its first and latest position
     for (;;) {
         if (heavy) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_heavy = 1; } break; }
         uint32_t u_kp = uni(u_next);
         if (u_kp >= kp_end) {
-            if (visits >= DENSE_EVALS && last_kp - from_kp < 2 * visits) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; } break; }
+            if (!a.redo && visits >= DENSE_EVALS && last_kp - from_kp < 2 * visits) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; } break; }
             uint32_t kq = 0;
             if (lane == 0) kq = atomicAdd(&s_next, 1u);
             kq = uni(kq);
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
         }
         if (heavy) continue;
         if (best == 0) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
-            if (visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) {   // (the density test sits on this path because dense data comes through here all the time, text rarely)
+            if (!a.redo && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) {   // (the density test sits on this path because dense data comes through here all the time, text rarely)
                 if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; }
                 break;
             }
@@ -888,8 +901,141 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(HashArgs a) {
     }
 #endif
     __syncthreads();
-    if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / CT)] = 1;
-    if (tid == 0 && s_dense && !s_heavy) a.dense[blockIdx.x / (MATCH_STRIP / CT)] = 1;
+    const ChainTail T = chain_tail();
+    if (tid == 0 && s_heavy) T.heavy[blockIdx.x / (MATCH_STRIP / CT)] = 1;
+    if (tid == 0 && s_dense && !s_heavy) T.dense[blockIdx.x / (MATCH_STRIP / CT)] = 1;
+    if (s_heavy || s_dense) { if (tid == 0) T.tchain[blockIdx.x] = TileChain{0, 0, 0, 0}; return; }
+
+    // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(T.dump + (size_t)blockIdx.x * C::DUMP_BYTES);
+        for (int i = tid; i < C::DUMP_BYTES / 16; i += CTH) dst[i] = reinterpret_cast<const uint4 *>(s_claim)[i];
+        if (tid == 0) T.tchain[blockIdx.x] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
+    }
+}
+
+// The chain inside a tile, resolved from k_match_chain's claim bitmap and the keys instead of by the general parse
+// (k_parse_exit .. k_parse_mark).  Every landing position of a walked chain was claimed and evaluated, so following
+// i -> i + max(1, L) from the warm-up start never leaves the claimed set: the claimed positions (about one in five)
+// are ranked by a prefix popcount, each gets the rank of its successor, and pointer doubling over that compact list
+// flags what the warm-up start reaches (after round r: everything within < 2^(r+1) steps).  The block reports where
+// the chain enters the tile and where it first lands beyond it; k_chain_verify accepts the whole stream iff each
+// tile's exit IS the next tile's entry (tile 0 entering at position 0) -- then the flags written here are the true
+// chain and the general parse is skipped; otherwise the general parse runs as before.
+template <class C>
+__global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ dump, const uint32_t *__restrict__ keys, uint32_t E,
+                                                    TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+    constexpr int CT = C::CT, CH = C::CH, NKP = CH + CT, NW = NKP / 32, TT = 512;
+    constexpr uint32_t OUT = 0xFFFFu;
+    __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];
+    __shared__ uint32_t s_pre[NW + 1];                                    // claimed positions before every bitmap word
+    __shared__ uint16_t s_pos[NKP], s_j0[NKP], s_j1[NKP];                 // per rank: its position; the rank 2^r steps on (two buffers)
+    __shared__ uint8_t s_bytes[NKP];                                      // per rank: bytes the position emits if it is on the chain
+    __shared__ uint32_t s_on[NW], s_flag[CT / 32];                        // ranks on the chain; the same as position bits of the tile
+    __shared__ uint32_t s_part[TT / 64];
+    __shared__ uint32_t s_entry, s_exit, s_nout;
+    __shared__ uint16_t s_out_rank[1024], s_out_nxt[1024];               // the few positions whose match reaches beyond the tile
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const TileChain tc = tchain[blockIdx.x];
+    if (!tc.walked || tc.exit != 0) return;                               // periodic / dense / heavy tile: the general parse will have to do it; or resolved by an earlier launch
+    const long long t0 = (long long)blockIdx.x * CT;
+    const uint32_t base = (uint32_t)(t0 - CH);
+    const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0), kp_end = CH + npos, kp_first = tc.pad;
+    for (int i = tid; i < C::DUMP_BYTES / 16; i += TT) reinterpret_cast<uint4 *>(s_claim)[i] = reinterpret_cast<const uint4 *>(dump + (size_t)blockIdx.x * C::DUMP_BYTES)[i];
+    for (int i = tid; i < NW; i += TT) s_on[i] = 0;
+    for (int i = tid; i < CT / 32; i += TT) s_flag[i] = 0;
+    if (tid == 0) { s_entry = 0xFFFFFFFFu; s_exit = 0xFFFFFFFFu; s_nout = 0; }
+    __syncthreads();
+    if (wv == 0) {                                                        // exclusive prefix of the word popcounts (NW = 264 words: one wavefront, 5 per lane)
+        constexpr int PER = (NW + 63) / 64;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int w = lane * PER + k; c[k] = w < NW ? (uint32_t)__builtin_popcount(s_claim[w]) : 0u; sum += c[k]; }
+        uint32_t incl = sum;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int w = lane * PER + k; if (w < NW) s_pre[w] = run; run += c[k]; }
+        if (lane == 63) s_pre[NW] = incl;
+    }
+    __syncthreads();
+    const uint32_t n_cl = s_pre[NW];
+    auto rank_of = [&](uint32_t p) { return s_pre[p >> 5] + (uint32_t)__builtin_popcount(s_claim[p >> 5] & ((1u << (p & 31)) - 1u)); };
+    // the keys of the tile's NKP positions, 16 bytes per load (one position in five is claimed: scattered 4-byte loads
+    // would touch every line anyway, one request each)
+    for (uint32_t q = tid; q < (uint32_t)NKP / 4; q += TT) {
+        const uint32_t p4 = 4 * q, nib = (s_claim[p4 >> 5] >> (p4 & 31)) & 15u;
+        if (!nib) continue;
+        const long long g = t0 - CH + (long long)p4;                      // stream position of p4 (negative only in tile 0's unused warm-up zone)
+        uint32_t kk[4] = {0, 0, 0, 0};
+        if (g >= 0 && g + 4 <= (long long)E) { const uint4 v = *reinterpret_cast<const uint4 *>(keys + g); kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w; }
+        else for (int u = 0; u < 4; u++) if (g + u >= 0 && g + u < (long long)E) kk[u] = keys[g + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!((nib >> u) & 1)) continue;
+            const uint32_t p = p4 + u, key = kk[u], L = key >> 16, nxt = p + max(1u, L), r = rank_of(p);
+            const uint32_t el = enc_len(key & 0xFFFFu, L);
+            s_pos[r] = (uint16_t)p;
+            s_bytes[r] = (uint8_t)(L == 0 ? 1u : (el < L ? el : L));      // token only if strictly shorter than the bytes it stands for (lzss.go:143)
+            uint32_t j = OUT;
+            if (nxt < kp_end) j = ((s_claim[nxt >> 5] >> (nxt & 31)) & 1) ? rank_of(nxt) : OUT;   // (an unclaimed landing cannot happen in a finished walk)
+            else { const uint32_t k = atomicAdd(&s_nout, 1u); if (k < 1024) { s_out_rank[k] = (uint16_t)r; s_out_nxt[k] = (uint16_t)nxt; } }
+            s_j0[r] = (uint16_t)j;
+        }
+    }
+    if (tid == 0) { const uint32_t r0 = rank_of(kp_first); s_on[r0 >> 5] = 1u << (r0 & 31); }
+    __syncthreads();
+    for (int round = 0; round < 16; round++) {
+        const uint16_t *jc = (round & 1) ? s_j1 : s_j0;
+        uint16_t *jn = (round & 1) ? s_j0 : s_j1;
+        bool any = false;
+        for (uint32_t r = tid; r < n_cl; r += TT) {
+            const uint32_t j = jc[r];
+            if (j != OUT) {
+                if (((s_on[r >> 5] >> (r & 31)) & 1) && !((s_on[j >> 5] >> (j & 31)) & 1)) { atomicOr(&s_on[j >> 5], 1u << (j & 31)); any = true; }
+                jn[r] = jc[j];
+            } else jn[r] = (uint16_t)OUT;
+        }
+        if (!__syncthreads_or(any)) break;                                // nothing new at distance [2^r, 2^(r+1)): the chain is shorter than that
+    }
+    uint32_t bytes = 0;
+    for (uint32_t r = tid; r < n_cl; r += TT) {
+        if (!((s_on[r >> 5] >> (r & 31)) & 1)) continue;
+        const uint32_t p = s_pos[r];
+        if (p >= (uint32_t)CH) { bytes += s_bytes[r]; atomicMin(&s_entry, p); atomicOr(&s_flag[(p - CH) >> 5], 1u << ((p - CH) & 31)); }
+    }
+    for (uint32_t k = tid; k < min(s_nout, 1024u); k += TT) {             // exactly one chain position steps out of the tile
+        const uint32_t r = s_out_rank[k];
+        if ((s_on[r >> 5] >> (r & 31)) & 1) s_exit = s_out_nxt[k];
+    }
+    if (s_nout > 1024u && tid == 0) s_exit = 0xFFFFFFFFu;                 // (more candidates than the list holds: leave it to the general parse)
+    for (int dd = 32; dd; dd >>= 1) bytes += __shfl_down(bytes, dd);
+    if (lane == 0) s_part[wv] = bytes;
+    __syncthreads();
+    for (int w = tid; w < CT / 32; w += TT) flags[(size_t)blockIdx.x * (CT / 32) + w] = s_flag[w];
+    if (tid == 0) {
+        unsigned long long tb = 0;
+        for (int k = 0; k < TT / 64; k++) tb += s_part[k];
+        tile_bytes[blockIdx.x] = tb;
+        // a tile the chain jumps over entirely cannot happen (L <= W <= 4096 < CT); a chain that ends inside the warm-up zone can (last tile)
+        tchain[blockIdx.x] = TileChain{s_entry == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + s_entry, s_exit == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + s_exit, 1u, 0u};
+    }
+}
+
+// Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
+// tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
+__global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tiles) return;
+    const TileChain c = tc[k];
+    bool ok = c.walked != 0;
+    if (ok) {
+        if (k == 0) ok = c.entry == 0;
+        if (k + 1 < n_tiles) { const TileChain nx = tc[k + 1]; ok = ok && nx.walked && c.exit == nx.entry && (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile; }
+        else ok = ok && c.exit >= E && c.exit != 0xFFFFFFFFu;
+        ok = ok && c.entry != 0xFFFFFFFFu;
+    }
+    if (!ok) atomicAdd(&bad[c.walked ? 1 : 0], 1u);                     // bad[0]: tiles without a walked chain, bad[1]: chains that do not join
 }
 
 // ------------------------------------------------------------------ E3: greedy chain
@@ -1287,20 +1433,27 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         }
         return RSN_OK;
     };
+    // E3 buffers (the chain walk fills flags and tile bytes itself when its per-tile chains join up)
+    const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
+    rc = dev_buf(c, 12, (size_t)n_pt * 4 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 2) * 8 + (size_t)n_pt * sizeof(TileChain) + 64, &p); if (rc) return rc;
+    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;   // d_ttot[1]: strips to redo / chains that do not join
+    uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
+    uint32_t *d_flags = d_entry + n_pt;
+    TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
+    bool parsed = false;                                              // flags + tile offsets + total are final
     if (chain_mode) {
-        static const int cs_env = getenv("RSN_LZSS_CS") ? atoi(getenv("RSN_LZSS_CS")) : 128;   // tuning switch
+        using CC = ChainCfg<8192, 1024, 128>;             // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
         RSN_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)E * 4, s));
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
-        HashArgs ha{d_fc, E, W, d_keys, d_heavy, nullptr, nullptr, d_dense};
+        void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
+        uint8_t *d_dump = (uint8_t *)dp;
+        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
         ha.stats = (unsigned long long *)stp;
 #endif
-        if (cs_env == 64) { using CC = ChainCfg<8192, 1024, 64>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
-        else if (cs_env == 256) { using CC = ChainCfg<8192, 1024, 256>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
-        else if (cs_env == 512) { using CC = ChainCfg<8192, 512, 128>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
-        else { using CC = ChainCfg<8192, 1024, 128>; RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha); }
+        RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha);
 #ifdef RSN_CHAIN_STATS
         {
             unsigned long long hs[8];
@@ -1310,26 +1463,48 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                     hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1]);
         }
 #endif
-        HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense, nullptr, d_dense};
-        RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
-        rc = sweep(d_heavy); if (rc) return rc;
+        static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
+        static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
+        RSN_HIP(hipMemsetAsync(d_ttot, 0, 16, s));
+        RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+        RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
+        RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+        RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        parsed = h64[1] == 0 && !no_fused;
+        static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u without a walked chain, %u chains that do not join\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32));
+        const uint32_t not_walked = (uint32_t)h64[1];
+        if (!parsed && !no_fused && not_walked && not_walked <= std::max(4u, n_pt / 64)) {
+            // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
+            ha.redo = 1;
+            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha);
+            RSN_HIP(hipMemsetAsync(d_ttot, 0, 16, s));
+            RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
+            RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+            RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            parsed = h64[1] == 0;
+            if (dbg) fprintf(stderr, "lzss chain walk, second look: %u without a walked chain, %u chains that do not join\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32));
+        }
+        if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
+            HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
+            RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
+            rc = sweep(d_heavy); if (rc) return rc;
+        }
     } else if (hashed) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
-        HashArgs ha{d_fc, E, W, d_keys, d_heavy, nullptr, nullptr, d_dense};
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy, nullptr};
         RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
         rc = sweep(d_heavy); if (rc) return rc;
     } else {
         RSN_HIP(hipMemsetAsync(d_redo, 0, (size_t)n_strips * 4, s));
         rc = sweep(nullptr); if (rc) return rc;
     }
-    // ---- E3
-    const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
+    // ---- E3: the general parse (skipped when the chain walk's own per-tile parse was accepted)
     rc = dev_buf(c, 11, (size_t)E * 2 + 64, &p); if (rc) return rc;
     uint16_t *d_exit = (uint16_t *)p;
-    rc = dev_buf(c, 12, (size_t)n_pt * 4 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 2) * 8 + 64, &p); if (rc) return rc;
-    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;   // d_ttot[1]: strips to redo
-    uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
-    uint32_t *d_flags = d_entry + n_pt;
     const uint32_t n_groups = (uint32_t)ceil_div(n_pt, SUPER);
     void *q; rc = dev_buf(c, 17, (size_t)n_groups * PT * 4 + (size_t)n_groups * 8 + 64, &q); if (rc) return rc;
     uint32_t *d_super = (uint32_t *)q;
@@ -1337,7 +1512,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     const size_t mark_sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
     static thread_local size_t mark_attr = 0;
     if (mark_sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mark_sh)); mark_attr = mark_sh; }
-    for (uint32_t round = 0;; round++) {
+    for (uint32_t round = 0; !parsed; round++) {
         RSN_HIP(hipMemsetAsync(d_ttot + 1, 0, 8, s));
         RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
         RSN_LAUNCH("lzss_parse_super", k_parse_super, dim3(n_groups), dim3(LB), 0, s, d_exit, n_pt, E, d_super);
@@ -1351,7 +1526,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         if (!chain_mode || round > n_strips) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: the parse met an unevaluated position outside chain mode");
         // the true chain landed where no speculative chain had been: search those strips at every position
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 4, s));
-        HashArgs ha{d_fc, E, W, d_keys, d_heavy, d_redo, nullptr, d_dense};
+        HashArgs ha{d_fc, E, W, d_keys, d_heavy, d_redo};
         RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, ha);
         rc = sweep(d_heavy); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(d_redo, 0, (size_t)n_strips * 4, s));
