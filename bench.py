@@ -31,17 +31,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def load_traffic():
-    """HBM bytes per launch from the newest committed PMC profile (scripts/profile.sh): a constant of that
-    profile, not a measurement of this run."""
+# librsn's profiling names of the headline (flat-code) kernels -> the kernel's name in a rocprofv3 trace
+TRACE_NAME = {"huff_emit": "k_emit_flat", "huff_dec_flat": "k_dec_flat", "huff_byte_hist": "k_byte_hist"}
+
+
+def load_traffic(prof_name):
+    """HBM bytes per launch of one kernel from the newest committed PMC profile (scripts/profile.sh + summarize_prof.py:
+    FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate passes): a constant of that profile, not a
+    measurement of this run."""
     import glob
+    want = TRACE_NAME.get(prof_name)
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
-            best = json.load(open(p))
+            d = json.load(open(p))
         except Exception:
-            pass
-    return best or {}
+            continue
+        for k, v in d.items():
+            if want and k.startswith(want):
+                best = v
+    return best
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines
@@ -368,7 +377,7 @@ def main():
                 ent["frac_of_hbm_peak"] = round(alg[k] / ms / 1e6 / HBM_PEAK_GBPS, 4)
             kernels[k] = ent
         dom = max((k for k in per if k in alg), key=lambda k: per[k] * cnt[k])
-        traffic = load_traffic().get(dom)
+        traffic = load_traffic(dom)
         roofline = {
             "kernel": dom, "bound": "hbm", "achieved": round(alg[dom] / per[dom] / 1e6, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(alg[dom] / per[dom] / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,

@@ -54,16 +54,10 @@ def main():
             a[1] += 1
         for k, (tot, cnt) in acc.items():
             res[k][key] = tot / cnt
-    names = {"k_byte_hist": "huff_byte_hist", "k_emit<0>": "huff_emit", "k_dec_sync": "huff_dec_sync", "k_dec_emit": "huff_dec_emit",
-             "k_dec_flat": "huff_dec_flat", "k_emit_ascii32": "huff_emit", "k_emit_flat": "huff_emit"}
     final = {}
     for k, v in res.items():
-        base = k
-        for a, b in names.items():
-            if k.startswith(a.split("<")[0]) and (("<" not in a) or k.startswith(a)):
-                base = b
         v["hbm_bytes"] = v.get("fetch_bytes", 0) + v.get("write_bytes", 0)
-        final[base] = v
+        final[k] = v                                  # keyed by the kernel's own (template) name: bench.py picks by prefix
         print("%-40s fetch %.3e  write %.3e B per launch" % (k, v.get("fetch_bytes", 0), v.get("write_bytes", 0)))
     json.dump({k: round(v["hbm_bytes"]) for k, v in final.items()}, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     json.dump(final, open(os.path.join(prof, tag + "_pmc_detail.json"), "w"), indent=1, sort_keys=True)
