@@ -575,8 +575,9 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
 
     // ---- tables
-    const int K = (int)std::min<unsigned>(codes.max_len, LUT_BITS_MAX);
-    const bool short_codes = codes.max_len <= (unsigned)LUT_BITS_MAX;
+    static const int k_env = [] { const char *e = getenv("RSN_DEC_K"); return e ? std::min(std::max(atoi(e), 4), LUT_BITS_MAX) : LUT_BITS_MAX; }();   // tuning switch: index bits of the first-level table
+    const int K = (int)std::min<unsigned>(codes.max_len, (unsigned)k_env);
+    const bool short_codes = codes.max_len <= (unsigned)K;
     std::vector<uint32_t> lut; std::vector<int32_t> child;
     build_tables(tree, K, lut, child);
     // multi-symbol table: decode as many whole codewords (<= 3) as fit in KM bits
