@@ -778,120 +778,129 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     // k_match_hash's one lane per position with its near-empty buckets.  A wavefront whose chain
     // advanced less than two positions per visit hands the strip to k_match_hash.
     constexpr uint32_t DENSE_EVALS = 32;
-    bool heavy = false, longm = false;
-    uint32_t u_next = 0xFFFFFFFFu, rounds = 0, visits = 0, from_kp = 0, last_kp = 0;   // the start in hand; visits of its chain, its first and latest position
-    for (;;) {
-        if (heavy) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_heavy = 1; } break; }
+    // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
+    //  state machine and spends ~40 scalar instructions per visit on its masks, and scalar issue is this kernel's bound.)
+    bool alive = true;
+    uint32_t u_next = 0xFFFFFFFFu, visits = 0, from_kp = 0;               // where the chain in hand goes on; its visits and its start
+    while (alive) {
         uint32_t u_kp = uni(u_next);
-        if (u_kp >= kp_end) {
-            if (!a.redo && visits >= DENSE_EVALS && last_kp - from_kp < 2 * visits) { if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; } break; }
+        u_next = 0xFFFFFFFFu;
+        if (u_kp >= kp_end) {                                             // the chain in hand has ended: a new start
             uint32_t kq = 0;
             if (lane == 0) kq = atomicAdd(&s_next, 1u);
             kq = uni(kq);
-            if (kq >= nitems) break;
+            alive = kq < nitems;
             u_kp = kq == 0 ? kp_first : CH + (kq - 1) * CS;
             visits = 0; from_kp = u_kp;
         }
-        {
+        bool mine = false;
+        if (alive) {
             uint32_t old = 0;
             if (lane == 0) old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
-            old = uni(old);
-            u_next = 0xFFFFFFFFu;
-            if ((old >> (u_kp & 31)) & 1) continue;                       // somebody else's already: that wavefront walks the rest
+            mine = !((uni(old) >> (u_kp & 31)) & 1);                      // somebody else's already: that wavefront walks the rest
         }
-        const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
-        const uint32_t u_b0 = uni(sb[u_irel]), u_b1 = uni(sb[u_irel + 1]);
-        uint32_t best = 0;
-        if (u_capE >= 2) {
-            const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
-            uint32_t u_lo = uni(u_h ? ends[u_h - 1] : 0);
-            const uint32_t u_hi = uni(ends[u_h]);
-            const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
-            const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);      // the position's own bytes: one address for all lanes
-            while (u_hi - u_lo > 64) {                                    // skip the entries before the window, 64-ary
-                const uint32_t n = u_hi - u_lo, stride = (n + 63) >> 6;
-                const uint32_t idx = min(u_lo + (uint32_t)lane * stride, u_hi - 1);
-                const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
-                const unsigned long long in = __ballot(blk >= u_blk_lo);
-                const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
-                if (first <= 1) break;
-                u_lo = min(u_lo + (first - 1) * stride, u_hi - 1);
-                if (stride == 1) break;
-            }
-            for (uint32_t base = u_lo; base < u_hi; base += 64) {
-#ifdef RSN_CHAIN_STATS
-                n_rounds++;
-#endif
-                if (++rounds > C::ROUND_CAP) { heavy = true; break; }
-                const uint32_t idx = base + (uint32_t)lane;
-                const bool valid = idx < u_hi;
-                const uint32_t e = s_list[valid ? idx : u_lo];
-                const uint32_t rel = e & OFFM, dn = u_irel - rel;
-                const bool ok = valid && dn - 1u < W && (e >> C::OFFB) == u_tag;   // candidate start in [i-W, i), same bigram up to the tag
-                const bool last = __ballot(valid && (rel >> CSH) > u_blk_i) != 0; // the rest of the bucket starts after i
-                if (__ballot(ok)) {
-                    const uint32_t cap = min(dn, u_capE);                  // entirely inside the window, and inside the stream
-                    uint32_t off = C::OFF0;
-                    unsigned long long x = lds_load8(sw, rel + off) ^ pat0;
-                    uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                    bool more = ok && n == 8 && off + 8 < cap;
-                    while (__ballot(more)) {                               // longer than eight bytes: the lanes concerned go on, eight at a time
-#ifdef RSN_CHAIN_STATS
-                        n_ext++;
-#endif
-                        if (more) {
-                            off += 8;
-                            x = lds_load8(sw, rel + off) ^ lds_load8(sw, u_irel + off);
-                            n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                            more = n == 8 && off + 8 < cap;
-                        }
-                        if (__ballot(more && off + 8 >= HLMAX)) { longm = true; break; }
-                    }
-                    uint32_t len = min(off + n, cap);
-                    if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
-                    best = max(best, (ok && len) ? (len << 16) | dn : 0u); // longest, then farthest back (bytes.Index, lzss.go:419)
+        if (mine) {
+            const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
+            const uint32_t u_b0 = uni(sb[u_irel]), u_b1 = uni(sb[u_irel + 1]);
+            uint32_t best = 0;
+            bool longm = false, giveup_heavy = false, giveup_dense = false;
+            if (u_capE >= 2) {
+                const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
+                uint32_t u_lo = uni(ends[max(u_h, 1u) - 1]);
+                u_lo = u_h ? u_lo : 0u;
+                uint32_t u_hi = uni(ends[u_h]);
+                const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
+                const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);  // the position's own bytes: one address for all lanes
+                bool narrowing = u_hi - u_lo > 64;
+                while (narrowing) {                                           // skip the entries before the window, 64-ary
+                    const uint32_t n = u_hi - u_lo, stride = (n + 63) >> 6;
+                    const uint32_t idx = min(u_lo + (uint32_t)lane * stride, u_hi - 1);
+                    const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
+                    const unsigned long long in = __ballot(blk >= u_blk_lo);
+                    const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
+                    u_lo = first > 1 ? min(u_lo + (first - 1) * stride, u_hi - 1) : u_lo;
+                    narrowing = first > 1 && stride > 1 && u_hi - u_lo > 64;
                 }
-                if (last) break;
-            }
-            best = wave_max_u32(best);
-        }
-        if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
-                       // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
-            longm = false;
-            const uint32_t Lp = min(W, u_capE);
-            bool eq = u_ipos >= W;
-            if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
-            if (__ballot(!eq)) heavy = true;
-            else best = (Lp << 16) | W;
-        }
-        if (heavy) continue;
-        if (best == 0) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
-            if (!a.redo && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) {   // (the density test sits on this path because dense data comes through here all the time, text rarely)
-                if (lane == 0) { atomicOr(&s_next, GIVE_UP); s_dense = 1; }
-                break;
-            }
-            const uint32_t ws = max(u_irel - min(W, u_irel), zrel);       // the window is staged [ws, irel)
-            const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
-            bool hit = false;
-            if (fb_lo < fb_hi) {
-                const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
-                hit = (s_present[u_b0] & m) != 0;
-            }
-            if (!hit) {                                                   // the two ragged ends, byte by byte
-                const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
-                bool f = false;
-                for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
-                for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
-                hit = __ballot(f) != 0;
-            }
-            best = hit ? (1u << 16) : 0u;
-        }
-        if (lane == 0) a.keys[u_ipos] = best;
-        u_next = u_kp + max(1u, best >> 16);                              // lzss.go:139-142: a reference skips size-1 positions
-        visits++; last_kp = u_kp;
+                uint32_t base = u_lo;
+                while (base < u_hi) {
 #ifdef RSN_CHAIN_STATS
-        n_evals++;
+                    n_rounds++;
 #endif
+                    const uint32_t idx = base + (uint32_t)lane;
+                    const bool valid = idx < u_hi;
+                    const uint32_t e = s_list[valid ? idx : u_lo];
+                    const uint32_t rel = e & OFFM, dn = u_irel - rel;
+                    const bool ok = valid && dn - 1u < W && (e >> C::OFFB) == u_tag;   // candidate start in [i-W, i), same bigram up to the tag
+                    if (__ballot(valid && (rel >> CSH) > u_blk_i)) u_hi = base;       // the rest of the bucket starts after i: this is the last round
+                    base += 64;
+                    if (__ballot(ok)) {
+                        const uint32_t cap = min(dn, u_capE);                  // entirely inside the window, and inside the stream
+                        uint32_t off = C::OFF0;
+                        unsigned long long x = lds_load8(sw, rel + off) ^ pat0;
+                        uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                        bool more = ok && n == 8 && off + 8 < cap;
+                        while (__ballot(more)) {                               // longer than eight bytes: the lanes concerned go on, eight at a time
+#ifdef RSN_CHAIN_STATS
+                            n_ext++;
+#endif
+                            if (more) {
+                                off += 8;
+                                x = lds_load8(sw, rel + off) ^ lds_load8(sw, u_irel + off);
+                                n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                                more = n == 8 && off + 8 < cap;
+                            }
+                            if (__ballot(more && off + 8 >= HLMAX)) { longm = true; more = false; }
+                        }
+                        uint32_t len = min(off + n, cap);
+                        if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
+                        best = max(best, (ok && len) ? (len << 16) | dn : 0u); // longest, then farthest back (bytes.Index, lzss.go:419)
+                    }
+                }
+                best = wave_max_u32(best);
+            }
+            if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
+                           // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
+                const uint32_t Lp = min(W, u_capE);
+                bool eq = u_ipos >= W;
+                if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
+                if (__ballot(!eq)) giveup_heavy = true;
+                else best = (Lp << 16) | W;
+            }
+            if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
+                // (the density test sits on this path because dense data comes through here all the time, text rarely)
+                if (!a.redo && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
+                else {
+                    const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
+                    const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
+                    bool hit = false;
+                    if (fb_lo < fb_hi) {
+                        const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
+                        hit = (s_present[u_b0] & m) != 0;
+                    }
+                    if (!hit) {                                               // the two ragged ends, byte by byte
+                        const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
+                        bool f = false;
+                        for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
+                        for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
+                        hit = __ballot(f) != 0;
+                    }
+                    best = hit ? (1u << 16) : 0u;
+                }
+            }
+            if (giveup_heavy || giveup_dense) {
+                // the start counter is pushed past every item; the other wavefronts finish the chain they are on (text: a handful
+                // of visits; dense data: they run into this test themselves within DENSE_EVALS visits) and find nothing more to start
+                if (lane == 0) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
+                alive = false;
+            } else {
+                if (lane == 0) a.keys[u_ipos] = best;
+                u_next = u_kp + max(1u, best >> 16);                          // lzss.go:139-142: a reference skips size-1 positions
+                visits++;
+#ifdef RSN_CHAIN_STATS
+                n_evals++;
+#endif
+            }
+        }
     }
 #ifdef RSN_CHAIN_STATS
     if (a.stats && lane == 0) {
