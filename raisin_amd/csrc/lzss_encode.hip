@@ -709,7 +709,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             if (__syncthreads_and(ok)) {
                 for (long long p = t0 + tid; p < min(t0 + (long long)CT, (long long)E); p += CTH)
                     a.keys[p] = ((uint32_t)min((long long)W, (long long)E - p) << 16) | W;
-                if (tid == 0) chain_tail().tchain[blockIdx.x] = TileChain{0, 0, 0, 0};   // every position has a key here, no chain was walked: the general parse takes over
+                if (tid == 0) chain_tail().tchain[blockIdx.x] = TileChain{0, 0, 2u, 0};   // W-periodic: every position has the key (min(W, E-p), W); k_chain_periodic places the chain once its entry is known
                 return;
             }
         }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
     __shared__ uint16_t s_out_rank[1024], s_out_nxt[1024];               // the few positions whose match reaches beyond the tile
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const TileChain tc = tchain[blockIdx.x];
-    if (!tc.walked || tc.exit != 0) return;                               // periodic / dense / heavy tile: the general parse will have to do it; or resolved by an earlier launch
+    if (tc.walked != 1 || tc.exit != 0) return;                           // periodic / dense / heavy tile: the general parse will have to do it; or resolved by an earlier launch
     const long long t0 = (long long)blockIdx.x * CT;
     const uint32_t base = (uint32_t)(t0 - CH);
     const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0), kp_end = CH + npos, kp_first = tc.pad;
@@ -1031,20 +1031,96 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
     }
 }
 
+// W-periodic tiles (config 3 is nothing else) have a key at every position -- L = min(W, E-p) at distance W -- and
+// no chain of their own: chains of different phase never merge in periodic data, the phase is handed on from tile
+// to tile.  k_prev_walked finds, for every tile, the nearest tile before it whose chain was really walked (an
+// inclusive max-scan of "index if walked"); k_chain_periodic then places the chain of a periodic tile by
+// arithmetic: from that tile's exit x the chain steps by W through the periodic stretch, so it enters this tile
+// at x + W * ceil((t0 - x) / W) -- valid because every tile in between is periodic too (checked) -- and the flags,
+// the output bytes and the tile's entry / exit follow.  k_chain_verify then checks the joints as for any tile.
+__global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t *__restrict__ prev) {
+    constexpr int IT = 8;
+    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;                                          // 0 = none yet; else tile index + 1
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024 * IT) {
+        const uint32_t i0 = base + tid * IT;
+        uint32_t x[IT], loc = 0;
+#pragma unroll
+        for (int k = 0; k < IT; k++) { x[k] = (i0 + k < n_tiles && tc[i0 + k].walked == 1) ? i0 + k + 1 : 0u; loc = max(loc, x[k]); }
+        uint32_t sfx = loc;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(sfx, d); if (lane >= d) sfx = max(sfx, y); }
+        if (lane == 63) wmax[wv] = sfx;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int k = 0; k < wv; k++) pre = max(pre, wmax[k]);
+        uint32_t before = max(pre, (uint32_t)__shfl_up(sfx, 1));
+        if (lane == 0) before = pre;
+        uint32_t run = before;
+#pragma unroll
+        for (int k = 0; k < IT; k++) { run = max(run, x[k]); if (i0 + k < n_tiles) prev[i0 + k] = run; }   // inclusive: a walked tile names itself
+        __syncthreads();
+        if (tid == 1023) carry_s = max(pre, sfx);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain_periodic(TileChain *__restrict__ tc, const uint32_t *__restrict__ prev, uint32_t n_tiles, uint32_t E, uint32_t W,
+                                                        uint32_t tile, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+    const uint32_t k = blockIdx.x;
+    if (tc[k].walked != 2) return;
+    const uint32_t words = tile / 32;
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) flags[(size_t)k * words + w] = 0;
+    __syncthreads();
+    if (threadIdx.x) return;
+    const uint32_t pw = prev[k];
+    if (pw == 0) return;                                                // nothing walked before it: stays unresolved, the general parse decides
+    const TileChain src = tc[pw - 1];
+    if (src.exit == 0 || src.exit == 0xFFFFFFFFu) return;
+    const unsigned long long t0 = (unsigned long long)k * tile, t1 = min(t0 + tile, (unsigned long long)E);
+    unsigned long long x = src.exit;                                    // first chain position beyond the walked tile: inside the periodic stretch
+    if (x < (unsigned long long)pw * tile || x >= t1 + W) return;
+    if (x < t0) x += (t0 - x + W - 1) / W * W;                          // whole steps of W through the periodic tiles in between
+    if (x >= t1) {                                                      // (cannot happen: W <= 4096 < tile) the chain jumps over this tile
+        tc[k] = TileChain{0xFFFFFFFFu, 0xFFFFFFFFu, 2u, 0};
+        return;
+    }
+    const unsigned long long entry = x;
+    unsigned long long bytes = 0;
+    while (x < t1) {
+        const uint32_t L = (uint32_t)min((unsigned long long)W, (unsigned long long)E - x), el = enc_len(W, L);
+        bytes += el < L ? el : L;                                       // lzss.go:143
+        const uint32_t r = (uint32_t)(x - t0);
+        flags[(size_t)k * words + (r >> 5)] |= 1u << (r & 31);
+        x += L;                                                         // L >= 1 here (x < E)
+    }
+    tile_bytes[k] = bytes;
+    tc[k] = TileChain{(uint32_t)entry, (uint32_t)x, 2u, 1u};            // pad = 1: resolved
+}
+
 // Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
 // tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
 __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_tiles) return;
-    const TileChain c = tc[k];
-    bool ok = c.walked != 0;
-    if (ok) {
+    const bool live = k < n_tiles;
+    const TileChain c = live ? tc[k] : TileChain{0, 0, 1u, 0};
+    bool ok = c.walked == 1 || (c.walked == 2 && c.pad == 1);           // walked, or periodic and placed by k_chain_periodic
+    if (ok && live) {
         if (k == 0) ok = c.entry == 0;
-        if (k + 1 < n_tiles) { const TileChain nx = tc[k + 1]; ok = ok && nx.walked && c.exit == nx.entry && (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile; }
+        if (k + 1 < n_tiles) { const TileChain nx = tc[k + 1]; ok = ok && (nx.walked == 1 || (nx.walked == 2 && nx.pad == 1)) && c.exit == nx.entry && (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile; }
         else ok = ok && c.exit >= E && c.exit != 0xFFFFFFFFu;
         ok = ok && c.entry != 0xFFFFFFFFu;
     }
-    if (!ok) atomicAdd(&bad[c.walked ? 1 : 0], 1u);                     // bad[0]: tiles without a walked chain, bad[1]: chains that do not join
+    // bad[0]: tiles that gave up (dense / heavy), bad[1]: chains that do not join, bad[2]: periodic tiles that could not be placed
+    // (one atomic per wavefront and class: config 3's first look fails 131071 times)
+    const uint32_t cls = c.walked == 1 ? 1u : (c.walked == 2 ? 2u : 0u);
+#pragma unroll
+    for (uint32_t q = 0; q < 3; q++) {
+        const unsigned long long m = __ballot(live && !ok && cls == q);
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
+    }
 }
 
 // ------------------------------------------------------------------ E3: greedy chain
@@ -1444,9 +1520,9 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     };
     // E3 buffers (the chain walk fills flags and tile bytes itself when its per-tile chains join up)
     const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
-    rc = dev_buf(c, 12, (size_t)n_pt * 4 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 2) * 8 + (size_t)n_pt * sizeof(TileChain) + 64, &p); if (rc) return rc;
-    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;   // d_ttot[1]: strips to redo / chains that do not join
-    uint32_t *d_entry = (uint32_t *)(d_ttot + 2);
+    rc = dev_buf(c, 12, (size_t)n_pt * 8 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 4) * 8 + (size_t)n_pt * sizeof(TileChain) + 64, &p); if (rc) return rc;
+    unsigned long long *d_tbytes = (unsigned long long *)p, *d_toff = d_tbytes + n_pt, *d_ttot = d_toff + n_pt;   // d_ttot[1..2]: strips to redo / the chain walk's three failure counts
+    uint32_t *d_entry = (uint32_t *)(d_ttot + 4);                       // (also k_prev_walked's output: the two are never live together)
     uint32_t *d_flags = d_entry + n_pt;
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
@@ -1474,28 +1550,29 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
-        RSN_HIP(hipMemsetAsync(d_ttot, 0, 16, s));
-        RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-        RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
-        RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
-        RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
-        RSN_HIP(hipStreamSynchronize(s));
-        parsed = h64[1] == 0 && !no_fused;
+        auto resolve = [&]() -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
+            RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
+            RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(1), dim3(1024), 0, s, d_tchain, n_pt, d_entry);
+            RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
+            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
+            RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+            RSN_HIP(hipMemcpyAsync(h64, d_ttot, 24, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            return RSN_OK;
+        };
+        rc = resolve(); if (rc) return rc;
+        parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u without a walked chain, %u chains that do not join\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32));
+        if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         const uint32_t not_walked = (uint32_t)h64[1];
         if (!parsed && !no_fused && not_walked && not_walked <= std::max(4u, n_pt / 64)) {
             // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
             ha.redo = 1;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha);
-            RSN_HIP(hipMemsetAsync(d_ttot, 0, 16, s));
-            RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
-            RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
-            RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
-            RSN_HIP(hipStreamSynchronize(s));
-            parsed = h64[1] == 0;
-            if (dbg) fprintf(stderr, "lzss chain walk, second look: %u without a walked chain, %u chains that do not join\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32));
+            rc = resolve(); if (rc) return rc;
+            parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
+            if (dbg) fprintf(stderr, "lzss chain walk, second look: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         }
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
