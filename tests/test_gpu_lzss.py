@@ -303,6 +303,17 @@ def test_chain_period_inside_first_tile(lz, oracle):
         assert lz.CompressAsync(data, False, w) == oracle.lzss_compress(data, w)
 
 
+def test_chain_periodic_stretches_between_text(lz, oracle):
+    """W-periodic tiles have no chain of their own (phases never merge in periodic data): their chain is placed by
+    arithmetic from the last walked tile's exit (k_chain_periodic) and must join the walked tiles on both sides."""
+    blk = rnd(78, 4096, bytes(v for v in range(256) if v not in (0x5C, 0xFF, 0x3C)))
+    for w, per, reps in ((4096, 4096, 21), (4096, 4096, 5), (3000, 3000, 40), (1024, 1024, 70)):
+        data = text(41, 30000) + blk[:per] * reps + text(42, 41000) + blk[:per] * (reps + 3) + b"end"
+        c, p = _prof(lz, data, w)
+        assert c == oracle.lzss_compress(data, w), (w, per, reps)
+        assert lz.Decompress(c) == data
+
+
 def test_chain_vs_allpos_switch(oracle):
     """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes: separate process,
     the switch is read once."""
