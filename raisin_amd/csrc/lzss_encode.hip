@@ -801,13 +801,14 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
         }
         if (mine) {
             const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
-            const uint32_t u_b0 = uni(sb[u_irel]), u_b1 = uni(sb[u_irel + 1]);
+            // (the bigram, its bucket index and tag stay in vector registers although they are wave-uniform: scalar issue is the bound)
+            const uint32_t u_b0 = sb[u_irel], u_b1 = sb[u_irel + 1];
             uint32_t best = 0;
             bool longm = false, giveup_heavy = false, giveup_dense = false;
             if (u_capE >= 2) {
                 const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
-                uint32_t u_lo = uni(ends[max(u_h, 1u) - 1]);
-                u_lo = u_h ? u_lo : 0u;
+                const uint32_t v_lo = ends[max(u_h, 1u) - 1];
+                uint32_t u_lo = uni(u_h ? v_lo : 0u);
                 uint32_t u_hi = uni(ends[u_h]);
                 const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
                 const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);  // the position's own bytes: one address for all lanes
