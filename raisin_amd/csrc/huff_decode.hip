@@ -20,9 +20,13 @@
 //                    tree is perfectly balanced) the payload is an array of L-bit
 //                    fields: no synchronisation is needed, each lane unpacks 16
 //                    fields and stores 16 bytes.
-// Code lookup: a 2^K-entry table in LDS (K = min(maxlen,12)), replicated so that
-// the lanes of a wavefront hit different banks; longer codes finish with a
-// bit-by-bit walk of the tree's child array (global, L2 resident).
+// Code lookup: ONE 2^K-entry table in LDS (K = min(maxlen, 11)), replicated across banks when it is small.
+// For byte alphabets (every rune < 0x80) an entry describes up to three whole codewords inside the K-bit
+// window -- the counting walk takes them all in one lookup, a single-symbol step uses the first -- or, when
+// the first codeword is longer than K bits, the tree node the window leads to; longer codes finish with a
+// bit-by-bit walk of the tree's child array (staged in LDS for byte alphabets).  One table instead of r1's
+// two (single + multi) is what lets seven blocks share a CU in the counting pass instead of four: the walks
+// are bound by the latency of their own dependent LDS reads, i.e. by how many wavefronts are there to hide it.
 #include "codecs.h"
 
 namespace rsn {
@@ -37,7 +41,6 @@ constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are of
 constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
-constexpr int KM = 12;              // index bits of the multi-symbol table (ASCII alphabets with codes <= 11 bits)
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
 constexpr int CHILD_LDS = 1024;     // child[] of a byte alphabet (<= 2 * 255 entries) is staged in LDS: a code longer than K bits
                                     // costs LDS latency per extra bit instead of a global load (one wavefront in five hits one per step on skewed data)
@@ -52,7 +55,6 @@ struct DecArgs {
     uint32_t n_sub;             // number of subsequences
     const uint32_t *lut; int K; int rep_log2;   // (1<<K) entries, each replicated 1<<rep_log2 times in LDS
     const int32_t *child;       // 2 per internal node: >=0 internal index, <0 -(rune+1)
-    const uint32_t *mlut;       // MULTI: 2^12 entries, up to 3 symbols each: sym1 | sym2<<8 | sym3<<16 | bits<<24 | (n-1)<<28
     uint32_t min_len; int flat_guess; int warm;   // warm: bits decoded ahead of a subsequence so that the guess self-synchronises
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
@@ -127,10 +129,18 @@ __device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) {
 
 // One codeword at `pos`: returns the rune and advances pos.  No state is carried between
 // symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
-template <bool SHORT>
+// Table entries.  Rune alphabets:  len << 24 | rune, or 0x80000000 | node when the code is longer than K bits.
+// Byte alphabets (unified):        sym1 | sym2 << 7 | sym3 << 14 | bits of all n << 21 | n << 25 | bits of the first << 27
+//                                  (n = 1..3 whole codewords inside the window), or 0x80000000 | node.
+__device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 21) & 15u; }
+__device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 25) & 3u; }
+__device__ __forceinline__ uint32_t u_len1(uint32_t e) { return (e >> 27) & 15u; }
+
+template <bool ASCII, bool SHORT>
 __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos) {
     const uint32_t ent = s_lut[((window32(s_data, pos) >> (32 - a.K)) << a.rep_log2) | lane_r];
     if (SHORT || !(ent & 0x80000000u)) {
+        if (ASCII) { pos += u_len1(ent); return ent & 0x7Fu; }
         pos += ent >> 24;
         return ent & 0x1FFFFFu;
     }
@@ -150,21 +160,20 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t 
 // Walk from block-relative bit `pos` to the first code boundary >= lim.  A code that runs past
 // the end of the payload can only be the last one of the walk: checked once, after the loop.
 template <bool ASCII, bool SHORT, bool MULTI>
-__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut, uint32_t lane_r,
+__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r,
                                      uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
     uint32_t nb = 0;
-    if (MULTI) {
-        // up to 3 codewords per table lookup while a whole KM-bit step stays inside the subsequence
-        const uint32_t safe = lim >= KM ? lim - KM : 0;
-        while (pos <= safe && lim >= KM) {
-            const uint32_t e = s_mlut[window32(s_data, pos) >> (32 - KM)];
-            const uint32_t n = (e >> 28) & 3;
-            if (n == 0) { (void)decode_one<SHORT>(a, s_data, s_lut, lane_r, pos); nb++; }   // first code longer than KM bits
-            else { pos += (e >> 24) & 15; nb += n; }
+    if (ASCII && MULTI) {
+        // up to 3 codewords per table lookup while a whole K-bit step stays inside the subsequence
+        const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
+        while (pos <= safe && lim >= K) {
+            const uint32_t e = s_lut[((window32(s_data, pos) >> (32 - K)) << a.rep_log2) | lane_r];
+            if (!SHORT && (e & 0x80000000u)) { (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos); nb++; }   // first code longer than K bits
+            else { pos += u_used(e); nb += u_n(e); }
         }
     }
     while (pos < lim) {
-        const uint32_t r = decode_one<SHORT>(a, s_data, s_lut, lane_r, pos);
+        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos);
         nb += ASCII ? 1 : dev_utf8_len(r);
     }
     *exit_pos = pos > end_rel ? BAD_POS : pos;
@@ -175,7 +184,6 @@ template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_PHYS];
     __shared__ uint32_t s_lut[LUT_WORDS];
-    __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
@@ -185,7 +193,6 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);   // once per (persistent) block
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
-    if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
                 // codewords, so the first boundary at or after my0 is very likely the true entry
                 const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
                 uint32_t q = start;
-                while (q < my0) (void)decode_one<SHORT>(a, s_data, s_lut, lane_r, q);
+                while (q < my0) (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, q);
                 e = q;
             }
         } else {
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         for (int round = 0; round <= DB; round++) {
             if (live && !have) {
                 if (e == BAD_POS) { x = BAD_POS; nb = 0; }
-                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, e, lim, end_rel, &x, &nb);
+                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, e, lim, end_rel, &x, &nb);
                 have = true;
             }
             s_exit[tid] = x;
@@ -303,11 +310,11 @@ __device__ __forceinline__ void put_rune(uint32_t rune, Put put) {   // string(r
 }
 
 // Decode loop of D3: entries are exact, so the walk never runs off the payload.
-template <bool ASCII, bool SHORT, bool MULTI, class Put>
-__device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, const uint32_t *s_mlut,
+template <bool ASCII, bool SHORT, class Put>
+__device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut,
                                           uint32_t lane_r, uint32_t pos, uint32_t lim, Put put) {
     while (pos < lim) {
-        const uint32_t r = decode_one<SHORT>(a, s_data, s_lut, lane_r, pos);
+        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos);
         if (ASCII) put(r); else put_rune(r, put);
     }
 }
@@ -316,7 +323,6 @@ template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_PHYS];
     __shared__ uint32_t s_lut[LUT_WORDS];
-    __shared__ uint32_t s_mlut[MULTI ? (1 << KM) : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
@@ -325,7 +331,6 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
-    if (MULTI) for (int i = tid; i < (1 << KM); i += DB) s_mlut[i] = a.mlut[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -349,11 +354,12 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
         if (live && er != BAD_REL && nb != 0) {
             if (staged) {
                 uint8_t *o = s_out + al + my_off;
-                emit_walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, my0 + er, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
+                uint32_t pos = my0 + er;
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
             } else {
                 Sink sink;
                 sink.start(dst + my_off);
-                emit_walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, s_mlut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
                 sink.finish();
             }
         }
@@ -580,33 +586,32 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const bool short_codes = codes.max_len <= (unsigned)K;
     std::vector<uint32_t> lut; std::vector<int32_t> child;
     build_tables(tree, K, lut, child);
-    // multi-symbol table: decode as many whole codewords (<= 3) as fit in KM bits
+    // byte alphabets: the unified table (up to three whole codewords per K-bit window)
     static const bool no_multi = getenv("RSN_NO_MULTI") != nullptr;
-    // worth it when a KM-bit window usually holds two or more codewords
     unsigned long long n_syms_total = 0;
     for (uint32_t i = 0; i < tree.n_leaves; i++) n_syms_total += tree.freq[i];
+    // taking several codewords per lookup is worth it when a K-bit window usually holds two or more
     const bool multi = ascii && !no_multi && n_syms_total && codes.total_bits * 10 <= n_syms_total * 65;   // mean code <= 6.5 bits
-    std::vector<uint32_t> mlut;
-    if (multi) {
-        mlut.assign((size_t)1 << KM, 0);
-        for (uint32_t v = 0; v < (1u << KM); v++) {
-            uint32_t used = 0, nsym = 0, ent = 0;
-            while (nsym < 3 && used < (uint32_t)KM) {
+    if (ascii) {
+        const std::vector<uint32_t> plain = lut;                              // len << 24 | rune, or 0x80000000 | node
+        for (uint32_t v = 0; v < (1u << K); v++) {
+            if (plain[v] & 0x80000000u) continue;                                 // first code longer than K bits: the node stays
+            uint32_t used = 0, nsym = 0, syms = 0, len1 = 0;
+            while (nsym < 3 && used < (uint32_t)K) {
                 int32_t node = tree.root;
                 uint32_t q = used;
-                while (!tree.is_leaf(node) && q < (uint32_t)KM) { node = ((v >> (KM - 1 - q)) & 1) ? tree.right[node] : tree.left[node]; q++; }
-                if (!tree.is_leaf(node)) break;            // ran out of bits inside a codeword
-                ent |= (tree.rune[node] & 0xFF) << (8 * nsym);
+                while (!tree.is_leaf(node) && q < (uint32_t)K) { node = ((v >> (K - 1 - q)) & 1) ? tree.right[node] : tree.left[node]; q++; }
+                if (!tree.is_leaf(node)) break;                                   // ran out of bits inside a codeword
+                syms |= (tree.rune[node] & 0x7Fu) << (7 * nsym);
+                if (nsym == 0) len1 = q;
                 used = q; nsym++;
             }
-            mlut[v] = ent | (used << 24) | (nsym << 28);   // nsym == 0: the first code is longer than KM bits
+            lut[v] = syms | (used << 21) | (nsym << 25) | (len1 << 27);           // nsym >= 1 here: the first codeword fits
         }
     }
-    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4 + mlut.size() * 4, &p); if (rc) return rc;
+    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4, &p); if (rc) return rc;
     uint32_t *d_lut = (uint32_t *)p;
     int32_t *d_child = (int32_t *)(d_lut + lut.size());
-    uint32_t *d_mlut = (uint32_t *)(d_child + child.size());
-    if (multi) RSN_HIP(hipMemcpyAsync(d_mlut, mlut.data(), mlut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
 
@@ -617,7 +622,6 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const unsigned long long n_sub64 = (a.end + SBITS - 1) / SBITS;
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
-    a.mlut = d_mlut;
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.child_n = (uint32_t)child.size(); a.min_len = codes.min_len;
     a.flat_guess = codes.min_len == codes.max_len;
     static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 96; }();
@@ -671,7 +675,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- D3
     a.blk_off = d_blk_off; a.out = d_out;
-    // (the multi-symbol table pays in the counting walk only: with byte stores per symbol the emit loop measured slower)
+    // (one symbol per lookup here: taking up to three and writing them with one unaligned 4-byte LDS store measured slower, 1.54 vs 1.29 ms)
     if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
