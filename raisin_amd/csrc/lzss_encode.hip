@@ -795,8 +795,8 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
         }
         bool mine = false;
         if (alive) {
-            uint32_t old = 0;
-            if (lane == 0) old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
+            // (issued by the whole wavefront on one address: the compiler's atomic optimiser turns it into one LDS atomic by the first lane)
+            const uint32_t old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
             mine = !((uni(old) >> (u_kp & 31)) & 1);                      // somebody else's already: that wavefront walks the rest
         }
         if (mine) {
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                 if (lane == 0) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
                 alive = false;
             } else {
-                if (lane == 0) a.keys[u_ipos] = best;
+                a.keys[u_ipos] = best;                                        // (all 64 lanes, one address: one request, and no exec-mask bookkeeping on the scalar unit)
                 u_next = u_kp + max(1u, best >> 16);                          // lzss.go:139-142: a reference skips size-1 positions
                 visits++;
 #ifdef RSN_CHAIN_STATS
