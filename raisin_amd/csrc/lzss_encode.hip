@@ -932,15 +932,18 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
 // the chain enters the tile and where it first lands beyond it; k_chain_verify accepts the whole stream iff each
 // tile's exit IS the next tile's entry (tile 0 entering at position 0) -- then the flags written here are the true
 // chain and the general parse is skipped; otherwise the general parse runs as before.
-template <class C>
+// CAP = claimed positions the block has room for.  Two instantiations run back to back: CAP = half of all positions
+// (34 KB of LDS, four blocks per CU) resolves every ordinary tile; a tile with more claims than that -- a stretch of
+// one- and two-byte steps -- is left to the second, full-size one (64 KB), which returns at once everywhere else.
+template <class C, int CAP>
 __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ dump, const uint32_t *__restrict__ keys, uint32_t E,
                                                     TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
     constexpr int CT = C::CT, CH = C::CH, NKP = CH + CT, NW = NKP / 32, TT = 512;
     constexpr uint32_t OUT = 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];
     __shared__ uint32_t s_pre[NW + 1];                                    // claimed positions before every bitmap word
-    __shared__ uint16_t s_pos[NKP], s_j0[NKP], s_j1[NKP];                 // per rank: its position; the rank 2^r steps on (two buffers)
-    __shared__ uint8_t s_bytes[NKP];                                      // per rank: bytes the position emits if it is on the chain
+    __shared__ uint16_t s_pos[CAP], s_j0[CAP], s_j1[CAP];                 // per rank: its position; the rank 2^r steps on (two buffers)
+    __shared__ uint8_t s_bytes[CAP];                                      // per rank: bytes the position emits if it is on the chain
     __shared__ uint32_t s_on[NW], s_flag[CT / 32];                        // ranks on the chain; the same as position bits of the tile
     __shared__ uint32_t s_part[TT / 64];
     __shared__ uint32_t s_entry, s_exit, s_nout;
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
     }
     __syncthreads();
     const uint32_t n_cl = s_pre[NW];
+    if (n_cl > (uint32_t)CAP) return;                                     // more claims than this instantiation holds: the full-size one takes the tile
     auto rank_of = [&](uint32_t p) { return s_pre[p >> 5] + (uint32_t)__builtin_popcount(s_claim[p >> 5] & ((1u << (p & 31)) - 1u)); };
     // the keys of the tile's NKP positions, 16 bytes per load (one position in five is claimed: scattered 4-byte loads
     // would touch every line anyway, one request each)
@@ -1553,7 +1557,8 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
         auto resolve = [&]() -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
-            RSN_LAUNCH("lzss_chain_tail", k_chain_tail<CC>, dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(1), dim3(1024), 0, s, d_tchain, n_pt, d_entry);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
             RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
