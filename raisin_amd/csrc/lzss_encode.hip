@@ -39,6 +39,7 @@ constexpr int MATCH_WAVES = 4;          // each takes a quarter of the diagonals
 constexpr int PT = 8192;                // positions per parse tile
 constexpr uint32_t MAX_WINDOW = 8192;
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_UNKNOWN = 0xFFFFFFFFu;                     // chain mode: no key evaluated for this position (the parse redoes the strip if the true chain lands here)
 
 // ------------------------------------------------------------------ E1: escape
 __device__ __forceinline__ uint32_t count_special16(const uint32_t w[4]) {
@@ -1072,6 +1073,34 @@ __global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restric
     }
 }
 
+// Only when the general parse has to take over: the chain walk wrote keys where a chain landed and nothing else
+// (the key array is not cleared beforehand -- that alone was a 4-byte store per position), so every position
+// without an exact key gets KEY_UNKNOWN here.  A position has one iff its tile was W-periodic, or its tile's
+// finished walk claimed it, or it lies in the next tile's warm-up zone and that tile's finished walk claimed it.
+// (A tile that gave up keeps none: its strip is redone for all positions anyway.)
+template <class C>
+__global__ __launch_bounds__(256) void k_chain_unknown(const uint8_t *__restrict__ dump, const TileChain *__restrict__ tchain, uint32_t n_tiles, uint32_t E,
+                                                       uint32_t *__restrict__ keys) {
+    constexpr int CT = C::CT, CH = C::CH;
+    static_assert(CH % 32 == 0 && CT % 32 == 0, "bitmap words line up with the tile");
+    __shared__ uint32_t s_known[CT / 32];
+    const int tid = threadIdx.x;
+    const uint32_t k = blockIdx.x;
+    const uint32_t w_own = tchain[k].walked, w_nxt = k + 1 < n_tiles ? tchain[k + 1].walked : 0u;
+    const uint32_t *own = reinterpret_cast<const uint32_t *>(dump + (size_t)k * C::DUMP_BYTES);
+    const uint32_t *nxt = reinterpret_cast<const uint32_t *>(dump + (size_t)(k + 1) * C::DUMP_BYTES);
+    for (int w = tid; w < CT / 32; w += 256) {
+        uint32_t m = w_own == 2 ? 0xFFFFFFFFu : w_own == 1 ? own[CH / 32 + w] : 0u;
+        if (w >= (CT - CH) / 32 && w_nxt == 1) m |= nxt[w - (CT - CH) / 32];
+        s_known[w] = m;
+    }
+    __syncthreads();
+    const size_t t0 = (size_t)k * CT;
+    const uint32_t npos = (uint32_t)min((size_t)CT, (size_t)E - t0);
+    for (uint32_t i = tid; i < npos; i += 256)
+        if (!((s_known[i >> 5] >> (i & 31)) & 1)) keys[t0 + i] = KEY_UNKNOWN;
+}
+
 __global__ __launch_bounds__(256) void k_chain_periodic(TileChain *__restrict__ tc, const uint32_t *__restrict__ prev, uint32_t n_tiles, uint32_t E, uint32_t W,
                                                         uint32_t tile, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
     const uint32_t k = blockIdx.x;
@@ -1533,8 +1562,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     bool parsed = false;                                              // flags + tile offsets + total are final
     if (chain_mode) {
         using CC = ChainCfg<8192, 1024, 128>;             // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
-        RSN_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)E * 4, s));
-        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
         void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
         uint8_t *d_dump = (uint8_t *)dp;
         ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump}};
@@ -1581,6 +1609,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             if (dbg) fprintf(stderr, "lzss chain walk, second look: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         }
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
+            RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, d_keys);
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
             RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
             rc = sweep(d_heavy); if (rc) return rc;
