@@ -42,8 +42,9 @@ constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code th
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
-constexpr int CHILD_LDS = 1024;     // child[] of a byte alphabet (<= 2 * 255 entries) is staged in LDS: a code longer than K bits
-                                    // costs LDS latency per extra bit instead of a global load (one wavefront in five hits one per step on skewed data)
+constexpr int CHILD_LDS = 256;      // child[] of a byte alphabet (<= 2 * 127 entries) is staged in LDS
+constexpr int LUT2_LDS = 768;       // second-level entries that fit in LDS (larger second levels are read through L2)
+constexpr uint32_t LUT2_GLOBAL_MAX = 1u << 20;   // entries of a second level kept in device memory (4 MB)
 constexpr uint32_t BAD_REL = 0xFFFF;
 constexpr uint32_t BAD_POS = 0xFFFFFFFFu;
 
@@ -61,6 +62,7 @@ struct DecArgs {
     int *changed; int pass;
     const unsigned long long *blk_off; uint8_t *out;   // D3
     uint32_t child_n;           // entries of child[]
+    const uint32_t *lut2; uint32_t lut2_n;   // second level: sub-tables for the K-bit prefixes that lead inside the tree
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return j + (j >> 5); }
@@ -129,23 +131,39 @@ __device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) {
 
 // One codeword at `pos`: returns the rune and advances pos.  No state is carried between
 // symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
-// Table entries.  Rune alphabets:  len << 24 | rune, or 0x80000000 | node when the code is longer than K bits.
+// Table entries.  Rune alphabets:  len << 24 | rune, or a LONG entry when the code is longer than K bits.
 // Byte alphabets (unified):        sym1 | sym2 << 7 | sym3 << 14 | bits of all n << 21 | n << 25 | bits of the first << 27
-//                                  (n = 1..3 whole codewords inside the window), or 0x80000000 | node.
+//                                  (n = 1..3 whole codewords inside the window), or a LONG entry.
+// LONG entry:                      0x80000000 | sb << 26 | x.  sb > 0: the next sb bits of the window index the
+//                                  2^sb-entry sub-table at lut2[x] (one more dependent lookup instead of one per bit);
+//                                  sb == 0: x is the tree node the K bits lead to, walked bit by bit.
+// Second-level entries:            len << 24 | rune (len counts all bits of the code), or 0x80000000 | node when the
+//                                  code is longer than K + sb bits still (the bit-by-bit walk goes on from there).
 __device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 21) & 15u; }
 __device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 25) & 3u; }
 __device__ __forceinline__ uint32_t u_len1(uint32_t e) { return (e >> 27) & 15u; }
 
+struct Lut2 { const uint32_t *lds; bool in_lds; };   // where the second level is (uniform per launch)
+
 template <bool ASCII, bool SHORT>
-__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos) {
-    const uint32_t ent = s_lut[((window32(s_data, pos) >> (32 - a.K)) << a.rep_log2) | lane_r];
+__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos, const Lut2 &l2) {
+    const uint32_t win = window32(s_data, pos);
+    const uint32_t ent = s_lut[((win >> (32 - a.K)) << a.rep_log2) | lane_r];
     if (SHORT || !(ent & 0x80000000u)) {
         if (ASCII) { pos += u_len1(ent); return ent & 0x7Fu; }
         pos += ent >> 24;
         return ent & 0x1FFFFFu;
     }
-    int32_t node = (int32_t)(ent & 0x7FFFFFFFu);
+    const uint32_t sb = (ent >> 26) & 31u;
+    int32_t node = (int32_t)(ent & 0x3FFFFFFu);
     uint32_t l = a.K, rune = 0;
+    if (sb) {
+        const uint32_t i2 = (ent & 0x3FFFFFFu) + ((win << a.K) >> (32 - sb));
+        const uint32_t e2 = l2.in_lds ? l2.lds[i2] : a.lut2[i2];
+        if (!(e2 & 0x80000000u)) { pos += e2 >> 24; return e2 & 0x1FFFFFu; }
+        node = (int32_t)(e2 & 0x7FFFFFFFu);
+        l += sb;
+    }
     for (;;) {
         const int32_t nxt = a.child[2 * node + bit_at(s_data, pos + l)];
         l++;
@@ -160,24 +178,30 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t 
 // Walk from block-relative bit `pos` to the first code boundary >= lim.  A code that runs past
 // the end of the payload can only be the last one of the walk: checked once, after the loop.
 template <bool ASCII, bool SHORT, bool MULTI>
-__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r,
-                                     uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
+__device__ __forceinline__ uint32_t advance(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, const Lut2 &l2,
+                                            uint32_t &pos, uint32_t lim) {
     uint32_t nb = 0;
     if (ASCII && MULTI) {
         // up to 3 codewords per table lookup while a whole K-bit step stays inside the subsequence
         const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
         while (pos <= safe && lim >= K) {
             const uint32_t e = s_lut[((window32(s_data, pos) >> (32 - K)) << a.rep_log2) | lane_r];
-            if (!SHORT && (e & 0x80000000u)) { (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos); nb++; }   // first code longer than K bits
+            if (!SHORT && (e & 0x80000000u)) { (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, l2); nb++; }   // first code longer than K bits
             else { pos += u_used(e); nb += u_n(e); }
         }
     }
     while (pos < lim) {
-        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos);
+        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, l2);
         nb += ASCII ? 1 : dev_utf8_len(r);
     }
+    return nb;
+}
+
+template <bool ASCII, bool SHORT, bool MULTI>
+__device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, const Lut2 &l2,
+                                     uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
+    *nbytes = advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, pos, lim);
     *exit_pos = pos > end_rel ? BAD_POS : pos;
-    *nbytes = nb;
 }
 
 template <bool ASCII, bool SHORT, bool MULTI>
@@ -188,11 +212,14 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
+    __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
     const int tid = threadIdx.x;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);   // once per (persistent) block
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
+    const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
+    if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
                 // codewords, so the first boundary at or after my0 is very likely the true entry
                 const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
                 uint32_t q = start;
-                while (q < my0) (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, q);
+                (void)advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, q, my0);   // (several codewords per lookup here too)
                 e = q;
             }
         } else {
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         for (int round = 0; round <= DB; round++) {
             if (live && !have) {
                 if (e == BAD_POS) { x = BAD_POS; nb = 0; }
-                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, e, lim, end_rel, &x, &nb);
+                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, e, lim, end_rel, &x, &nb);
                 have = true;
             }
             s_exit[tid] = x;
@@ -312,9 +339,9 @@ __device__ __forceinline__ void put_rune(uint32_t rune, Put put) {   // string(r
 // Decode loop of D3: entries are exact, so the walk never runs off the payload.
 template <bool ASCII, bool SHORT, class Put>
 __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut,
-                                          uint32_t lane_r, uint32_t pos, uint32_t lim, Put put) {
+                                          uint32_t lane_r, const Lut2 &l2, uint32_t pos, uint32_t lim, Put put) {
     while (pos < lim) {
-        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos);
+        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, l2);
         if (ASCII) put(r); else put_rune(r, put);
     }
 }
@@ -326,11 +353,15 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
+    __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
     stage_lut(a, s_lut);
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
+    const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
+    if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
+    if (ASCII) for (int i = tid; i < (OUT_STAGE + 32) / 16; i += DB) reinterpret_cast<uint4 *>(s_out)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -351,15 +382,40 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
         uint8_t *dst = a.out + a.blk_off[blk];
         const uint32_t al = (uint32_t)((uintptr_t)dst & 15);      // LDS image is shifted so that 16-byte units line up with global memory
         const bool staged = total + al <= OUT_STAGE;              // uniform per block
-        if (live && er != BAD_REL && nb != 0) {
+        if (ASCII && staged) {
+            // Byte alphabets: the lane knows how many symbols it owes (nb), so the walk is count-driven and takes up to
+            // three codewords per table lookup to the very end; the bytes collect in a 64-bit register and leave as
+            // aligned 4-byte LDS ORs into the zeroed image -- the words two lanes share need no special case.
+            if (live && er != BAD_REL && nb != 0) {
+                const uint32_t o0 = al + my_off;
+                uint32_t *o = reinterpret_cast<uint32_t *>(s_out) + (o0 >> 2);
+                uint32_t cnt = o0 & 3, remaining = nb, pos = my0 + er;
+                unsigned long long acc = 0;
+                const uint32_t K = (uint32_t)a.K;
+                while (remaining) {
+                    const uint32_t e = s_lut[((window32(s_data, pos) >> (32 - K)) << a.rep_log2) | lane_r];
+                    uint32_t bytes, take, used;
+                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos; bytes = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, q, l2); take = 1; used = q - pos; }
+                    else {
+                        bytes = (e & 0x7Fu) | ((e << 1) & 0x7F00u) | ((e << 2) & 0x7F0000u);
+                        take = min(u_n(e), remaining);                    // (the last lookup may list more codewords than the lane owes:
+                        used = u_used(e);                                 //  whatever lies above `cnt` bytes is never stored, pos is dead by then)
+                    }
+                    acc |= (unsigned long long)bytes << (8 * cnt);
+                    cnt += take; remaining -= take; pos += used;
+                    if (cnt >= 4) { atomicOr(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
+                }
+                if (cnt) atomicOr(o, (uint32_t)acc & (0xFFFFFFFFu >> (32 - 8 * cnt)));
+            }
+        } else if (live && er != BAD_REL && nb != 0) {
             if (staged) {
                 uint8_t *o = s_out + al + my_off;
                 uint32_t pos = my0 + er;
-                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, l2, pos, lim, [&](uint32_t b) { *o++ = (uint8_t)b; });
             } else {
                 Sink sink;
                 sink.start(dst + my_off);
-                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
+                emit_walk<ASCII, SHORT>(a, s_data, s_lut, lane_r, l2, my0 + er, lim, [&](uint32_t b) { sink.put(b); });
                 sink.finish();
             }
         }
@@ -371,6 +427,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
             const uint32_t b0 = u * 16;
             if (b0 >= al && b0 + 16 <= span) *reinterpret_cast<uint4 *>(gbase + b0) = *reinterpret_cast<const uint4 *>(s_out + b0);
             else for (uint32_t k = max(b0, al); k < min(b0 + 16, span); k++) gbase[k] = s_out[k];
+            if (ASCII) *reinterpret_cast<uint4 *>(s_out + b0) = make_uint4(0, 0, 0, 0);   // the ORs of the next block need a zeroed image
         }
     }
 }
@@ -486,6 +543,55 @@ void build_tables(const HuffTree &t, int K, std::vector<uint32_t> &lut, std::vec
             st.push_back({t.right[it.node], (it.prefix << 1) | 1, it.depth + 1});
             st.push_back({t.left[it.node], it.prefix << 1, it.depth + 1});
         }
+    }
+}
+
+// Second level: every K-bit prefix that ends INSIDE the tree gets a sub-table indexed by the next sb bits, sb = the
+// depth of the sub-tree below it, capped so that (a) K + sb <= 32 (the index comes out of the same 32-bit window) and
+// (b) all sub-tables together fit the budget: LDS if the whole sub-trees fit there (byte alphabets: always LDS, as
+// deep as it allows), else LUT2_GLOBAL_MAX entries read through L2 (rune alphabets with 10^5 symbols: half the symbols
+// are longer than K bits and child[] is far too large for LDS).  Codes deeper than K + sb continue bit by bit.
+void build_second_level(const std::vector<int32_t> &child, int K, bool byte_alphabet, std::vector<uint32_t> &lut, std::vector<uint32_t> &lut2) {
+    lut2.clear();
+    const size_t n_int = child.size() / 2;
+    std::vector<uint8_t> depth(n_int, 0);                          // bits from an internal node to its deepest leaf (children precede parents)
+    for (size_t i = 0; i < n_int; i++) {
+        unsigned d = 0;
+        for (int b = 0; b < 2; b++) { const int32_t k = child[2 * i + b]; d = std::max(d, k < 0 ? 1u : 1u + depth[(size_t)k]); }
+        depth[i] = (uint8_t)std::min(d, 255u);
+    }
+    std::vector<uint32_t> longs;
+    for (uint32_t v = 0; v < (1u << K); v++) if (lut[v] & 0x80000000u) longs.push_back(v);
+    if (longs.empty()) return;
+    auto total = [&](unsigned cap) { uint64_t t = 0; for (uint32_t v : longs) t += 1ull << std::min<unsigned>(depth[lut[v] & 0x3FFFFFFu], cap); return t; };
+    unsigned cap = 32u - (unsigned)K;
+    if (total(cap) > (uint64_t)LUT2_LDS) {
+        const uint64_t budget = byte_alphabet ? (uint64_t)LUT2_LDS : (uint64_t)LUT2_GLOBAL_MAX;
+        while (cap > 0 && total(cap) > budget) cap--;
+    }
+    if (cap == 0) return;                                          // (the entries stay "node, walked bit by bit")
+    struct It { int32_t node; uint32_t prefix; unsigned q; };
+    std::vector<It> st;
+    for (uint32_t v : longs) {
+        const int32_t top = (int32_t)(lut[v] & 0x3FFFFFFu);
+        const unsigned sb = std::min<unsigned>(depth[(size_t)top], cap);
+        const uint32_t off = (uint32_t)lut2.size();
+        lut2.resize(lut2.size() + ((size_t)1 << sb));
+        st.push_back({top, 0, 0});
+        while (!st.empty()) {
+            const It it = st.back();
+            st.pop_back();
+            if (it.q == sb) { lut2[off + it.prefix] = 0x80000000u | (uint32_t)it.node; continue; }   // still inside the tree after K + sb bits
+            for (int b = 0; b < 2; b++) {
+                const int32_t k = child[2 * (size_t)it.node + b];
+                const uint32_t pre = (it.prefix << 1) | (uint32_t)b;
+                if (k >= 0) { st.push_back({k, pre, it.q + 1}); continue; }
+                const uint32_t ent = ((uint32_t)(K + it.q + 1) << 24) | (uint32_t)(-(k + 1));
+                const unsigned rest = sb - (it.q + 1);
+                for (uint32_t x = 0; x < (1u << rest); x++) lut2[off + (pre << rest) + x] = ent;
+            }
+        }
+        lut[v] = 0x80000000u | (sb << 26) | off;
     }
 }
 
@@ -609,11 +715,18 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             lut[v] = syms | (used << 21) | (nsym << 25) | (len1 << 27);           // nsym >= 1 here: the first codeword fits
         }
     }
-    rc = dev_buf(c, 5, lut.size() * 4 + child.size() * 4, &p); if (rc) return rc;
+    std::vector<uint32_t> lut2;
+    static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
+    if (!short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
+    static const bool dbg = getenv("RSN_DEC_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "huffman decode tables: K %d, longest code %u, %zu tree nodes, second level %zu entries (%s)\n", K, codes.max_len, child.size() / 2, lut2.size(), lut2.size() <= (size_t)LUT2_LDS ? "LDS" : "L2");
+    rc = dev_buf(c, 5, (lut.size() + child.size() + lut2.size()) * 4 + 64, &p); if (rc) return rc;
     uint32_t *d_lut = (uint32_t *)p;
     int32_t *d_child = (int32_t *)(d_lut + lut.size());
+    uint32_t *d_lut2 = (uint32_t *)(d_child + child.size());
     RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
     RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
+    if (!lut2.empty()) RSN_HIP(hipMemcpyAsync(d_lut2, lut2.data(), lut2.size() * 4, hipMemcpyHostToDevice, s));
 
     DecArgs a{};
     a.base = d_in + A0; a.nbytes = n - A0;
@@ -623,6 +736,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.child_n = (uint32_t)child.size(); a.min_len = codes.min_len;
+    a.lut2 = d_lut2; a.lut2_n = (uint32_t)lut2.size();
     a.flat_guess = codes.min_len == codes.max_len;
     static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 96; }();
     a.warm = std::min(std::max(warm_env, 0), ORG - 32);
