@@ -77,7 +77,10 @@ __device__ __forceinline__ void stage_lut(const DecArgs &a, uint32_t *s_lut) {
     for (int i = threadIdx.x; i < total; i += DB) s_lut[i] = a.lut[i >> a.rep_log2];
 }
 
-// Stages payload words [w0, w0+DATA_WORDS) as big-endian words into the grouped LDS image.
+// Stages payload words [w0, w0+DATA_WORDS) into the grouped LDS image, LSB-FIRST: stream bit k of a word sits at bit k
+// (bytes in memory order, the bits of every byte reversed), so that the 32 stream bits from any position are one
+// v_alignbit_b32 of two adjacent dwords and a table index is a plain AND -- the tables are stored bit-reversed to match.
+__device__ __forceinline__ uint32_t lsb_first(uint32_t le_word) { return __builtin_bitreverse32(__builtin_bswap32(le_word)); }
 // Interior blocks take a branch-free path: all 16-byte loads are issued before the first use.
 __device__ __forceinline__ void put_word(uint32_t *s_data, uint32_t j, uint32_t v) {
     const uint32_t p = grp(j);
@@ -99,9 +102,9 @@ __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint3
             const int idx = threadIdx.x + k * DB;
             if (idx < NV) {
                 const uint32_t j = 4 * idx, pj = grp(j);   // 4 consecutive words never straddle a group
-                const uint32_t x = __builtin_bswap32(v[k].x);
-                s_data[pj] = x; s_data[pj + 1] = __builtin_bswap32(v[k].y);
-                s_data[pj + 2] = __builtin_bswap32(v[k].z); s_data[pj + 3] = __builtin_bswap32(v[k].w);
+                const uint32_t x = lsb_first(v[k].x);
+                s_data[pj] = x; s_data[pj + 1] = lsb_first(v[k].y);
+                s_data[pj + 2] = lsb_first(v[k].z); s_data[pj + 3] = lsb_first(v[k].w);
                 if ((j & 7) == 0 && j) s_data[pj - 1] = x;
             }
         }
@@ -112,22 +115,23 @@ __device__ __forceinline__ void stage_data(const DecArgs &a, uint32_t blk, uint3
         uint32_t v = 0;
         if (w >= 0) {
             const size_t off = (size_t)w * 4;
-            if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
-            else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (24 - 8 * k);
+            if (off + 4 <= a.nbytes) v = *reinterpret_cast<const uint32_t *>(a.base + off);
+            else for (int k = 0; k < 4; k++) if (off + k < a.nbytes) v |= (uint32_t)a.base[off + k] << (8 * k);
         }
-        put_word(s_data, (uint32_t)i, v);
+        put_word(s_data, (uint32_t)i, lsb_first(v));
     }
 }
 
 __device__ __forceinline__ int dev_utf8_len(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
 
-// The 32 stream bits that start at block-relative bit `pos`: two adjacent dwords, one 64-bit shift.
+// The 32 stream bits that start at block-relative bit `pos` (the first one in bit 0): two adjacent dwords, one funnel shift.
 __device__ __forceinline__ uint32_t window32(const uint32_t *s_data, uint32_t pos) {
     const uint32_t p = grp(pos >> 5);
-    const unsigned long long v = (((unsigned long long)s_data[p] << 32) | s_data[p + 1]) << (pos & 31);
-    return (uint32_t)(v >> 32);
+    return __builtin_amdgcn_alignbit(s_data[p + 1], s_data[p], pos & 31);
 }
-__device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) { return (s_data[grp(q >> 5)] >> (31 - (q & 31))) & 1; }
+__device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) { return (s_data[grp(q >> 5)] >> (q & 31)) & 1; }
+// Index of the first-level table entry for a window (the lane's own copy of it when the table is replicated).
+__device__ __forceinline__ uint32_t lut_index(const DecArgs &a, uint32_t win, uint32_t lane_r) { return ((win & ((1u << a.K) - 1u)) << a.rep_log2) | lane_r; }
 
 // One codeword at `pos`: returns the rune and advances pos.  No state is carried between
 // symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
@@ -139,26 +143,19 @@ __device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) {
 //                                  sb == 0: x is the tree node the K bits lead to, walked bit by bit.
 // Second-level entries:            len << 24 | rune (len counts all bits of the code), or 0x80000000 | node when the
 //                                  code is longer than K + sb bits still (the bit-by-bit walk goes on from there).
-__device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 21) & 15u; }
-__device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 25) & 3u; }
+__host__ __device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 21) & 15u; }
+__host__ __device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 25) & 3u; }
 __device__ __forceinline__ uint32_t u_len1(uint32_t e) { return (e >> 27) & 15u; }
 
 struct Lut2 { const uint32_t *lds; bool in_lds; };   // where the second level is (uniform per launch)
 
-template <bool ASCII, bool SHORT>
-__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos, const Lut2 &l2) {
-    const uint32_t win = window32(s_data, pos);
-    const uint32_t ent = s_lut[((win >> (32 - a.K)) << a.rep_log2) | lane_r];
-    if (SHORT || !(ent & 0x80000000u)) {
-        if (ASCII) { pos += u_len1(ent); return ent & 0x7Fu; }
-        pos += ent >> 24;
-        return ent & 0x1FFFFFu;
-    }
+// A codeword longer than K bits: `ent` is the LONG entry its first K bits led to, `win` the 32 stream bits from pos.
+__device__ __forceinline__ uint32_t decode_long(const DecArgs &a, const uint32_t *s_data, uint32_t win, uint32_t ent, uint32_t &pos, const Lut2 &l2) {
     const uint32_t sb = (ent >> 26) & 31u;
     int32_t node = (int32_t)(ent & 0x3FFFFFFu);
     uint32_t l = a.K, rune = 0;
     if (sb) {
-        const uint32_t i2 = (ent & 0x3FFFFFFu) + ((win << a.K) >> (32 - sb));
+        const uint32_t i2 = (ent & 0x3FFFFFFu) + __builtin_amdgcn_ubfe(win, (uint32_t)a.K, sb);
         const uint32_t e2 = l2.in_lds ? l2.lds[i2] : a.lut2[i2];
         if (!(e2 & 0x80000000u)) { pos += e2 >> 24; return e2 & 0x1FFFFFu; }
         node = (int32_t)(e2 & 0x7FFFFFFFu);
@@ -175,6 +172,18 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t 
     return rune;
 }
 
+template <bool ASCII, bool SHORT>
+__device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos, const Lut2 &l2) {
+    const uint32_t win = window32(s_data, pos);
+    const uint32_t ent = s_lut[lut_index(a, win, lane_r)];
+    if (SHORT || !(ent & 0x80000000u)) {
+        if (ASCII) { pos += u_len1(ent); return ent & 0x7Fu; }
+        pos += ent >> 24;
+        return ent & 0x1FFFFFu;
+    }
+    return decode_long(a, s_data, win, ent, pos, l2);
+}
+
 // Walk from block-relative bit `pos` to the first code boundary >= lim.  A code that runs past
 // the end of the payload can only be the last one of the walk: checked once, after the loop.
 template <bool ASCII, bool SHORT, bool MULTI>
@@ -185,7 +194,7 @@ __device__ __forceinline__ uint32_t advance(const DecArgs &a, const uint32_t *s_
         // up to 3 codewords per table lookup while a whole K-bit step stays inside the subsequence
         const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
         while (pos <= safe && lim >= K) {
-            const uint32_t e = s_lut[((window32(s_data, pos) >> (32 - K)) << a.rep_log2) | lane_r];
+            const uint32_t e = s_lut[lut_index(a, window32(s_data, pos), lane_r)];
             if (!SHORT && (e & 0x80000000u)) { (void)decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, l2); nb++; }   // first code longer than K bits
             else { pos += u_used(e); nb += u_n(e); }
         }
@@ -391,11 +400,11 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                 uint32_t *o = reinterpret_cast<uint32_t *>(s_out) + (o0 >> 2);
                 uint32_t cnt = o0 & 3, remaining = nb, pos = my0 + er;
                 unsigned long long acc = 0;
-                const uint32_t K = (uint32_t)a.K;
                 while (remaining) {
-                    const uint32_t e = s_lut[((window32(s_data, pos) >> (32 - K)) << a.rep_log2) | lane_r];
+                    const uint32_t win = window32(s_data, pos);
+                    const uint32_t e = s_lut[lut_index(a, win, lane_r)];
                     uint32_t bytes, take, used;
-                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos; bytes = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, q, l2); take = 1; used = q - pos; }
+                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q - pos; }
                     else {
                         bytes = (e & 0x7Fu) | ((e << 1) & 0x7F00u) | ((e << 2) & 0x7F0000u);
                         take = min(u_n(e), remaining);                    // (the last lookup may list more codewords than the lane owes:
@@ -718,6 +727,19 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     std::vector<uint32_t> lut2;
     static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
     if (!short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
+    {   // the device reads the stream LSB-first: entry v moves to the index with v's K bits reversed; sub-tables likewise
+        auto rev = [](uint32_t v, unsigned bits) { return bits ? __builtin_bitreverse32(v) >> (32 - bits) : 0u; };
+        std::vector<uint32_t> t(lut.size());
+        for (uint32_t v = 0; v < (1u << K); v++) t[rev(v, (unsigned)K)] = lut[v];
+        lut.swap(t);
+        t.assign(lut2.size(), 0);
+        for (uint32_t v = 0; v < (1u << K); v++) {
+            const uint32_t e = lut[v], sb = (e >> 26) & 31u, off = e & 0x3FFFFFFu;
+            if (!(e & 0x80000000u) || !sb || lut2.empty()) continue;
+            for (uint32_t u = 0; u < (1u << sb); u++) t[off + rev(u, sb)] = lut2[off + u];
+        }
+        lut2.swap(t);
+    }
     static const bool dbg = getenv("RSN_DEC_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "huffman decode tables: K %d, longest code %u, %zu tree nodes, second level %zu entries (%s)\n", K, codes.max_len, child.size() / 2, lut2.size(), lut2.size() <= (size_t)LUT2_LDS ? "LDS" : "L2");
     rc = dev_buf(c, 5, (lut.size() + child.size() + lut2.size()) * 4 + 64, &p); if (rc) return rc;
@@ -789,7 +811,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- D3
     a.blk_off = d_blk_off; a.out = d_out;
-    // (one symbol per lookup here: taking up to three and writing them with one unaligned 4-byte LDS store measured slower, 1.54 vs 1.29 ms)
+    // (8-byte table entries with the symbols already spread to bytes measured slower than unpacking the 4-byte ones: 1.19 vs 0.98 ms)
     if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
