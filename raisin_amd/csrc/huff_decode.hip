@@ -27,6 +27,7 @@
 // bit-by-bit walk of the tree's child array (staged in LDS for byte alphabets).  One table instead of r1's
 // two (single + multi) is what lets seven blocks share a CU in the counting pass instead of four: the walks
 // are bound by the latency of their own dependent LDS reads, i.e. by how many wavefronts are there to hide it.
+#include <chrono>
 #include "codecs.h"
 
 namespace rsn {
@@ -642,10 +643,18 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         memcpy(head.data() + old, hpin, sep + 3 - old);
     }
     std::vector<HuffSym> syms; std::string msg;
+    static const bool host_timing = getenv("RSN_HOST_TIMING") != nullptr;   // prints where the host side of a call spends its time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     if (!parse_header(head.data(), sep, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
+    const auto t1 = now();
     HuffTree tree; HuffCodes codes;
     if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
+    const auto t2 = now();
     if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    const auto t3 = now();
+    if (host_timing) fprintf(stderr, "huffman decode host: header of %zu bytes parsed in %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n", sep, ms(t0, t1), ms(t1, t2), ms(t2, t3), syms.size());
 
     const size_t sn = n - sep - 2;                       // bytes after the separator
     const unsigned diff = sn ? head[sep + 2] : 0;         // byteArr[0] (huffman.go:275)
@@ -740,6 +749,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         }
         lut2.swap(t);
     }
+    if (host_timing) fprintf(stderr, "huffman decode host: tables %.2f ms (second level %zu entries)\n", ms(t3, now()), lut2.size());
     static const bool dbg = getenv("RSN_DEC_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "huffman decode tables: K %d, longest code %u, %zu tree nodes, second level %zu entries (%s)\n", K, codes.max_len, child.size() / 2, lut2.size(), lut2.size() <= (size_t)LUT2_LDS ? "LDS" : "L2");
     rc = dev_buf(c, 5, (lut.size() + child.size() + lut2.size()) * 4 + 64, &p); if (rc) return rc;

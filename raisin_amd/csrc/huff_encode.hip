@@ -18,6 +18,7 @@
 // Bit layout (huffman.go:245-255): out = header || "\\\n" || byte(pad) || bytes(0^pad || S),
 // S MSB-first.  The kernels treat `out` as one big-endian bit string whose first
 // code bit sits at bit 8*(hdr+3)+pad; tile t starts at that plus tile_off[t].
+#include <chrono>
 #include <cstddef>
 
 #include "huff_host.h"
@@ -762,13 +763,23 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
 
     std::vector<HuffSym> syms;
     bool ascii;
+    static const bool host_timing = getenv("RSN_HOST_TIMING") != nullptr;   // prints where the host side of a call spends its time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, d_tile_hist, syms, ascii); if (rc) return rc;
+    const auto t1 = now();
 
     std::string hdr;
     emit_header(syms, hdr);   // syms is ascending by rune here
+    const auto t2 = now();
     HuffTree tree; HuffCodes codes; std::string msg;
     if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
+    const auto t3 = now();
     if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    const auto t4 = now();
+    if (host_timing) fprintf(stderr, "huffman encode host: histogram (kernels + D2H + compaction) %.2f ms, header %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n",
+                             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), syms.size());
     if (tree_out) *tree_out = tree;
     if (codes_out) *codes_out = codes;
     if (!d_out) return RSN_OK;   // table introspection only
