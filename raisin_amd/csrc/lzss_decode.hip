@@ -660,6 +660,13 @@ __global__ __launch_bounds__(ZB) void k_une_count(const uint8_t *__restrict__ es
     if (threadIdx.x == 0) blk_len[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
 }
 
+// 0xFF in every byte of w that equals the byte `c` (exact per byte)
+__device__ __forceinline__ uint32_t une_bytes_equal(uint32_t w, uint32_t c) {
+    const uint32_t t = w ^ (c * 0x01010101u);
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+    return (z >> 7) * 0xFFu;
+}
+
 // the block's output is contiguous: bytes go to LDS first, then out in 16-byte units
 __global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ esc, uint32_t E, const uint8_t *__restrict__ in_par,
                                                   const unsigned long long *__restrict__ blk_off, uint8_t *__restrict__ out) {
@@ -681,6 +688,18 @@ __global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ es
     __syncthreads();
     uint32_t pre = 0, tot = 0;
     for (int k = 0; k < ZB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
+    uint8_t *const g0 = out + blk_off[blockIdx.x];
+    {   // no escape marker anywhere in the block (most blocks of most files): every byte keeps its place, FF becomes '<'
+        const bool plain = st0 == 0 && !(une_bytes_equal(w[0], 0x5Cu) | une_bytes_equal(w[1], 0x5Cu) | une_bytes_equal(w[2], 0x5Cu) | une_bytes_equal(w[3], 0x5Cu));
+        if (__syncthreads_and(plain) && ((uintptr_t)g0 & 3) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint32_t m = une_bytes_equal(w[j], 0xFFu); w[j] = (w[j] & ~m) | (0x3C3C3C3Cu & m); }
+            uint8_t *d = g0 + tid * 16;
+            if (len == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);   // (a 16-byte store only needs dword alignment)
+            else for (uint32_t k = 0; k < len; k++) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            return;
+        }
+    }
     uint8_t *so = reinterpret_cast<uint8_t *>(s_out);
     uint32_t o = pre + incl - cnt;
     st = st0;

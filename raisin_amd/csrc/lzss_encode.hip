@@ -51,6 +51,13 @@ __device__ __forceinline__ uint32_t count_special16(const uint32_t w[4]) {
     return c;
 }
 
+// 0xFF in every byte of w that equals the byte `c` (exact per byte: no borrow crosses a byte boundary)
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t w, uint32_t c) {
+    const uint32_t t = w ^ (c * 0x01010101u);
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 where the byte of t is zero
+    return (z >> 7) * 0xFFu;
+}
+
 __device__ __forceinline__ void load16(const uint8_t *in, size_t n, size_t P, uint32_t w[4], int *cnt) {
     w[0] = w[1] = w[2] = w[3] = 0;
     if (P + 16 <= n) {
@@ -109,6 +116,16 @@ __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in
     uint8_t *dst = fc + (size_t)blockIdx.x * ESC_TILE + blk_off[blockIdx.x];
     const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
     const uint32_t total = (uint32_t)min((size_t)ESC_TILE, n - (size_t)blockIdx.x * ESC_TILE) + extra;
+    if (extra == 0 && (al & 3) == 0) {
+        // no byte of the block needs an escape (most blocks of most files): every byte keeps its place, '<' becomes FF
+        // (lzss.go:373-377); a 16-byte store only needs dword alignment
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] |= bytes_equal(w[j], 0x3Cu);
+        uint8_t *d = dst + tid * 16;
+        if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+        else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        return;
+    }
     uint8_t *o = s_img + al + tid * 16 + pre + incl - c;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
