@@ -291,14 +291,12 @@ __global__ __launch_bounds__(ZB) void k_lzd_gather(const uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------ L2: tile path
-constexpr int DT = 16384;               // escaped-stream bytes per resolve tile
+constexpr int DT = 16384;               // escaped-stream bytes per resolve tile (8192 with twice the tiles per group: resolve 7 % faster, compose + chain 2x slower)
 constexpr int DTH = 1024;               // threads of the tile kernels: 16 bytes per lane
 constexpr int DGRP = 128;               // tiles per chain group (the serial chain walks E / (DT * DGRP) links)
 constexpr uint32_t D_LOC = 0x4000u;     // descriptor: position inside the tile
 constexpr uint32_t D_EXT = 0x8000u;     // descriptor: position inside the previous tile's tail; otherwise the literal byte
 constexpr uint32_t D_PAY = 0x3FFFu;
-constexpr int D_BIG = 12;               // longer tokens are expanded by the whole block
-constexpr int D_NBIG = DT / D_BIG + 2;
 static_assert(DT / 16 == DTH && DT <= 16384, "one 16-byte span per lane; 14-bit payload");
 
 // validate every token (lzss.go:349-350), record the largest back-pointer and, for every output
@@ -356,16 +354,21 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
     if (e) atomicOr(err, 1);
 }
 
-struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback; };
+struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback;
+                     unsigned long long *stats; };   // RSN_LZD_STATS: cycles per phase, summed over blocks
 
 __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 waves per SIMD: two blocks per CU
     __shared__ __attribute__((aligned(16))) uint32_t sw[(DT + 128) / 4 + 8];
     __shared__ __attribute__((aligned(16))) uint16_t sd[DT];
     __shared__ uint32_t masks[DTH + 2];
     __shared__ uint32_t s_part[DTH / 64];
-    __shared__ uint32_t s_big[D_NBIG * 3];
-    __shared__ uint32_t s_nbig;
+    __shared__ uint32_t s_wlast[DTH / 64];
+    constexpr uint32_t NONE = 0xFFFFu;                                    // "no item starts here" (both type bits set: never a descriptor)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long t_prev = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+    auto phase_done = [&](int q) {                                        // RSN_LZD_STATS: cycles of the phase that just ended (thread 0's view)
+        if (a.stats) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&a.stats[q], now - t_prev); t_prev = now; }
+    };
     const uint32_t k = blockIdx.x, ts = k * DT;
     const int tlen = (int)min((uint32_t)DT, a.E - ts);
     const uint2 info = a.tile_info[k];
@@ -381,14 +384,16 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         else if (P < a.n) { uint32_t w[4] = {0, 0, 0, 0}; for (int q = 0; q < 16 && P + q < a.n; q++) w[q >> 2] |= (uint32_t)a.in[P + q] << (8 * (q & 3)); x = {w[0], w[1], w[2], w[3]}; }
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
-    if (tid == 0) s_nbig = 0;
+    for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
     __syncthreads();
+    phase_done(0);
     const int TL = (int)a.TL;
-    auto token_desc = [&](int x, uint32_t ptr) -> uint16_t {              // source of output byte x of a token with this back-pointer
+    auto token_desc = [&](int x, uint32_t ptr) -> uint32_t {              // source of output byte x of a token with this back-pointer
         const int q = x - (int)ptr;
-        return (uint16_t)(q >= 0 ? (D_LOC | (uint32_t)q) : (D_EXT | (uint32_t)(TL + q)));
+        return q >= 0 ? (D_LOC | (uint32_t)q) : (D_EXT | (uint32_t)(TL + q));
     };
-    // every token here has len <= ptr <= DT (k_lzd_tiles checked it), so 32-bit offsets cannot overflow
+    // ---- A: every item marks the output position it starts at -- a literal with its byte, a token with D_LOC | (ptr - 1).
+    // every token here has 1 <= len <= ptr <= DT (k_lzd_tiles checked it), so 32-bit offsets cannot overflow
     int run = (int)((long long)info.y - (long long)ts);                   // output offset (relative to the tile) of the first staged item: <= 0
     for (int base = 0; lo + 16 * base < hi; base += DTH) {
         const int sp = base + tid, sbyte = lo + 16 * sp;
@@ -426,11 +431,8 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
                 if ((uint32_t)q < r.ntok) {
                     const int x0 = o + __builtin_popcount(r.lit & ((1u << r.tj[q]) - 1u)) + before;
                     const uint32_t ptr = r.tptr[q], len = r.tlen[q];
-                    if (len > D_BIG) {
-                        if (x0 + (int)len > 0 && x0 < tlen) { const uint32_t b = atomicAdd(&s_nbig, 1u); s_big[3 * b] = (uint32_t)x0; s_big[3 * b + 1] = ptr; s_big[3 * b + 2] = len; }
-                    } else {
-                        for (int j = 0; j < (int)len; j++) { const int x = x0 + j; if (x >= 0 && x < tlen) sd[x] = token_desc(x, ptr); }
-                    }
+                    const int xs = max(x0, 0);                            // a token that began in the previous tile: its first byte HERE
+                    if (len && x0 + (int)len > 0 && xs < tlen) sd[xs] = (uint16_t)(D_LOC | (ptr - 1u));
                     before += (int)len;
                 }
             }
@@ -438,21 +440,76 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         run += (int)tot;
     }
     __syncthreads();
-    for (uint32_t b = wv; b < s_nbig; b += DTH / 64) {                    // one wavefront per long token
-        const int o = (int)s_big[3 * b]; const uint32_t ptr = s_big[3 * b + 1], len = s_big[3 * b + 2];
-        const int x0 = max(o, 0), x1 = min(o + (int)len, tlen);
-        for (int x = x0 + lane; x < x1; x += 64) sd[x] = token_desc(x, ptr);
+    phase_done(1);
+    // ---- B: a lane owns 16 consecutive output positions.  The item a position belongs to is the last mark at or before it
+    // (fill forward: a scan with "rightmost mark" inside the lane, across the wavefront, across the block), and a token's
+    // bytes get their descriptor from the position and the token's back-pointer alone.
+    const int xb = 16 * tid;
+    uint32_t pk[8];
+    {
+        const uint4 v0 = reinterpret_cast<const uint4 *>(sd + xb)[0], v1 = reinterpret_cast<const uint4 *>(sd + xb)[1];
+        pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
     }
+    uint32_t mylast = NONE;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const uint32_t val = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; mylast = val != NONE ? val : mylast; }
+    uint32_t incl = mylast;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d && incl == NONE) incl = y; }
+    if (lane == 63) s_wlast[wv] = incl;
+    uint32_t cur = __shfl_up(incl, 1);
+    if (lane == 0) cur = NONE;
     __syncthreads();
-    for (;;) {                                                            // in-tile pointer jumping, all in LDS
-        bool any = false;
-        for (int x = tid; x < tlen; x += DTH) {
-            const uint32_t v = sd[x];
-            if ((v >> 14) == 1) { const uint32_t w = sd[v & D_PAY]; sd[x] = (uint16_t)w; any = any || (w >> 14) == 1; }
-        }
-        if (!__syncthreads_or(any)) break;
+    if (cur == NONE) for (int w = wv - 1; w >= 0; w--) { const uint32_t y = s_wlast[w]; if (y != NONE) { cur = y; break; } }
+    uint32_t dsc[16];
+    uint32_t unres = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t val = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        cur = val != NONE ? val : cur;
+        const int x = xb + j;
+        uint32_t d = 0;                                                   // (a position no item covers cannot occur in a validated stream)
+        if ((cur & 0xC000u) == D_LOC) d = token_desc(x, (cur & D_PAY) + 1u);
+        else if (cur != NONE) d = cur;                                    // a literal
+        if (x >= tlen) d = 0;
+        dsc[j] = d;
+        unres |= ((d >> 14) == 1u ? 1u : 0u) << j;
     }
+    auto write_back = [&]() {
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = dsc[2 * j] | (dsc[2 * j + 1] << 16);
+        reinterpret_cast<uint4 *>(sd + xb)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    };
+    __syncthreads();                                                      // every lane has read its marks
+    write_back();
+    __syncthreads();
+    phase_done(2);
+    // ---- C: in-tile pointer jumping, the lane's 16 descriptors in registers; only the unresolved ones read LDS, two hops a round.
+    // (A reader may see another lane's descriptor before or after that lane's update of the same round: both name the same byte.
+    //  Giving lane t the positions t, t + DTH, ... instead -- consecutive lanes on consecutive addresses -- measured slower.)
+    uint32_t rounds = 0;
+    for (;;) {
+        rounds++;
+        if (unres) {
+#pragma unroll
+            for (int hop = 0; hop < 2; hop++) {                           // all 16 reads of a hop are issued together
+                uint32_t w[16];                                           // (a resolved slot reads sd[0] with everybody else: a broadcast)
+#pragma unroll
+                for (int j = 0; j < 16; j++) w[j] = sd[(unres >> j) & 1 ? (dsc[j] & D_PAY) : 0u];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((unres >> j) & 1) { dsc[j] = w[j]; if ((w[j] >> 14) != 1u) unres &= ~(1u << j); }
+                }
+            }
+            write_back();
+        }
+        if (!__syncthreads_or(unres != 0)) break;
+    }
+    phase_done(3);
     for (int v = tid; v * 8 < tlen; v += DTH) reinterpret_cast<uint4 *>(a.desc + ts)[v] = reinterpret_cast<const uint4 *>(sd)[v];
+    phase_done(4);
+    if (a.stats && tid == 0) atomicAdd(&a.stats[5], (unsigned long long)rounds);
 }
 
 // C_g = the tail map of the group's last tile expressed in the tail that precedes the group
@@ -777,8 +834,17 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         rc = dev_buf(c, 22, (size_t)n_groups * TL * 3 + 64, &p); if (rc) return rc;
         uint16_t *d_comp = (uint16_t *)p;
         uint8_t *d_gtail = (uint8_t *)(d_comp + (size_t)n_groups * TL);
-        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback};
+        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr};
+        static const bool lzd_stats = getenv("RSN_LZD_STATS") != nullptr;
+        if (lzd_stats) { void *sp; rc = dev_buf(c, 23, 64, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 64, s)); ra.stats = (unsigned long long *)sp; }
         RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
+        if (lzd_stats) {
+            unsigned long long hs[8];
+            RSN_HIP(hipMemcpyAsync(hs, ra.stats, 64, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "lzss_dec_resolve, cycles per tile: staging %.0f, parse + item marks %.0f, fill forward %.0f, pointer jumping %.0f (%.2f rounds), store %.0f\n",
+                    (double)hs[0] / n_tiles, (double)hs[1] / n_tiles, (double)hs[2] / n_tiles, (double)hs[3] / n_tiles, (double)hs[5] / n_tiles, (double)hs[4] / n_tiles);
+        }
         static thread_local size_t attr_tl = 0;
         if ((size_t)TL * 4 > attr_tl) {
             RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lzd_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TL * 4)));
