@@ -459,7 +459,12 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     uint32_t cur = __shfl_up(incl, 1);
     if (lane == 0) cur = NONE;
     __syncthreads();
-    if (cur == NONE) for (int w = wv - 1; w >= 0; w--) { const uint32_t y = s_wlast[w]; if (y != NONE) { cur = y; break; } }
+    {   // what the wavefronts before this one leave open: the same scan over their (at most 16) last marks
+        uint32_t wl = lane < DTH / 64 ? s_wlast[lane] : NONE;
+        for (int d = 1; d < DTH / 64; d <<= 1) { const uint32_t y = __shfl_up(wl, d); if (lane >= d && wl == NONE) wl = y; }
+        const uint32_t carry = wv ? (uint32_t)__builtin_amdgcn_readlane((int)wl, wv - 1) : NONE;
+        if (cur == NONE) cur = carry;
+    }
     uint32_t dsc[16];
     uint32_t unres = 0;
 #pragma unroll
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (unres) {
 #pragma unroll
             for (int hop = 0; hop < 2; hop++) {                           // all 16 reads of a hop are issued together
+                if (hop && !__ballot(unres != 0)) break;
                 uint32_t w[16];                                           // (a resolved slot reads sd[0] with everybody else: a broadcast)
 #pragma unroll
                 for (int j = 0; j < 16; j++) w[j] = sd[(unres >> j) & 1 ? (dsc[j] & D_PAY) : 0u];
