@@ -19,4 +19,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
 int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
+// exclusive scan of n counts on the stream (huff_encode.hip); *total (may be null) receives the sum; in and out must not overlap
+int scan_u64(Ctx &c, hipStream_t s, const char *name, const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
+
 }  // namespace rsn

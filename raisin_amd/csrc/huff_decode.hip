@@ -32,7 +32,6 @@
 
 namespace rsn {
 
-__global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
 
 constexpr int DB = 256;             // lanes per block
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits)
@@ -808,7 +807,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         if (!*h_changed) break;
     }
     // ---- D2: offsets, total, validity of the final exit
-    RSN_LAUNCH("huff_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, a.blk_bytes, d_blk_off, n_blk, d_total);
+    rc = scan_u64(c, s, "huff_dec_scan", a.blk_bytes, d_blk_off, n_blk, d_total); if (rc) return rc;
     struct Tail { unsigned long long total; uint16_t last_exit; };
     Tail *ht = (Tail *)hp;
     RSN_HIP(hipMemcpyAsync(&ht->total, d_total, 8, hipMemcpyDeviceToHost, s));

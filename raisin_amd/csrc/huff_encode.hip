@@ -245,35 +245,77 @@ __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict
     }
 }
 
-// ---------------------------------------------------------------- K3: exclusive scan (single block)
-// 8 consecutive items per lane, 8192 per sweep.
+// ---------------------------------------------------------------- K3: exclusive scan
+// 8 consecutive items per lane, 8192 per block.  Up to SCAN_ONE items: one block sweeps them all.  Beyond (a 1 GiB call scans
+// 131072 .. 262144 per-tile counts): one block per 8192 items scans locally and leaves its total, a second launch adds the
+// totals of the blocks before -- a single block spends 0.14 ms on that many items (one CU's 64 cache lines per load).
+constexpr uint32_t SCAN_BLK = 1024 * 8, SCAN_ONE = 2 * SCAN_BLK;
+
+__device__ __forceinline__ unsigned long long scan_sweep(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+                                                        uint32_t base, uint32_t n, unsigned long long carry, unsigned long long *wsum) {
+    constexpr int IT = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t i0 = base + tid * IT;
+    unsigned long long x[IT], loc = 0;
+#pragma unroll
+    for (int k = 0; k < IT; k++) { x[k] = i0 + k < n ? in[i0 + k] : 0; loc += x[k]; }
+    unsigned long long s = loc;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d); if (lane >= d) s += y; }
+    if (lane == 63) wsum[wv] = s;
+    __syncthreads();
+    unsigned long long pre = carry, all = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) pre += wsum[k]; all += wsum[k]; }
+    unsigned long long run = pre + s - loc;
+#pragma unroll
+    for (int k = 0; k < IT; k++) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
+    __syncthreads();
+    return carry + all;
+}
+
 __global__ __launch_bounds__(1024) void k_scan_u64(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
                                                    uint32_t n, unsigned long long *__restrict__ total) {
-    constexpr int IT = 8;
     __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry_s;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n; base += SCAN_BLK) carry = scan_sweep(in, out, base, n, carry, wsum);
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_local(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+                                                     uint32_t n, unsigned long long *__restrict__ part) {
+    __shared__ unsigned long long wsum[16];
+    const unsigned long long all = scan_sweep(in, out, blockIdx.x * SCAN_BLK, n, 0, wsum);
+    if (threadIdx.x == 0) part[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add(unsigned long long *__restrict__ out, uint32_t n, const unsigned long long *__restrict__ part,
+                                                   unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long red[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const bool last = b + 1 == nb;
+    unsigned long long s = 0;                                            // sum of the totals before this block (all of them in the last block: the grand total)
+    for (uint32_t k = tid; k < (last ? nb : b); k += 1024) s += part[k];
+    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) red[wv] = s;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024 * IT) {
-        const uint32_t i0 = base + tid * IT;
-        unsigned long long x[IT], loc = 0;
-#pragma unroll
-        for (int k = 0; k < IT; k++) { x[k] = i0 + k < n ? in[i0 + k] : 0; loc += x[k]; }
-        unsigned long long s = loc;
-        for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d); if (lane >= d) s += y; }
-        if (lane == 63) wsum[wv] = s;
-        __syncthreads();
-        unsigned long long pre = carry_s;
-        for (int k = 0; k < wv; k++) pre += wsum[k];
-        unsigned long long run = pre + s - loc;
-#pragma unroll
-        for (int k = 0; k < IT; k++) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
-        __syncthreads();
-        if (tid == 1023) carry_s = pre + s;
-        __syncthreads();
+    unsigned long long pre = 0;
+    for (int k = 0; k < 16; k++) pre += red[k];
+    if (last) { if (tid == 0 && total) *total = pre; pre -= part[b]; }
+    if (pre) for (uint32_t i = b * SCAN_BLK + tid; i < min(n, (b + 1) * SCAN_BLK); i += 1024) out[i] += pre;
+}
+
+// Exclusive scan of n counts on the stream; *total (may be null) receives their sum.  in and out must not overlap.
+int scan_u64(Ctx &c, hipStream_t s, const char *name, const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total) {
+    if (n <= SCAN_ONE) {
+        RSN_LAUNCH(name, k_scan_u64, dim3(1), dim3(1024), 0, s, in, out, n, total);
+        return RSN_OK;
     }
-    if (tid == 0 && total) *total = carry_s;
+    const uint32_t nb = (uint32_t)ceil_div(n, SCAN_BLK);
+    void *p; int rc = dev_buf(c, 24, (size_t)nb * 8, &p); if (rc) return rc;
+    unsigned long long *part = (unsigned long long *)p;
+    RSN_LAUNCH(name, k_scan_local, dim3(nb), dim3(1024), 0, s, in, out, n, part);
+    RSN_LAUNCH(name, k_scan_add, dim3(nb), dim3(1024), 0, s, out, n, (const unsigned long long *)part, total);
+    return RSN_OK;
 }
 
 // ---------------------------------------------------------------- K4: boundary units
@@ -872,7 +914,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     } else {
         RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, d_tile_hist, d_len8, n_tiles, d_tile_bits);
     }
-    RSN_LAUNCH("huff_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tile_bits, d_tile_off, n_tiles, d_tile_off + n_tiles);
+    rc = scan_u64(c, s, "huff_scan", d_tile_bits, d_tile_off, n_tiles, d_tile_off + n_tiles); if (rc) return rc;
 
     // ---- emit
     const uint32_t tiles_per_block = (uint32_t)std::max<size_t>(1, ceil_div(n_tiles, 2048));

@@ -17,7 +17,6 @@
 
 namespace rsn {
 
-__global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
 
 namespace {
 constexpr int BB = 256;                       // threads per block (4 wavefronts)
@@ -156,7 +155,7 @@ int lzss_encode_big(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint
         std::swap(a, b);
     }
     RSN_LAUNCH("lzss_big_count", k_big_count, dim3(n_blk), dim3(BT), 0, s, d_keys, d_on, E, d_bbytes);
-    RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_bbytes, d_boff, n_blk, d_btot);
+    rc = scan_u64(c, s, "lzss_scan", d_bbytes, d_boff, n_blk, d_btot); if (rc) return rc;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 16, hipMemcpyDeviceToHost, s));

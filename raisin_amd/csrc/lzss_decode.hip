@@ -27,7 +27,6 @@
 
 namespace rsn {
 
-__global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
 
 constexpr int ZB = 256;
 constexpr int ZTILE = ZB * 16;          // compressed bytes per block, 16 per lane
@@ -805,7 +804,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     volatile int *hflag = (volatile int *)(h64 + 1);
     RSN_HIP(hipMemsetAsync(d_flag, 0, 16, s));
     RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
-    RSN_LAUNCH("lzss_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_blen, d_boff, n_cb, d_btot);
+    rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
@@ -884,7 +883,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!tile_path) RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);   // the tile path's emit kernel wrote them
     RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(1024), 0, s, d_summ, n_ub, d_inpar);
     RSN_LAUNCH("lzss_une_count", k_une_count, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_inpar, d_ulen);
-    RSN_LAUNCH("lzss_dec_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_ulen, d_uoff, n_ub, d_utot);
+    rc = scan_u64(c, s, "lzss_dec_scan", d_ulen, d_uoff, n_ub, d_utot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_utot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     const size_t total = (size_t)h64[0];

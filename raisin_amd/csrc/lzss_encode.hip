@@ -29,7 +29,6 @@
 
 namespace rsn {
 
-__global__ void k_scan_u64(const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
 int lzss_encode_big(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint32_t W, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
 constexpr int LB = 256;                 // threads per block
@@ -410,6 +409,7 @@ static_assert(MATCH_STRIP % HT == 0, "a strip is a whole number of hash tiles");
 static_assert((1 << HSH) == HTH && (HWMAX + HT) % HTH == 0 && (HNB / 2) % HTH == 0, "round structure");
 
 struct HashArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t *heavy; const uint32_t *only; };
+constexpr uint32_t PREV_BLK = 8192;                                  // tiles per block of k_prev_walked
 struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's chain enters its tile / first lands beyond it (stream positions)
 // k_match_chain's arguments.  What only the prologue and the epilogue need sits in `tail` and is read from the
 // kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
@@ -1061,33 +1061,40 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
 // arithmetic: from that tile's exit x the chain steps by W through the periodic stretch, so it enters this tile
 // at x + W * ceil((t0 - x) / W) -- valid because every tile in between is periodic too (checked) -- and the flags,
 // the output bytes and the tile's entry / exit follow.  k_chain_verify then checks the joints as for any tile.
-__global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t *__restrict__ prev) {
-    constexpr int IT = 8;
+__global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t *__restrict__ prev, uint32_t *__restrict__ part) {
+    // one block per PREV_BLK tiles: the inclusive maximum inside the block; k_prev_fix brings in the blocks before
+    constexpr int IT = PREV_BLK / 1024;
     __shared__ uint32_t wmax[16];
-    __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;                                          // 0 = none yet; else tile index + 1
+    const uint32_t i0 = blockIdx.x * PREV_BLK + tid * IT;
+    uint32_t x[IT], loc = 0;
+#pragma unroll
+    for (int k = 0; k < IT; k++) { x[k] = (i0 + k < n_tiles && tc[i0 + k].walked == 1) ? i0 + k + 1 : 0u; loc = max(loc, x[k]); }   // 0 = none yet; else tile index + 1
+    uint32_t sfx = loc;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(sfx, d); if (lane >= d) sfx = max(sfx, y); }
+    if (lane == 63) wmax[wv] = sfx;
     __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024 * IT) {
-        const uint32_t i0 = base + tid * IT;
-        uint32_t x[IT], loc = 0;
+    uint32_t pre = 0, all = 0;
+    for (int k = 0; k < 16; k++) { if (k < wv) pre = max(pre, wmax[k]); all = max(all, wmax[k]); }
+    uint32_t run = max(pre, (uint32_t)__shfl_up(sfx, 1));
+    if (lane == 0) run = pre;
 #pragma unroll
-        for (int k = 0; k < IT; k++) { x[k] = (i0 + k < n_tiles && tc[i0 + k].walked == 1) ? i0 + k + 1 : 0u; loc = max(loc, x[k]); }
-        uint32_t sfx = loc;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(sfx, d); if (lane >= d) sfx = max(sfx, y); }
-        if (lane == 63) wmax[wv] = sfx;
-        __syncthreads();
-        uint32_t pre = carry_s;
-        for (int k = 0; k < wv; k++) pre = max(pre, wmax[k]);
-        uint32_t before = max(pre, (uint32_t)__shfl_up(sfx, 1));
-        if (lane == 0) before = pre;
-        uint32_t run = before;
-#pragma unroll
-        for (int k = 0; k < IT; k++) { run = max(run, x[k]); if (i0 + k < n_tiles) prev[i0 + k] = run; }   // inclusive: a walked tile names itself
-        __syncthreads();
-        if (tid == 1023) carry_s = max(pre, sfx);
-        __syncthreads();
-    }
+    for (int k = 0; k < IT; k++) { run = max(run, x[k]); if (i0 + k < n_tiles) prev[i0 + k] = run; }   // inclusive: a walked tile names itself
+    if (tid == 0) part[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(1024) void k_prev_fix(uint32_t *__restrict__ prev, uint32_t n_tiles, const uint32_t *__restrict__ part) {
+    __shared__ uint32_t red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    uint32_t m = 0;
+    for (uint32_t k = tid; k < b; k += 1024) m = max(m, part[k]);
+    for (int d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_down(m, d));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < 16; k++) pre = max(pre, red[k]);
+    if (pre) for (uint32_t i = b * PREV_BLK + tid; i < min(n_tiles, (b + 1) * PREV_BLK); i += 1024) prev[i] = max(prev[i], pre);
 }
 
 // Only when the general parse has to take over: the chain walk wrote keys where a chain landed and nothing else
@@ -1514,7 +1521,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
     unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
     RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
-    RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_extra, d_eoff, n_eb, d_etot);
+    rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
@@ -1600,14 +1607,18 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
+        const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
+        void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
+        uint32_t *d_prev_part = (uint32_t *)pp;
         auto resolve = [&]() -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
             RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
             RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-            RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(1), dim3(1024), 0, s, d_tchain, n_pt, d_entry);
+            RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
+            if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
             RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
-            RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+            rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(h64, d_ttot, 24, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
             return RSN_OK;
@@ -1657,7 +1668,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry);
         RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
         RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), mark_sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, d_redo, d_ttot + 1);
-        RSN_LAUNCH("lzss_scan", k_scan_u64, dim3(1), dim3(1024), 0, s, d_tbytes, d_toff, n_pt, d_ttot);
+        rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64, d_ttot, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (h64[1] == 0) break;
