@@ -415,7 +415,7 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
 // 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
-struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; };
+struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; };   // redo_list: the tiles of a second launch (ChainArgs::redo)
 struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };
 __device__ __forceinline__ ChainTail chain_tail() {
     return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __shared__ uint32_t s_heavy, s_next, s_dense;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
-    if (a.redo && chain_tail().tchain[blockIdx.x].walked) return;                    // second launch: only the tiles that gave up as "dense" the first time
-    const long long t0 = (long long)blockIdx.x * CT;
+    const uint32_t bx = a.redo ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;     // the tile; a second launch holds only the tiles that gave up as "dense" the first time (k_chain_verify lists them)
+    const long long t0 = (long long)bx * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
 #ifdef RSN_CHAIN_STATS
@@ -725,9 +725,10 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             const long long q_end = min(t0 + (long long)CT + (long long)W - 1, (long long)E);
             for (long long q = t0 + CT + HLMAX + tid; q < q_end; q += CTH) ok = ok && a.fc[q] == a.fc[q - W];
             if (__syncthreads_and(ok)) {
-                for (long long p = t0 + tid; p < min(t0 + (long long)CT, (long long)E); p += CTH)
-                    a.keys[p] = ((uint32_t)min((long long)W, (long long)E - p) << 16) | W;
-                if (tid == 0) chain_tail().tchain[blockIdx.x] = TileChain{0, 0, 2u, 0};   // W-periodic: every position has the key (min(W, E-p), W); k_chain_periodic places the chain once its entry is known
+                // W-periodic: every position p has the key (min(W, E-p), W).  Nobody writes them (4 bytes per position for nothing):
+                // k_chain_periodic places the chain by arithmetic, k_tok_emit computes the key of a flagged position, and
+                // k_chain_unknown stores them only if the general parse has to take over.
+                if (tid == 0) chain_tail().tchain[bx] = TileChain{0, 0, 2u, 0};
                 return;
             }
         }
@@ -930,15 +931,15 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
 #endif
     __syncthreads();
     const ChainTail T = chain_tail();
-    if (tid == 0 && s_heavy) T.heavy[blockIdx.x / (MATCH_STRIP / CT)] = 1;
-    if (tid == 0 && s_dense && !s_heavy) T.dense[blockIdx.x / (MATCH_STRIP / CT)] = 1;
-    if (s_heavy || s_dense) { if (tid == 0) T.tchain[blockIdx.x] = TileChain{0, 0, 0, 0}; return; }
+    if (tid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
+    if (tid == 0 && s_dense && !s_heavy) T.dense[bx / (MATCH_STRIP / CT)] = 1;
+    if (s_heavy || s_dense) { if (tid == 0) T.tchain[bx] = TileChain{0, 0, 0, 0}; return; }
 
     // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
     {
-        uint4 *dst = reinterpret_cast<uint4 *>(T.dump + (size_t)blockIdx.x * C::DUMP_BYTES);
+        uint4 *dst = reinterpret_cast<uint4 *>(T.dump + (size_t)bx * C::DUMP_BYTES);
         for (int i = tid; i < C::DUMP_BYTES / 16; i += CTH) dst[i] = reinterpret_cast<const uint4 *>(s_claim)[i];
-        if (tid == 0) T.tchain[blockIdx.x] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
+        if (tid == 0) T.tchain[bx] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
     }
 }
 
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(1024) void k_prev_fix(uint32_t *__restrict__ prev, 
 // (A tile that gave up keeps none: its strip is redone for all positions anyway.)
 template <class C>
 __global__ __launch_bounds__(256) void k_chain_unknown(const uint8_t *__restrict__ dump, const TileChain *__restrict__ tchain, uint32_t n_tiles, uint32_t E,
-                                                       uint32_t *__restrict__ keys) {
+                                                       uint32_t W, uint32_t *__restrict__ keys) {
     constexpr int CT = C::CT, CH = C::CH;
     static_assert(CH % 32 == 0 && CT % 32 == 0, "bitmap words line up with the tile");
     __shared__ uint32_t s_known[CT / 32];
@@ -1113,14 +1114,18 @@ __global__ __launch_bounds__(256) void k_chain_unknown(const uint8_t *__restrict
     const uint32_t w_own = tchain[k].walked, w_nxt = k + 1 < n_tiles ? tchain[k + 1].walked : 0u;
     const uint32_t *own = reinterpret_cast<const uint32_t *>(dump + (size_t)k * C::DUMP_BYTES);
     const uint32_t *nxt = reinterpret_cast<const uint32_t *>(dump + (size_t)(k + 1) * C::DUMP_BYTES);
+    const size_t t0 = (size_t)k * CT;
+    const uint32_t npos = (uint32_t)min((size_t)CT, (size_t)E - t0);
+    if (w_own == 2) {                                                     // W-periodic tile: its keys are known but were never stored
+        for (uint32_t i = tid; i < npos; i += 256) keys[t0 + i] = (min(W, E - (uint32_t)(t0 + i)) << 16) | W;
+        return;
+    }
     for (int w = tid; w < CT / 32; w += 256) {
-        uint32_t m = w_own == 2 ? 0xFFFFFFFFu : w_own == 1 ? own[CH / 32 + w] : 0u;
+        uint32_t m = w_own == 1 ? own[CH / 32 + w] : 0u;
         if (w >= (CT - CH) / 32 && w_nxt == 1) m |= nxt[w - (CT - CH) / 32];
         s_known[w] = m;
     }
     __syncthreads();
-    const size_t t0 = (size_t)k * CT;
-    const uint32_t npos = (uint32_t)min((size_t)CT, (size_t)E - t0);
     for (uint32_t i = tid; i < npos; i += 256)
         if (!((s_known[i >> 5] >> (i & 31)) & 1)) keys[t0 + i] = KEY_UNKNOWN;
 }
@@ -1160,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_chain_periodic(TileChain *__restrict__ 
 
 // Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
 // tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
-__global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad) {
+__global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad,
+                               uint32_t *__restrict__ redo_list, uint32_t redo_cap) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = k < n_tiles;
     const TileChain c = live ? tc[k] : TileChain{0, 0, 1u, 0};
@@ -1177,7 +1183,12 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
 #pragma unroll
     for (uint32_t q = 0; q < 3; q++) {
         const unsigned long long m = __ballot(live && !ok && cls == q);
-        if (m && (threadIdx.x & 63) == 0) atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
+        uint32_t at = 0;
+        if (m && (threadIdx.x & 63) == 0) at = atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
+        if (q == 0 && m) {                                                // the tiles that gave up, listed for a second look
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            if (((m >> (threadIdx.x & 63)) & 1) && at < redo_cap) redo_list[at] = k;
+        }
     }
 }
 
@@ -1422,7 +1433,7 @@ __device__ __forceinline__ uint8_t *put_dec(uint8_t *o, uint32_t v) {
 
 __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc, const uint32_t *__restrict__ keys, uint32_t E,
                                                  const uint32_t *__restrict__ flags, const unsigned long long *__restrict__ tile_off,
-                                                 uint8_t *__restrict__ out) {
+                                                 uint8_t *__restrict__ out, const TileChain *__restrict__ tchain, uint32_t W) {
     constexpr int RP = LB * 16;                                    // positions per round
     __shared__ uint32_t wsum[LB / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[RP];
@@ -1431,6 +1442,8 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t base = blockIdx.x * PT;
     unsigned long long run = tile_off[blockIdx.x];
+    const bool periodic = tchain && tchain[blockIdx.x].walked == 2;     // a W-periodic tile of the chain walk: its keys are arithmetic, not stored
+    auto key_at = [&](uint32_t p) { return periodic ? (min(W, E - p) << 16) | W : keys[p]; };
     for (int r = 0; r < PT / RP; r++) {
         const uint32_t rb = base + r * RP;
         // 16 consecutive positions per lane = one half-word of the flag mask
@@ -1441,7 +1454,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
         if (busy < 8) {                                            // a handful of tokens: staging the round would cost more than it saves
             uint32_t mine = 0;
             for (uint32_t m = fw; m; m &= m - 1) {
-                const uint32_t k = keys[rb + i0 + __builtin_ctz(m)], L = k >> 16;
+                const uint32_t k = key_at(rb + i0 + __builtin_ctz(m)), L = k >> 16;
                 if (L == 0) mine += 1;
                 else { const uint32_t e = enc_len(k & 0xFFFF, L); mine += e < L ? e : L; }
             }
@@ -1454,7 +1467,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             uint8_t *o = out + run + pre + incl - mine;
             for (uint32_t m = fw; m; m &= m - 1) {
                 const uint32_t p = rb + i0 + __builtin_ctz(m);
-                const uint32_t k = keys[p], L = k >> 16, off = k & 0xFFFF;
+                const uint32_t k = key_at(p), L = k >> 16, off = k & 0xFFFF;
                 if (L == 0) { *o++ = fc[p]; continue; }
                 if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
                 else for (uint32_t j = 0; j < L; j++) *o++ = fc[p + j];
@@ -1466,7 +1479,8 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
         for (int v = tid; v < RP / 4; v += LB) {                   // keys and bytes of the round, 16 bytes per load
             const uint32_t p = rb + 4 * v;
             uint4 x = {0, 0, 0, 0};
-            if (p + 4 <= E) x = *reinterpret_cast<const uint4 *>(keys + p);
+            if (periodic) { if (p < E) x.x = key_at(p); if (p + 1 < E) x.y = key_at(p + 1); if (p + 2 < E) x.z = key_at(p + 2); if (p + 3 < E) x.w = key_at(p + 3); }
+            else if (p + 4 <= E) x = *reinterpret_cast<const uint4 *>(keys + p);
             else { if (p < E) x.x = keys[p]; if (p + 1 < E) x.y = keys[p + 1]; if (p + 2 < E) x.z = keys[p + 2]; }
             reinterpret_cast<uint4 *>(s_keys)[v] = x;
         }
@@ -1589,7 +1603,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
         void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
         uint8_t *d_dump = (uint8_t *)dp;
-        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump}};
+        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
@@ -1607,6 +1621,9 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
+        const uint32_t redo_cap = std::max(4u, n_pt / 64);                // a second look is worth it for this many tiles at most
+        void *rl; rc = dev_buf(c, 26, (size_t)redo_cap * 4 + 64, &rl); if (rc) return rc;
+        uint32_t *d_redo_list = (uint32_t *)rl;
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
         uint32_t *d_prev_part = (uint32_t *)pp;
@@ -1617,7 +1634,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
-            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1));
+            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1), d_redo_list, redo_cap);
             rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(h64, d_ttot, 24, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
@@ -1628,16 +1645,16 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         const uint32_t not_walked = (uint32_t)h64[1];
-        if (!parsed && !no_fused && not_walked && not_walked <= std::max(4u, n_pt / 64)) {
+        if (!parsed && !no_fused && not_walked && not_walked <= redo_cap) {
             // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
-            ha.redo = 1;
-            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha);
+            ha.redo = 1; ha.tail.redo_list = d_redo_list;
+            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(not_walked), dim3(CC::CTH), 0, s, ha);
             rc = resolve(); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
             if (dbg) fprintf(stderr, "lzss chain walk, second look: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         }
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
-            RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, d_keys);
+            RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
             RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
             rc = sweep(d_heavy); if (rc) return rc;
@@ -1684,7 +1701,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     *out_n = total;
     if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- E4
-    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out);
+    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W);
     RSN_HIP(hipStreamSynchronize(s));
     return RSN_OK;
 }
