@@ -34,7 +34,7 @@ namespace rsn {
 
 
 constexpr int DB = 256;             // lanes per block
-constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits)
+constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits; 128: emit 5 % faster, sync 40 % slower -- its warm-up is per subsequence)
 constexpr int SBITS = SW * 32;
 constexpr int ORG_WORDS = 8;              // words staged in front of the block: warm-up room for the entry guess
 constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are offset by this
@@ -783,7 +783,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     volatile int *h_changed = (volatile int *)hp;
 
-    const uint32_t grid_p = std::min<uint32_t>(n_blk, 256u * 8u * 2u);   // persistent blocks: the LUT is staged once per block
+    static const uint32_t grid_env = [] { const char *e = getenv("RSN_DEC_GRID"); return e ? (uint32_t)std::max(atoi(e), 1) : 256u * 8u * 2u; }();   // tuning switch: persistent blocks
+    const uint32_t grid_p = std::min<uint32_t>(n_blk, grid_env);          // persistent blocks: the LUT is staged once per block
     auto launch_sync = [&]() -> int {
         const char *nm = a.pass == 0 ? "huff_dec_sync" : a.pass == 1 ? "huff_dec_sync_fix" : "huff_dec_sync_verify";
         if (multi && short_codes) RSN_LAUNCH(nm, (k_dec_sync<true, true, true>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
@@ -821,6 +822,9 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // ---- D3
     a.blk_off = d_blk_off; a.out = d_out;
     // (8-byte table entries with the symbols already spread to bytes measured slower than unpacking the 4-byte ones: 1.19 vs 0.98 ms)
+    // (This kernel scales almost linearly with blocks per CU up to the four its LDS allows.  Without the LDS output stage --
+    //  a lane's dwords straight to memory -- seven blocks fit, but the scattered partial-line stores cost more than that
+    //  buys: 1.66 vs 0.96 ms.)
     if (ascii && short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
     else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
