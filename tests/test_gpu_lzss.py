@@ -339,3 +339,20 @@ def test_chain_vs_allpos_switch(oracle):
     import hashlib
     d = text(5, 150000) + long_copies(4, 60000)
     assert outs[0] == outs[1] == hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3, 4, 5])
+def test_escape_blocks_plain_and_mixed(lz, oracle, shift):
+    """Escape / unescape writers: 4096-byte blocks without any escape byte take a path of their own (SWAR map, one
+    16-byte store); `shift` escape bytes in front move every later block's output to each alignment, '<' (-> FF)
+    and FF / 5C (-> 5C FF / 5C 5C) sit at block edges, and a block in the middle is all escapes."""
+    rng = random.Random(900 + shift)
+    plain = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz <>,0123456789") for _ in range(5 * 4096))
+    data = bytearray(b"\xff" * shift + plain)
+    for p in (4095, 4096, 8191, 12288, 12289):
+        data[p + shift] = rng.choice(b"\\\xff<")
+    data += b"\\\xff" * 2048 + plain[:4096 + 77]
+    data = bytes(data)
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data, 4096)
+    assert lz.Decompress(c, False) == data
