@@ -415,8 +415,8 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
 // 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
-struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; };   // redo_list: the tiles of a second launch (ChainArgs::redo)
-struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };
+struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; };   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
+struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
 __device__ __forceinline__ ChainTail chain_tail() {
     return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
 }
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __shared__ uint32_t s_heavy, s_next, s_dense;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
-    const uint32_t bx = a.redo ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;     // the tile; a second launch holds only the tiles that gave up as "dense" the first time (k_chain_verify lists them)
+    const uint32_t bx = (a.redo & 2u) ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;     // the tile; a second launch holds only the tiles that gave up as "dense" the first time (k_chain_verify lists them)
     const long long t0 = (long long)bx * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             }
             if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
                 // (the density test sits on this path because dense data comes through here all the time, text rarely)
-                if (!a.redo && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
+                if (!(a.redo & 1u) && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
                 else {
                     const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
                     const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __syncthreads();
     const ChainTail T = chain_tail();
     if (tid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
-    if (tid == 0 && s_dense && !s_heavy) T.dense[bx / (MATCH_STRIP / CT)] = 1;
+    if (tid == 0 && s_dense && !s_heavy) { T.dense[bx / (MATCH_STRIP / CT)] = 1; if (T.n_dense) atomicAdd(T.n_dense, 1u); }
     if (s_heavy || s_dense) { if (tid == 0) T.tchain[bx] = TileChain{0, 0, 0, 0}; return; }
 
     // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
@@ -1165,6 +1165,10 @@ __global__ __launch_bounds__(256) void k_chain_periodic(TileChain *__restrict__ 
 
 // Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
 // tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
+__global__ void k_sample_tiles(uint32_t *__restrict__ list, uint32_t n, uint32_t n_tiles) {   // n tiles spread evenly over the stream (not tile 0: it has no window)
+    if (threadIdx.x < n) list[threadIdx.x] = (uint32_t)(((unsigned long long)threadIdx.x * n_tiles + n_tiles / 2) / n);
+}
+
 __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad,
                                uint32_t *__restrict__ redo_list, uint32_t redo_cap) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1563,7 +1567,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     static const bool brute = getenv("RSN_LZSS_BRUTE") != nullptr || getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: sweep every strip
     static const bool allpos = getenv("RSN_LZSS_ALLPOS") != nullptr;                                            // A/B switch: bucket search at every position
     const bool hashed = W <= HWMAX && !brute;
-    const bool chain_mode = hashed && !allpos;
+    bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
     auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 (or k_match) on every strip, or on the flagged ones
         MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, only};
         const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
@@ -1598,12 +1602,34 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     uint32_t *d_flags = d_entry + n_pt;
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
+    using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
+    uint8_t *d_dump = nullptr;
+    uint32_t *d_redo_list = nullptr;
+    const uint32_t redo_cap = std::max(64u, n_pt / 64);               // a second look is worth it for this many tiles at most (and room for the sample below)
     if (chain_mode) {
-        using CC = ChainCfg<8192, 1024, 128>;             // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
-        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
         void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
-        uint8_t *d_dump = (uint8_t *)dp;
-        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr}};
+        d_dump = (uint8_t *)dp;
+        void *rl; rc = dev_buf(c, 26, (size_t)redo_cap * 4 + 64, &rl); if (rc) return rc;
+        d_redo_list = (uint32_t *)rl;
+    }
+    // Nearly incompressible input is the one case where the chain walk loses (every tile walks a few dozen visits per wavefront,
+    // gives up as dense, and the bucket search does it all again: 57 against 41 ms per GiB of random bytes).  Large inputs walk a
+    // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
+    constexpr uint32_t SAMPLE_TILES = 64;
+    static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
+    if (chain_mode && !no_sample && n_pt >= 16 * SAMPLE_TILES) {
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
+        RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
+        RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
+        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3)}};
+        RSN_LAUNCH("lzss_sample", k_match_chain<CC>, dim3(SAMPLE_TILES), dim3(CC::CTH), 0, s, hs);
+        RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        if ((uint32_t)h64[3] * 4 >= SAMPLE_TILES * 3) chain_mode = false;
+    }
+    if (chain_mode) {
+        RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
+        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
@@ -1621,9 +1647,6 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
-        const uint32_t redo_cap = std::max(4u, n_pt / 64);                // a second look is worth it for this many tiles at most
-        void *rl; rc = dev_buf(c, 26, (size_t)redo_cap * 4 + 64, &rl); if (rc) return rc;
-        uint32_t *d_redo_list = (uint32_t *)rl;
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
         uint32_t *d_prev_part = (uint32_t *)pp;
@@ -1647,7 +1670,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         const uint32_t not_walked = (uint32_t)h64[1];
         if (!parsed && !no_fused && not_walked && not_walked <= redo_cap) {
             // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
-            ha.redo = 1; ha.tail.redo_list = d_redo_list;
+            ha.redo = 3; ha.tail.redo_list = d_redo_list;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(not_walked), dim3(CC::CTH), 0, s, ha);
             rc = resolve(); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;

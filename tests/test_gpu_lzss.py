@@ -356,3 +356,19 @@ def test_escape_blocks_plain_and_mixed(lz, oracle, shift):
     c = lz.CompressAsync(data)
     assert c == oracle.lzss_compress(data, 4096)
     assert lz.Decompress(c, False) == data
+
+
+def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
+    """Inputs of 1024 tiles and more walk a sample of 64 tiles first: all noise -> no chain walk at all; noise with
+    text in the second half -> the sample is split, the chain walk runs and hands the noisy strips back."""
+    rng = np.random.default_rng(77)
+    n = 9 << 20
+    noise = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    half = noise[: n // 2 + 12345] + text(78, n // 2)
+    for data, walks in ((noise, False), (half, True)):
+        c, p = _prof(lz, data)
+        if _chain_mode():
+            assert p["lzss_sample"][0] == 2                            # the list and the 64-tile walk
+            assert ("lzss_match_chain" in p) == walks
+        assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
+        assert lz.Decompress(c) == data
