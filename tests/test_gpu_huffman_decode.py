@@ -154,3 +154,34 @@ def test_device_resident_round_trip_256MiB(huff):
     c2 = huff.compress_tensor(src2)
     d2 = huff.decompress_tensor(c2)
     assert torch.equal(d2, src2)
+
+
+def test_second_level_tables_and_switches(oracle):
+    """Codes longer than the first-level table: sub-tables in LDS (byte alphabets), through L2 (rune alphabets with tens of
+    thousands of symbols), and the bit-by-bit walk below them (Fibonacci counts: 29-bit codes).  The same streams decode
+    the same with RSN_DEC_NO_LUT2=1 (no second level at all) and RSN_DEC_K=8 (a smaller first level): separate processes,
+    the switches are read once."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import hashlib\n"
+            "from raisin_amd import huffman\n"
+            "from oracle import oracle\n"
+            "from test_gpu_huffman_encode import fib_skewed, rnd_bytes\n"
+            "import workloads as W\n"
+            "for d in (fib_skewed(30), bytes(W.skewed_bytes(3 << 20).numpy()), rnd_bytes(11, 3 << 20)):\n"
+            "    c = oracle.huffman_compress(d)\n"
+            "    print(hashlib.sha256(huffman.Decompress(c)).hexdigest(), hashlib.sha256(oracle.huffman_decompress(c)).hexdigest())\n"
+            ) % (root, os.path.join(root, "tests"))
+    outs = []
+    for env in ({}, {"RSN_DEC_NO_LUT2": "1"}, {"RSN_DEC_K": "8"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l.split() for l in r.stdout.strip().splitlines()]
+        assert len(lines) == 3 and all(a == b for a, b in lines), (env, lines)
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2]
