@@ -826,54 +826,61 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             bool longm = false, giveup_heavy = false, giveup_dense = false;
             if (u_capE >= 2) {
                 const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
-                const uint32_t v_lo = ends[max(u_h, 1u) - 1];
-                uint32_t u_lo = uni(u_h ? v_lo : 0u);
-                uint32_t u_hi = uni(ends[u_h]);
+                // (bucket bounds and the bisection's arithmetic stay in VECTOR registers although every lane holds the same values:
+                //  the scalar unit is this kernel's bound; only the ballots and the loop branches are scalar)
+                const uint32_t v_lo0 = ends[max(u_h, 1u) - 1];
+                uint32_t v_lo = u_h ? v_lo0 : 0u;
+                const uint32_t v_hi = ends[u_h];
                 const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
                 const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);  // the position's own bytes: one address for all lanes
-                bool narrowing = u_hi - u_lo > 64;
-                while (narrowing) {                                           // skip the entries before the window, 64-ary
-                    const uint32_t n = u_hi - u_lo, stride = (n + 63) >> 6;
-                    const uint32_t idx = min(u_lo + (uint32_t)lane * stride, u_hi - 1);
+                bool narrowing = v_hi - v_lo > 64;
+                while (__ballot(narrowing)) {                                 // skip the entries before the window, 64-ary
+                    const uint32_t n = v_hi - v_lo, stride = (n + 63) >> 6;
+                    const uint32_t idx = min(v_lo + (uint32_t)lane * stride, v_hi - 1);
                     const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
                     const unsigned long long in = __ballot(blk >= u_blk_lo);
                     const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
-                    u_lo = first > 1 ? min(u_lo + (first - 1) * stride, u_hi - 1) : u_lo;
-                    narrowing = first > 1 && stride > 1 && u_hi - u_lo > 64;
+                    const uint32_t skip = max(first, 1u) - 1u;                // whole strides known to lie before the window
+                    v_lo = min(v_lo + skip * stride, v_hi - 1);               // (skip == 0 leaves v_lo: v_lo < v_hi)
+                    narrowing = skip * (stride - 1u) != 0 && v_hi - v_lo > 64;
                 }
+                const uint32_t u_lo = uni(v_lo);
+                uint32_t u_hi = uni(v_hi);
                 uint32_t base = u_lo;
+                // (lane predicates are folded into single vector compares: every s_and_b64 of two lane masks is one more
+                //  instruction on the scalar unit.  A lane beyond the bucket's end re-examines entry u_lo: harmless to a maximum.)
                 while (base < u_hi) {
 #ifdef RSN_CHAIN_STATS
                     n_rounds++;
 #endif
                     const uint32_t idx = base + (uint32_t)lane;
-                    const bool valid = idx < u_hi;
-                    const uint32_t e = s_list[valid ? idx : u_lo];
+                    const uint32_t e = s_list[idx < u_hi ? idx : u_lo];
                     const uint32_t rel = e & OFFM, dn = u_irel - rel;
-                    const bool ok = valid && dn - 1u < W && (e >> C::OFFB) == u_tag;   // candidate start in [i-W, i), same bigram up to the tag
-                    if (__ballot(valid && (rel >> CSH) > u_blk_i)) u_hi = base;       // the rest of the bucket starts after i: this is the last round
+                    // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
+                    const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ u_tag) << 20)) < W;
+                    if (__ballot((rel >> CSH) > u_blk_i)) u_hi = base;            // the rest of the bucket starts after i: this is the last round
                     base += 64;
                     if (__ballot(ok)) {
-                        const uint32_t cap = min(dn, u_capE);                  // entirely inside the window, and inside the stream
+                        const uint32_t lim = ok ? min(dn, u_capE) : 0u;        // entirely inside the window, and inside the stream; 0 = not a candidate
                         uint32_t off = C::OFF0;
                         unsigned long long x = lds_load8(sw, rel + off) ^ pat0;
-                        uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                        bool more = ok && n == 8 && off + 8 < cap;
-                        while (__ballot(more)) {                               // longer than eight bytes: the lanes concerned go on, eight at a time
+                        uint32_t room = x == 0 ? lim : 0u;                     // eight equal bytes so far: the match may run on up to here
+                        while (__ballot(off + 8 < room)) {                     // longer than eight bytes: the lanes concerned go on, eight at a time
 #ifdef RSN_CHAIN_STATS
                             n_ext++;
 #endif
-                            if (more) {
-                                off += 8;
-                                x = lds_load8(sw, rel + off) ^ lds_load8(sw, u_irel + off);
-                                n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                                more = n == 8 && off + 8 < cap;
-                            }
-                            if (__ballot(more && off + 8 >= HLMAX)) { longm = true; more = false; }
+                            const bool go = off + 8 < room;                    // (every lane computes, the lanes concerned commit)
+                            const uint32_t off2 = off + 8;
+                            const unsigned long long x2 = lds_load8(sw, rel + off2) ^ lds_load8(sw, u_irel + off2);
+                            off = go ? off2 : off;
+                            x = go ? x2 : x;
+                            room = go ? (x2 == 0 ? room : 0u) : 0u;
+                            if (__ballot((room ? off + 8 : 0u) >= HLMAX)) { longm = true; room = 0; }
                         }
-                        uint32_t len = min(off + n, cap);
+                        const uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                        uint32_t len = min(off + n, lim);
                         if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
-                        best = max(best, (ok && len) ? (len << 16) | dn : 0u); // longest, then farthest back (bytes.Index, lzss.go:419)
+                        best = max(best, len ? (len << 16) | dn : 0u);        // longest, then farthest back (bytes.Index, lzss.go:419)
                     }
                 }
                 best = wave_max_u32(best);
