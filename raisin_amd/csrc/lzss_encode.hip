@@ -667,15 +667,21 @@ struct ChainCfg {
 #define RSN_DPP_QUAD_XOR2 0x4E
 #define RSN_DPP_ROW_HALF_MIRROR 0x141
 #define RSN_DPP_ROW_MIRROR 0x140
+#define RSN_DPP_ROW_BCAST15 0x142
+#define RSN_DPP_ROW_BCAST31 0x143
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {       // the maximum over the 64 lanes, wave-uniform
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR1, 0xF, 0xF, true));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR2, 0xF, 0xF, true));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_MIRROR, 0xF, 0xF, true));   // every lane: maximum of its row of 16
-    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false)); // rows 1 and 3 take in the row before
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false)); // rows 2 and 3 take in lane 31: lane 63 has it all
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the same value, but in a vector register and opaque to the compiler's uniformity analysis: what is computed from it is
+// computed by the vector units (this kernel is bound by the CU's one scalar unit)
+__device__ __forceinline__ uint32_t vec(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
 template <class C>
 __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
@@ -816,15 +822,15 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
         if (alive) {
             // (issued by the whole wavefront on one address: the compiler's atomic optimiser turns it into one LDS atomic by the first lane)
             const uint32_t old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
-            mine = !((uni(old) >> (u_kp & 31)) & 1);                      // somebody else's already: that wavefront walks the rest
+            mine = !(__ballot((old >> (u_kp & 31)) & 1) & 1ull);          // lane 0 holds the word as it was: somebody else's already = that wavefront walks the rest
         }
         if (mine) {
             const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
             // (the bigram, its bucket index and tag stay in vector registers although they are wave-uniform: scalar issue is the bound)
             const uint32_t u_b0 = sb[u_irel], u_b1 = sb[u_irel + 1];
             uint32_t best = 0;
-            bool longm = false, giveup_heavy = false, giveup_dense = false;
-            if (u_capE >= 2) {
+            bool longm = false;
+            {   // (a position with a single byte left needs no case of its own: the stage is zero behind the stream and L is capped at E - i)
                 const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
                 // (bucket bounds and the bisection's arithmetic stay in VECTOR registers although every lane holds the same values:
                 //  the scalar unit is this kernel's bound; only the ballots and the loop branches are scalar)
@@ -885,47 +891,52 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                 }
                 best = wave_max_u32(best);
             }
-            if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
-                           // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
-                const uint32_t Lp = min(W, u_capE);
-                bool eq = u_ipos >= W;
-                if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
-                if (__ballot(!eq)) giveup_heavy = true;
-                else best = (Lp << 16) | W;
-            }
-            if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
-                // (the density test sits on this path because dense data comes through here all the time, text rarely)
-                if (!(a.redo & 1u) && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
-                else {
-                    const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
-                    const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
-                    bool hit = false;
-                    if (fb_lo < fb_hi) {
-                        const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
-                        hit = (s_present[u_b0] & m) != 0;
-                    }
-                    if (!hit) {                                               // the two ragged ends, byte by byte
-                        const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
-                        bool f = false;
-                        for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
-                        for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
-                        hit = __ballot(f) != 0;
-                    }
-                    best = hit ? (1u << 16) : 0u;
-                }
-            }
-            if (giveup_heavy || giveup_dense) {
-                // the start counter is pushed past every item; the other wavefronts finish the chain they are on (text: a handful
-                // of visits; dense data: they run into this test themselves within DENSE_EVALS visits) and find nothing more to start
-                if (lane == 0) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
-                alive = false;
-            } else {
-                a.keys[u_ipos] = best;                                        // (all 64 lanes, one address: one request, and no exec-mask bookkeeping on the scalar unit)
-                u_next = u_kp + max(1u, best >> 16);                          // lzss.go:139-142: a reference skips size-1 positions
+            auto commit = [&](uint32_t key) {
+                a.keys[vec(u_ipos)] = key;                                    // (all 64 lanes, one address: one request, and no exec-mask bookkeeping on the scalar unit)
+                u_next = vec(u_kp) + max(1u, vec(key) >> 16);                 // lzss.go:139-142: a reference skips size-1 positions
                 visits++;
 #ifdef RSN_CHAIN_STATS
                 n_evals++;
 #endif
+            };
+            if (best != 0 && !longm) commit(best);                            // the common case first, with nothing else on its path
+            else {
+                bool giveup_heavy = false, giveup_dense = false;
+                if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
+                               // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
+                    const uint32_t Lp = min(W, u_capE);
+                    bool eq = u_ipos >= W;
+                    if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
+                    if (__ballot(!eq)) giveup_heavy = true;
+                    else best = (Lp << 16) | W;
+                }
+                if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
+                    // (the density test sits on this path because dense data comes through here all the time, text rarely)
+                    if (!(a.redo & 1u) && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
+                    else {
+                        const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
+                        const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
+                        bool hit = false;
+                        if (fb_lo < fb_hi) {
+                            const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
+                            hit = (s_present[u_b0] & m) != 0;
+                        }
+                        if (!hit) {                                               // the two ragged ends, byte by byte
+                            const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
+                            bool f = false;
+                            for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
+                            for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
+                            hit = __ballot(f) != 0;
+                        }
+                        best = hit ? (1u << 16) : 0u;
+                    }
+                }
+                if (giveup_heavy || giveup_dense) {
+                    // the start counter is pushed past every item; the other wavefronts finish the chain they are on (text: a handful
+                    // of visits; dense data: they run into this test themselves within DENSE_EVALS visits) and find nothing more to start
+                    if (lane == 0) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
+                    alive = false;
+                } else commit(best);
             }
         }
     }
