@@ -820,9 +820,10 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
         }
         bool mine = false;
         if (alive) {
-            // (issued by the whole wavefront on one address: the compiler's atomic optimiser turns it into one LDS atomic by the first lane)
-            const uint32_t old = atomicOr(&s_claim[u_kp >> 5], 1u << (u_kp & 31));
-            mine = !(__ballot((old >> (u_kp & 31)) & 1) & 1ull);          // lane 0 holds the word as it was: somebody else's already = that wavefront walks the rest
+            const uint32_t v_kp = vec(u_kp);                               // (address and bit from vector registers, the atomic by lane 0 alone)
+            uint32_t old = 0;
+            if (lane == 0) old = atomicOr(&s_claim[v_kp >> 5], 1u << (v_kp & 31));
+            mine = !__ballot((old >> (v_kp & 31)) & 1);                   // somebody else's already: that wavefront walks the rest
         }
         if (mine) {
             const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                 uint32_t v_lo = u_h ? v_lo0 : 0u;
                 const uint32_t v_hi = ends[u_h];
                 const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
-                const unsigned long long pat0 = lds_load8(sw, u_irel + C::OFF0);  // the position's own bytes: one address for all lanes
+                const unsigned long long pat0 = lds_load8(sw, vec(u_irel) + C::OFF0);  // the position's own bytes: one address for all lanes
                 bool narrowing = v_hi - v_lo > 64;
                 while (__ballot(narrowing)) {                                 // skip the entries before the window, 64-ary
                     const uint32_t n = v_hi - v_lo, stride = (n + 63) >> 6;
@@ -850,22 +851,22 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                     v_lo = min(v_lo + skip * stride, v_hi - 1);               // (skip == 0 leaves v_lo: v_lo < v_hi)
                     narrowing = skip * (stride - 1u) != 0 && v_hi - v_lo > 64;
                 }
-                const uint32_t u_lo = uni(v_lo);
-                uint32_t u_hi = uni(v_hi);
-                uint32_t base = u_lo;
                 // (lane predicates are folded into single vector compares: every s_and_b64 of two lane masks is one more
-                //  instruction on the scalar unit.  A lane beyond the bucket's end re-examines entry u_lo: harmless to a maximum.)
-                while (base < u_hi) {
+                //  instruction on the scalar unit.  A lane beyond the bucket's end re-examines entry v_lo: harmless to a maximum.)
+                uint32_t v_base = v_lo, stop = 0;
+                if (__ballot(v_lo < v_hi)) do {
 #ifdef RSN_CHAIN_STATS
                     n_rounds++;
 #endif
-                    const uint32_t idx = base + (uint32_t)lane;
-                    const uint32_t e = s_list[idx < u_hi ? idx : u_lo];
+                    const uint32_t idx = v_base + (uint32_t)lane;
+                    const uint32_t e = s_list[idx < v_hi ? idx : v_lo];
                     const uint32_t rel = e & OFFM, dn = u_irel - rel;
                     // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
                     const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ u_tag) << 20)) < W;
-                    if (__ballot((rel >> CSH) > u_blk_i)) u_hi = base;            // the rest of the bucket starts after i: this is the last round
-                    base += 64;
+                    v_base += 64;
+                    // the last round if some lane's entry lies after i (the rest of the bucket does then) or no entries remain:
+                    // the sign bits of (block of i - block of the entry) and of NOT (next base - end), one vector value, one branch
+                    stop = ((u_blk_i - (rel >> CSH)) | ~(v_base - v_hi)) >> 31;
                     if (__ballot(ok)) {
                         const uint32_t lim = ok ? min(dn, u_capE) : 0u;        // entirely inside the window, and inside the stream; 0 = not a candidate
                         uint32_t off = C::OFF0;
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                         if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
                         best = max(best, len ? (len << 16) | dn : 0u);        // longest, then farthest back (bytes.Index, lzss.go:419)
                     }
-                }
+                } while (!__ballot(stop));
                 best = wave_max_u32(best);
             }
             auto commit = [&](uint32_t key) {
