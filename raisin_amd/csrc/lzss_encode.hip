@@ -1074,6 +1074,42 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
     }
 }
 
+// The same in-tile parse, serially: ONE LANE per walked tile follows i -> i + max(1, L) from the warm-up start through the keys
+// in memory (every position it lands on has one: the walk claimed and evaluated it), flags what lies inside the tile, adds up the
+// output bytes and reports entry and exit.  About 1 560 dependent loads per tile, most of them L2 hits (three chain positions share
+// a 64-byte line), and every tile of the stream has its own lane -- no LDS, no ranks, no doubling rounds, and no block left waiting
+// on the scalar unit, which is what bounded k_chain_tail (0.76 of its roofline: loop and mask bookkeeping of sixteen rounds).
+// (Four lanes per tile, one per quarter with its own warm-up, measured slower -- 3.3 vs 2.95 ms: the kernel is bound by cache-line
+//  requests, not by the length of a lane's chain.)
+template <class C>
+__global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict__ keys, uint32_t E, uint32_t n_tiles, TileChain *__restrict__ tchain,
+                                                     uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+    constexpr uint32_t CT = C::CT, CH = C::CH, WORDS = CT / 32;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_tiles) return;
+    const TileChain tc = tchain[k];
+    if (tc.walked != 1 || tc.exit != 0) return;                           // periodic / dense / heavy tile, or resolved by an earlier launch
+    const unsigned long long t0 = (unsigned long long)k * CT, t1 = min(t0 + CT, (unsigned long long)E);
+    unsigned long long p = t0 - CH + tc.pad;                              // the warm-up start (position 0 in tile 0)
+    while (p < t0) p += max(1u, keys[p] >> 16);                           // the warm-up chain: merged with the true one long before the tile
+    const unsigned long long entry = p;
+    uint32_t *fw = flags + (size_t)k * WORDS;
+    uint32_t wi = 0, word = 0;
+    unsigned long long bytes = 0;
+    while (p < t1) {
+        const uint32_t key = keys[p], L = key >> 16, r = (uint32_t)(p - t0);
+        while (wi < (r >> 5)) { fw[wi++] = word; word = 0; }              // (every word of the tile is written exactly once, in order)
+        word |= 1u << (r & 31);
+        const uint32_t el = enc_len(key & 0xFFFFu, L);
+        bytes += L == 0 ? 1u : (el < L ? el : L);                         // token only if strictly shorter than the bytes it stands for (lzss.go:143)
+        p += max(1u, L);
+    }
+    while (wi < WORDS) { fw[wi++] = word; word = 0; }
+    tile_bytes[k] = bytes;
+    tchain[k] = TileChain{(uint32_t)entry, (uint32_t)p, 1u, 0u};
+}
+
+
 // W-periodic tiles (config 3 is nothing else) have a key at every position -- L = min(W, E-p) at distance W -- and
 // no chain of their own: chains of different phase never merge in periodic data, the phase is handed on from tile
 // to tile.  k_prev_walked finds, for every tile, the nearest tile before it whose chain was really walked (an
@@ -1671,8 +1707,11 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         uint32_t *d_prev_part = (uint32_t *)pp;
         auto resolve = [&]() -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
-            RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-            RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switch: the in-tile parse by pointer doubling in LDS
+            if (doubling) {
+                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+            } else RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
