@@ -1091,13 +1091,25 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
     if (tc.walked != 1 || tc.exit != 0) return;                           // periodic / dense / heavy tile, or resolved by an earlier launch
     const unsigned long long t0 = (unsigned long long)k * CT, t1 = min(t0 + CT, (unsigned long long)E);
     unsigned long long p = t0 - CH + tc.pad;                              // the warm-up start (position 0 in tile 0)
-    while (p < t0) p += max(1u, keys[p] >> 16);                           // the warm-up chain: merged with the true one long before the tile
+    // keys come in aligned groups of four (one 16-byte load); a short step often stays inside the group it has
+    uint4 grp = {0, 0, 0, 0};
+    unsigned long long have = ~0ull;
+    auto key_at = [&](unsigned long long q) {
+        if ((q >> 2) != have) {
+            have = q >> 2;
+            if (4 * have + 4 <= (unsigned long long)E) grp = *reinterpret_cast<const uint4 *>(keys + 4 * have);
+            else { grp.x = keys[4 * have]; grp.y = 4 * have + 1 < E ? keys[4 * have + 1] : 0u; grp.z = 4 * have + 2 < E ? keys[4 * have + 2] : 0u; grp.w = 0u; }
+        }
+        const uint32_t sel = (uint32_t)q & 3u;
+        return sel == 0 ? grp.x : sel == 1 ? grp.y : sel == 2 ? grp.z : grp.w;
+    };
+    while (p < t0) p += max(1u, key_at(p) >> 16);                         // the warm-up chain: merged with the true one long before the tile
     const unsigned long long entry = p;
     uint32_t *fw = flags + (size_t)k * WORDS;
     uint32_t wi = 0, word = 0;
     unsigned long long bytes = 0;
     while (p < t1) {
-        const uint32_t key = keys[p], L = key >> 16, r = (uint32_t)(p - t0);
+        const uint32_t key = key_at(p), L = key >> 16, r = (uint32_t)(p - t0);
         while (wi < (r >> 5)) { fw[wi++] = word; word = 0; }              // (every word of the tile is written exactly once, in order)
         word |= 1u << (r & 31);
         const uint32_t el = enc_len(key & 0xFFFFu, L);
@@ -1705,10 +1717,12 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
         uint32_t *d_prev_part = (uint32_t *)pp;
-        auto resolve = [&]() -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
+        auto resolve = [&](bool second) -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
             static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switch: the in-tile parse by pointer doubling in LDS
-            if (doubling) {
+            // (the second look concerns a handful of tiles, dense ones among them: a lone lane's 8 000 dependent loads would be all
+            //  the call waits for -- there the block-per-tile kernel, which returns at once everywhere else, is the faster one)
+            if (doubling || second) {
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
             } else RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
@@ -1721,7 +1735,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             RSN_HIP(hipStreamSynchronize(s));
             return RSN_OK;
         };
-        rc = resolve(); if (rc) return rc;
+        rc = resolve(false); if (rc) return rc;
         parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
@@ -1730,7 +1744,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(not_walked), dim3(CC::CTH), 0, s, ha);
-            rc = resolve(); if (rc) return rc;
+            rc = resolve(true); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
             if (dbg) fprintf(stderr, "lzss chain walk, second look: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         }
