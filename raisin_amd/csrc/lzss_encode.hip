@@ -424,6 +424,9 @@ __device__ __forceinline__ ChainTail chain_tail() {
 __device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len);
 
 
+// eight staged bytes from any byte offset: three aligned dwords and two v_alignbyte.  (gfx950's LDS takes unaligned accesses, and
+// the compiler emits ONE ds_read_b64 for an align-1 load -- but an unaligned wave-instruction is replayed: the chain walk went from
+// 37 to 70 ms with it, k_match_hash from 20 to 27.)
 __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint32_t rel) {
     const uint32_t q = rel >> 2;
     const uint32_t w0 = sw[q], w1 = sw[q + 1], w2 = sw[q + 2];
