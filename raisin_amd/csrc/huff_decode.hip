@@ -579,7 +579,10 @@ void build_second_level(const std::vector<int32_t> &child, int K, bool byte_alph
         while (cap > 0 && total(cap) > budget) cap--;
     }
     if (cap == 0) return;                                          // (the entries stay "node, walked bit by bit")
-    struct It { int32_t node; uint32_t prefix; unsigned q; };
+    // Sub-tables are written in the device's index order straight away: the device reads the stream LSB-first, so the
+    // path bits of a node form the LOW bits of its index (first bit lowest) and a leaf at depth q fills every index whose low
+    // q bits are its path -- a strided fill instead of a contiguous one, and no permutation pass over 10^6 entries afterwards.
+    struct It { int32_t node; uint32_t path; unsigned q; };               // path: bit i = the i-th bit taken below the K-bit prefix
     std::vector<It> st;
     for (uint32_t v : longs) {
         const int32_t top = (int32_t)(lut[v] & 0x3FFFFFFu);
@@ -590,14 +593,14 @@ void build_second_level(const std::vector<int32_t> &child, int K, bool byte_alph
         while (!st.empty()) {
             const It it = st.back();
             st.pop_back();
-            if (it.q == sb) { lut2[off + it.prefix] = 0x80000000u | (uint32_t)it.node; continue; }   // still inside the tree after K + sb bits
+            if (it.q == sb) { lut2[off + it.path] = 0x80000000u | (uint32_t)it.node; continue; }   // still inside the tree after K + sb bits
             for (int b = 0; b < 2; b++) {
                 const int32_t k = child[2 * (size_t)it.node + b];
-                const uint32_t pre = (it.prefix << 1) | (uint32_t)b;
-                if (k >= 0) { st.push_back({k, pre, it.q + 1}); continue; }
-                const uint32_t ent = ((uint32_t)(K + it.q + 1) << 24) | (uint32_t)(-(k + 1));
-                const unsigned rest = sb - (it.q + 1);
-                for (uint32_t x = 0; x < (1u << rest); x++) lut2[off + (pre << rest) + x] = ent;
+                const uint32_t path = it.path | ((uint32_t)b << it.q);
+                const unsigned q1 = it.q + 1;
+                if (k >= 0) { st.push_back({k, path, q1}); continue; }
+                const uint32_t ent = ((uint32_t)(K + q1) << 24) | (uint32_t)(-(k + 1));
+                for (uint32_t y = 0; y < (1u << (sb - q1)); y++) lut2[off + path + (y << q1)] = ent;
             }
         }
         lut[v] = 0x80000000u | (sb << 26) | off;
@@ -709,6 +712,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const bool short_codes = codes.max_len <= (unsigned)K;
     std::vector<uint32_t> lut; std::vector<int32_t> child;
     build_tables(tree, K, lut, child);
+    const auto t4 = now();
     // byte alphabets: the unified table (up to three whole codewords per K-bit window)
     static const bool no_multi = getenv("RSN_NO_MULTI") != nullptr;
     unsigned long long n_syms_total = 0;
@@ -735,20 +739,14 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     std::vector<uint32_t> lut2;
     static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
     if (!short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
-    {   // the device reads the stream LSB-first: entry v moves to the index with v's K bits reversed; sub-tables likewise
-        auto rev = [](uint32_t v, unsigned bits) { return bits ? __builtin_bitreverse32(v) >> (32 - bits) : 0u; };
+    const auto t5 = now();
+    {   // the device reads the stream LSB-first: first-level entry v moves to the index with v's K bits reversed
+        //     (the second level is built in that order, see build_second_level)
         std::vector<uint32_t> t(lut.size());
-        for (uint32_t v = 0; v < (1u << K); v++) t[rev(v, (unsigned)K)] = lut[v];
+        for (uint32_t v = 0; v < (1u << K); v++) t[K ? __builtin_bitreverse32(v) >> (32 - K) : 0u] = lut[v];
         lut.swap(t);
-        t.assign(lut2.size(), 0);
-        for (uint32_t v = 0; v < (1u << K); v++) {
-            const uint32_t e = lut[v], sb = (e >> 26) & 31u, off = e & 0x3FFFFFFu;
-            if (!(e & 0x80000000u) || !sb || lut2.empty()) continue;
-            for (uint32_t u = 0; u < (1u << sb); u++) t[off + rev(u, sb)] = lut2[off + u];
-        }
-        lut2.swap(t);
     }
-    if (host_timing) fprintf(stderr, "huffman decode host: tables %.2f ms (second level %zu entries)\n", ms(t3, now()), lut2.size());
+    if (host_timing) fprintf(stderr, "huffman decode host: first level + child array %.2f ms, second level %.2f ms (%zu entries), bit-reversal %.2f ms\n", ms(t3, t4), ms(t4, t5), lut2.size(), ms(t5, now()));
     static const bool dbg = getenv("RSN_DEC_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "huffman decode tables: K %d, longest code %u, %zu tree nodes, second level %zu entries (%s)\n", K, codes.max_len, child.size() / 2, lut2.size(), lut2.size() <= (size_t)LUT2_LDS ? "LDS" : "L2");
     rc = dev_buf(c, 5, (lut.size() + child.size() + lut2.size()) * 4 + 64, &p); if (rc) return rc;
