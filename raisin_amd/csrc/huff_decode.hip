@@ -42,6 +42,7 @@ constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code th
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
+constexpr int OUT_STAGE_RUNE = 40960; // the same for rune alphabets: a rune is up to four bytes (two blocks per CU instead of four, but coalesced stores)
 constexpr int CHILD_LDS = 256;      // child[] of a byte alphabet (<= 2 * 127 entries) is staged in LDS
 constexpr int LUT2_LDS = 768;       // second-level entries that fit in LDS (larger second levels are read through L2)
 constexpr uint32_t LUT2_GLOBAL_MAX = 1u << 20;   // entries of a second level kept in device memory (4 MB)
@@ -359,7 +360,8 @@ template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_data[DATA_PHYS];
     __shared__ uint32_t s_lut[LUT_WORDS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_STAGE + 32];
+    constexpr int STAGE = ASCII ? OUT_STAGE : OUT_STAGE_RUNE;
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
     const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
     if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
-    if (ASCII) for (int i = tid; i < (OUT_STAGE + 32) / 16; i += DB) reinterpret_cast<uint4 *>(s_out)[i] = make_uint4(0, 0, 0, 0);
+    if (ASCII) for (int i = tid; i < (STAGE + 32) / 16; i += DB) reinterpret_cast<uint4 *>(s_out)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
         const uint32_t my_off = wpre + incl - nb;                 // byte offset of this lane inside the block's output
         uint8_t *dst = a.out + a.blk_off[blk];
         const uint32_t al = (uint32_t)((uintptr_t)dst & 15);      // LDS image is shifted so that 16-byte units line up with global memory
-        const bool staged = total + al <= OUT_STAGE;              // uniform per block
+        const bool staged = total + al <= (uint32_t)STAGE;        // uniform per block
         if (ASCII && staged) {
             // Byte alphabets: the lane knows how many symbols it owes (nb), so the walk is count-driven and takes up to
             // three codewords per table lookup to the very end; the bytes collect in a 64-bit register and leave as
