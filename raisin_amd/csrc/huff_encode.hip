@@ -781,6 +781,9 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh);
     RSN_HIP(hipMemcpyAsync(h, d_rh, (size_t)kMaxRune * 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
+    size_t present = 0;
+    for (uint32_t r = 0; r < kMaxRune; r++) present += h[r] != 0;
+    syms.reserve(present);
     for (uint32_t r = 0; r < kMaxRune; r++) if (h[r]) syms.push_back({r, h[r]});
     return RSN_OK;
 }
