@@ -653,7 +653,7 @@ template <int CT_, int CTH_, int CS_>
 struct ChainCfg {
     static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
     static constexpr int CSH = 8;                           // a bucket's entries are ordered by staged offset >> CSH
-    static constexpr int CH = 256;                          // warm-up positions before the tile
+    static constexpr int CH = 128;                          // warm-up positions before the tile
     static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
     static constexpr int OFFB = NS <= 8192 ? 13 : NS <= 16384 ? 14 : 15;   // bits of a staged offset in a list entry
     static constexpr int TAGB = 16 - OFFB;                  // the rest carries bits 5.. of the second byte
@@ -700,7 +700,10 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __shared__ uint32_t s_heavy, s_next, s_dense;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
-    const uint32_t bx = (a.redo & 2u) ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;     // the tile; a second launch holds only the tiles that gave up as "dense" the first time (k_chain_verify lists them)
+    // the tile.  A partial launch takes it from a list (k_chain_verify's: the tiles that gave up as "dense", and -- top bit set -- the tiles
+    // whose warm-up chain had not merged with the true chain by the time it entered them: those start from the tile before's exit instead)
+    const uint32_t list_entry = (a.redo & 2u) ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;
+    const uint32_t bx = list_entry & 0x7FFFFFFFu;
     const long long t0 = (long long)bx * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
@@ -796,7 +799,8 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     //      named u_* is the same in all 64 lanes.
     const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0);
     const uint32_t kp_end = CH + npos;                                    // a chain stops when it leaves the tile
-    const uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                 // the warm-up start (CH in tile 0: the true start)
+    uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                       // the warm-up start (CH in tile 0: the true start)
+    if (list_entry >> 31) kp_first = chain_tail().tchain[bx - 1].exit - (uint32_t)(t0 - CH);   // the true entry, known from the first look
     const uint32_t nitems = 1 + (npos + CS - 1) / CS;
     // a wavefront that gives up (s_heavy) also pushes the start counter past every item: the others
     // finish the chain they are on (at most CS-odd positions) and find nothing more to start
@@ -1251,18 +1255,29 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
         else ok = ok && c.exit >= E && c.exit != 0xFFFFFFFFu;
         ok = ok && c.entry != 0xFFFFFFFFu;
     }
-    // bad[0]: tiles that gave up (dense / heavy), bad[1]: chains that do not join, bad[2]: periodic tiles that could not be placed
-    // (one atomic per wavefront and class: config 3's first look fails 131071 times)
+    // bad[0]: tiles that gave up (dense / heavy), bad[1]: chains that do not join, bad[2]: periodic tiles that could not be placed,
+    // bad[3]: length of the list for a second look (one atomic per wavefront and class: config 3's first look fails 131071 times)
     const uint32_t cls = c.walked == 1 ? 1u : (c.walked == 2 ? 2u : 0u);
 #pragma unroll
     for (uint32_t q = 0; q < 3; q++) {
         const unsigned long long m = __ballot(live && !ok && cls == q);
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
+    }
+    // The list: a tile that gave up is walked again without the density test; a walked tile whose entry is not the exit of the
+    // (resolved) tile before it -- its warm-up chain had not merged with the true chain yet -- is walked again from that exit.
+    const bool gave = live && cls == 0;
+    bool fix = false;
+    if (live && !gave && k + 1 < n_tiles && c.entry != 0xFFFFFFFFu && (c.walked == 1 || c.pad == 1)) {
+        const TileChain nx = tc[k + 1];
+        fix = nx.walked == 1 && nx.entry != c.exit && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile &&
+              (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && c.exit < E;
+    }
+    const unsigned long long ml = __ballot(gave || fix);
+    if (ml) {
         uint32_t at = 0;
-        if (m && (threadIdx.x & 63) == 0) at = atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
-        if (q == 0 && m) {                                                // the tiles that gave up, listed for a second look
-            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-            if (((m >> (threadIdx.x & 63)) & 1) && at < redo_cap) redo_list[at] = k;
-        }
+        if ((threadIdx.x & 63) == 0) at = atomicAdd(&bad[3], (uint32_t)__builtin_popcountll(ml));
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__builtin_popcountll(ml & ((1ull << (threadIdx.x & 63)) - 1ull));
+        if ((gave || fix) && at < redo_cap) redo_list[at] = gave ? k : ((k + 1) | 0x80000000u);
     }
 }
 
@@ -1742,14 +1757,17 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
-        const uint32_t not_walked = (uint32_t)h64[1];
-        if (!parsed && !no_fused && not_walked && not_walked <= redo_cap) {
-            // a few tiles gave up (a stretch of one- and two-byte steps looked "dense"): walk just those, without that test, and check again
+        // A few tiles gave up (a stretch of one- and two-byte steps looked "dense"), or entered on a chain that had not merged with the
+        // true one yet: walk just those -- without that test / from the true entry, the tile before's exit -- and check again.  A joint
+        // next to a tile that gave up can only be judged once that tile is resolved, hence up to three looks (each costs a few tiles).
+        for (int look = 2; look <= 4 && !parsed && !no_fused; look++) {
+            const uint32_t n_list = (uint32_t)(h64[2] >> 32);
+            if (n_list == 0 || n_list > redo_cap) break;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
-            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(not_walked), dim3(CC::CTH), 0, s, ha);
+            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(n_list), dim3(CC::CTH), 0, s, ha);
             rc = resolve(true); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
-            if (dbg) fprintf(stderr, "lzss chain walk, second look: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
+            if (dbg) fprintf(stderr, "lzss chain walk, look %d: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", look, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         }
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
             RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);

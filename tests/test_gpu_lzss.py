@@ -372,3 +372,19 @@ def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
             assert ("lzss_match_chain" in p) == walks
         assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
         assert lz.Decompress(c) == data
+
+
+def test_chain_entry_fixed_by_second_look(lz, oracle):
+    """A tile whose warm-up chain has not merged with the true chain when it enters the tile: a 200-periodic stretch
+    lies across a tile boundary under a 300-byte window (chains of different phase keep their phase inside it), text
+    on both sides.  k_chain_verify lists the tile, the second look walks it from the true entry (the tile before's
+    exit) and the per-tile chains join: no general parse."""
+    rng = random.Random(41)
+    period = bytes(rng.randrange(97, 123) for _ in range(200))
+    for lead in (8192 - 900, 2 * 8192 - 1500, 8192 - 140):
+        data = text(51, lead) + (period * 12)[:2100] + text(52, 30000)
+        c, p = _prof(lz, data, 300)
+        assert c == oracle.lzss_compress(data, 300)
+        assert lz.Decompress(c) == data
+        if _chain_mode() and "RSN_LZSS_NO_FUSED_PARSE" not in __import__("os").environ:
+            assert 2 <= p["lzss_match_chain"][0] <= 4 and "lzss_parse_mark" not in p, sorted(p)
