@@ -229,7 +229,7 @@ def test_device_resident_16MiB(lz, oracle):
 # ---- chain walk (k_match_chain): keys only where greedy chains land -------------------------
 def long_copies(seed, n, seg=(90, 240)):
     """Matches of 90..240 bytes from up to 3000 back, one fresh byte between them: a chain step is
-    about as long as the 256-position warm-up, so the warm-up chain often has NOT merged with the
+    about as long as the warm-up, so the warm-up chain often has NOT merged with the
     true chain when it reaches its tile and the parse lands on unevaluated positions."""
     rng = np.random.default_rng(seed)
     out = bytearray(rng.integers(97, 123, size=4096, dtype=np.uint8).tobytes())
@@ -289,9 +289,9 @@ def test_chain_dense_and_mixed(lz, oracle):
 
 
 def test_chain_tile_edges(lz, oracle):
-    """Sizes around the 8192-position chain tile, its 256-position warm-up and the 16384 strip."""
+    """Sizes around the 8192-position chain tile, its warm-up (128 positions; 256 earlier) and the 16384 strip."""
     base = text(31, 40000)
-    for n in (8191, 8192, 8193, 8192 + 255, 8192 + 256, 8192 + 257, 16383, 16384, 16385, 24576 + 1, 32768):
+    for n in (8191, 8192, 8193, 8192 + 127, 8192 + 128, 8192 + 129, 8192 + 255, 8192 + 256, 8192 + 257, 16383, 16384, 16385, 24576 + 1, 32768):
         data = base[:n]
         assert lz.CompressAsync(data) == oracle.lzss_compress(data), n
 
