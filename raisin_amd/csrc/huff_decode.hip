@@ -769,7 +769,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.child_n = (uint32_t)child.size(); a.min_len = codes.min_len;
     a.lut2 = d_lut2; a.lut2_n = (uint32_t)lut2.size();
     a.flat_guess = codes.min_len == codes.max_len;
-    static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 96; }();
+    static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 128; }();
     a.warm = std::min(std::max(warm_env, 0), ORG - 32);
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
