@@ -225,6 +225,9 @@ __global__ __launch_bounds__(ZB) void k_lzd_count(const uint8_t *__restrict__ in
         mine = r.out;
         if (r.err) atomicOr(err, 1);
     }
+    // err[4]: the stream holds a 5C byte somewhere (tokens are digits and punctuation, so that is a literal of the escaped stream: an
+    // escape marker or an escaped backslash).  Without one, DecodeOpeningSymbols is the byte map FF -> '<' and k_lzd_emit applies it.
+    if (__ballot(valid && mask_5c(r.w) != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(&err[4], __ATOMIC_RELAXED) == 0) atomicOr(&err[4], 1);
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
     __syncthreads();
@@ -563,8 +566,17 @@ __global__ __launch_bounds__(DTH) void k_lzd_chain(const uint16_t *__restrict__ 
 // the bytes of every tile of a group, tile after tile: a literal, or a byte of the previous tile's tail
 // Also leaves the unescape stage its per-block summaries (k_une_summary's output) while the bytes
 // are still in registers: one pass over the escaped stream less.
+// 0xFF in every byte of w that equals the byte `c` (exact per byte)
+__device__ __forceinline__ uint32_t emit_bytes_equal(uint32_t w, uint32_t c) {
+    const uint32_t t = w ^ (c * 0x01010101u);
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+    return (z >> 7) * 0xFFu;
+}
+
+// map_ff: the stream holds no 5C at all, so unescaping is the byte map FF -> '<' (lzss.go:391-406, '<' never occurs in the escaped
+// stream): applied to the stored bytes here, `esc` is the caller's output buffer and no unescape pass follows (summ unused).
 __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t E,
-                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ) {
+                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ, int map_ff) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
     __shared__ uint32_t s_last[2][DT / ZTILE];                           // per ZTILE block of the tile: index past its last non-5C byte (by tile parity)
     uint8_t *prev = dsm, *nxt = dsm + TL;
@@ -592,8 +604,13 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
                 const uint32_t b = (v & D_EXT) ? prev[v & D_PAY] : (v & 0xFF);
                 o[q >> 2] |= b << (8 * (q & 3));
             }
-            if (x0 + 16 <= len) *reinterpret_cast<uint4 *>(esc + ts + x0) = make_uint4(o[0], o[1], o[2], o[3]);
-            else for (uint32_t q = 0; x0 + q < len; q++) esc[ts + x0 + q] = (uint8_t)(o[q >> 2] >> (8 * (q & 3)));
+            uint32_t so[4] = {o[0], o[1], o[2], o[3]};                     // what is stored (the tail below keeps the escaped bytes)
+            if (map_ff) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const uint32_t m = emit_bytes_equal(so[j], 0xFFu); so[j] = (so[j] & ~m) | (0x3C3C3C3Cu & m); }
+            }
+            if (x0 + 16 <= len) *reinterpret_cast<uint4 *>(esc + ts + x0) = make_uint4(so[0], so[1], so[2], so[3]);
+            else for (uint32_t q = 0; x0 + q < len; q++) esc[ts + x0 + q] = (uint8_t)(so[q >> 2] >> (8 * (q & 3)));
             if (x0 + 16 > DT - TL) {                                      // this span overlaps the tile's tail
                 for (uint32_t q = 0; q < 16; q++) { const uint32_t x = x0 + q; if (x >= DT - TL) nxt[x - (DT - TL)] = (uint8_t)(o[q >> 2] >> (8 * (q & 3))); }
             }
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
             if (non) atomicMax(&s_last[t & 1][x0 / ZTILE], (x0 % ZTILE) + 32u - (uint32_t)__builtin_clz(non));
         }
         __syncthreads();
-        if (threadIdx.x < DT / ZTILE && threadIdx.x * ZTILE < len) {
+        if (!map_ff && threadIdx.x < DT / ZTILE && threadIdx.x * ZTILE < len) {
             const uint32_t blen = min((uint32_t)ZTILE, len - threadIdx.x * ZTILE), last = s_last[t & 1][threadIdx.x];
             summ[ts / ZTILE + threadIdx.x] = (uint8_t)((last == 0 ? 2 : 0) | ((blen - last) & 1));   // bit1: all 5C; bit0: trailing-run parity
             s_last[t & 1][threadIdx.x] = 0;                               // two tiles (and two barriers) later it is used again
@@ -802,16 +819,18 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     volatile int *hflag = (volatile int *)(h64 + 1);
-    RSN_HIP(hipMemsetAsync(d_flag, 0, 16, s));
+    RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));                          // ... [4] the stream holds a 5C byte
     RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
     rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
     if (h64[0] >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
+    static const bool no_plain = getenv("RSN_LZSS_DEC_UNESCAPE") != nullptr;   // A/B switch: always the separate unescape passes
+    const bool plain = hflag[4] == 0 && !no_plain;                      // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
     rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_esc = (uint8_t *)p;
     const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);                 // unescape blocks
@@ -859,10 +878,15 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, d_comp);
             RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_groups - 1, d_gtail);
         }
-        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, d_esc, d_summ);
+        if (plain) {
+            *out_n = E;
+            if (!d_out || E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
+        }
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (hflag[3]) tile_path = false;                                  // a tile's input did not fit (zero-length tokens): redo with the general path
+        else if (plain) return RSN_OK;                                    // bytes are in place
     }
     if (!tile_path) {
         rc = dev_buf(c, 14, (size_t)E * 4 + 64, &p); if (rc) return rc;
