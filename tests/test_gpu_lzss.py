@@ -388,3 +388,22 @@ def test_chain_entry_fixed_by_second_look(lz, oracle):
         assert lz.Decompress(c) == data
         if _chain_mode() and "RSN_LZSS_NO_FUSED_PARSE" not in __import__("os").environ:
             assert 2 <= p["lzss_match_chain"][0] <= 4 and "lzss_parse_mark" not in p, sorted(p)
+
+
+def test_decode_without_unescape_pass_and_its_capacity_contract(lz, oracle):
+    """A stream without any 5C byte is unescaped by the emit kernel itself (FF -> '<' on its way into the caller's
+    buffer); with a backslash anywhere the separate passes run.  Both honour the size-query contract: a buffer
+    that is too small fails with RSN_ERR_CAPACITY and the needed size, exactly E bytes suffice."""
+    import torch
+    from raisin_amd import _lib
+    base = text(61, 200000).replace(b"\\", b"/")                  # holds "<tag>" (-> FF) but no backslash
+    for data in (base, base[:100000] + b"\\" + base[100000:]):
+        c = oracle.lzss_compress(data)
+        src = torch.frombuffer(bytearray(c), dtype=torch.uint8).cuda()
+        small = torch.empty(len(data) - 1 - (len(data) - 1) % 16, dtype=torch.uint8, device="cuda")
+        with pytest.raises(_lib.RsnError) as ei:
+            _lib.call_dev(_lib.lib().rsn_lzss_decompress_dev, src.data_ptr(), src.numel(), small.data_ptr(), small.numel(), None)
+        assert ei.value.code == _lib.RSN_ERR_CAPACITY and ei.value.needed >= len(data)
+        exact = torch.empty(len(data) + 16 - len(data) % 16, dtype=torch.uint8, device="cuda")[: len(data)]
+        got = _lib.call_dev(_lib.lib().rsn_lzss_decompress_dev, src.data_ptr(), src.numel(), exact.data_ptr(), len(data), None)
+        assert got == len(data) and bytes(exact.cpu().numpy()) == data
