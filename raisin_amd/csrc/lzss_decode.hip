@@ -563,6 +563,24 @@ __global__ __launch_bounds__(DTH) void k_lzd_chain(const uint16_t *__restrict__ 
     }
 }
 
+// The same without the serial walk: an inclusive scan of the group maps under composition.  After the round with stride d, map g
+// is expressed in the tail that precedes group g - 2d + 1 (or in nothing at all: only literals left); ceil(log2(links)) rounds of
+// one gather per entry, every group in parallel, then the literals are the tails' bytes (512 links per GiB: 9 rounds of 4 MB
+// instead of 512 dependent steps of one block).
+__global__ __launch_bounds__(256) void k_lzd_mapscan(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, uint32_t TL, uint32_t d) {
+    const uint32_t g = blockIdx.x;
+    const uint16_t *m = src + (size_t)g * TL, *before = src + (size_t)(g >= d ? g - d : 0) * TL;
+    for (uint32_t j = threadIdx.x; j < TL; j += 256) {
+        uint32_t v = m[j];
+        if (g >= d && (v & D_EXT)) v = before[v & D_PAY];
+        dst[(size_t)g * TL + j] = (uint16_t)v;
+    }
+}
+__global__ __launch_bounds__(256) void k_lzd_map_bytes(const uint16_t *__restrict__ maps, uint32_t TL, uint8_t *__restrict__ gtail) {
+    const size_t base = (size_t)blockIdx.x * TL;
+    for (uint32_t j = threadIdx.x; j < TL; j += 256) { const uint32_t v = maps[base + j]; gtail[base + j] = (v & D_EXT) ? 0 : (uint8_t)v; }   // (a reference before the stream: validated away)
+}
+
 // the bytes of every tile of a group, tile after tile: a literal, or a byte of the previous tile's tail
 // Also leaves the unescape stage its per-block summaries (k_une_summary's output) while the bytes
 // are still in registers: one pass over the escaped stream less.
@@ -855,9 +873,9 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         while (TL < hmax[0]) TL <<= 1;
         rc = dev_buf(c, 14, ((size_t)n_tiles * DT + 64) * 2, &p); if (rc) return rc;
         uint16_t *d_desc = (uint16_t *)p;
-        rc = dev_buf(c, 22, (size_t)n_groups * TL * 3 + 64, &p); if (rc) return rc;
-        uint16_t *d_comp = (uint16_t *)p;
-        uint8_t *d_gtail = (uint8_t *)(d_comp + (size_t)n_groups * TL);
+        rc = dev_buf(c, 22, (size_t)n_groups * TL * 5 + 64, &p); if (rc) return rc;
+        uint16_t *d_comp = (uint16_t *)p, *d_comp2 = d_comp + (size_t)n_groups * TL;   // (two map arrays: the scan below ping-pongs)
+        uint8_t *d_gtail = (uint8_t *)(d_comp2 + (size_t)n_groups * TL);
         ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr};
         static const bool lzd_stats = getenv("RSN_LZD_STATS") != nullptr;
         if (lzd_stats) { void *sp; rc = dev_buf(c, 23, 64, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 64, s)); ra.stats = (unsigned long long *)sp; }
@@ -876,7 +894,17 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         }
         if (n_groups > 1) {
             RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, d_comp);
-            RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_groups - 1, d_gtail);
+            static const bool serial_chain = getenv("RSN_LZSS_DEC_SERIAL_CHAIN") != nullptr;   // A/B switch: one block walks the groups in order
+            const uint32_t n_links = n_groups - 1;
+            if (serial_chain) RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_links, d_gtail);
+            else {
+                const uint16_t *cur = d_comp; uint16_t *oth = d_comp2;
+                for (uint32_t d = 1; d < n_links; d <<= 1) {
+                    RSN_LAUNCH("lzss_dec_chain", k_lzd_mapscan, dim3(n_links), dim3(256), 0, s, cur, oth, TL, d);
+                    const uint16_t *t = cur; cur = oth; oth = const_cast<uint16_t *>(t);
+                }
+                RSN_LAUNCH("lzss_dec_chain", k_lzd_map_bytes, dim3(n_links), dim3(256), 0, s, cur, TL, d_gtail);
+            }
         }
         if (plain) {
             *out_n = E;
