@@ -307,8 +307,13 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
             if (!__syncthreads_or(changed)) break;
         }
         if (live) {
+            const uint16_t new_exit = x == BAD_POS ? (uint16_t)BAD_REL : (uint16_t)(x - lim);
+            // Another pass is needed only if some block hands its successor a different exit than before: a block that decoded
+            // again from a corrected entry and re-synchronised inside itself changes nobody else's parse (only its own byte
+            // count, which the scan picks up).  So the usual decode is pass 0 + one fixing pass, without a third that only verifies.
+            if (a.pass > 0 && tid == DB - 1 && a.exit_rel[g] != new_exit) *a.changed = 1;
             a.entry_rel[g] = e == BAD_POS ? BAD_REL : (uint16_t)(e - my0);
-            a.exit_rel[g] = x == BAD_POS ? BAD_REL : (uint16_t)(x - lim);
+            a.exit_rel[g] = new_exit;
             a.nbyte[g] = (uint16_t)nb;
         }
         unsigned long long sum = live ? nb : 0;
@@ -317,7 +322,6 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         __syncthreads();
         if (tid == 0) {
             a.blk_bytes[blk] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-            if (a.pass > 0) *a.changed = 1;
         }
     }
 }
