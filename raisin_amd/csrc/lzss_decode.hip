@@ -138,6 +138,22 @@ __device__ __forceinline__ Tok parse_tok_w(const uint32_t *sw, int j) {
     if (pc < 1 || pc > 10 || pg < pc + 2 || pg > pc + 11) return t;     // 1..10 digits, ',', 1..10 digits, '>' (the first one)
     const uint32_t need = ((1u << pg) - 1u) & ~(1u << pc);
     if ((dm & need) != need) return t;
+    if (pc <= 4 && pg - pc - 1 <= 4) {
+        // Both numbers have at most four digits (every token of a window up to 9999: all the engine ever writes): no digit loops.
+        // The field's bytes in memory order (first digit lowest) are byte-swapped and shifted so that the LAST digit is the lowest
+        // byte and nothing lies above the first; then two multiply-adds fold the four digits.
+        auto dec4 = [](uint32_t x, uint32_t cnt) {
+            const uint32_t y = __builtin_bswap32(x & 0x0F0F0F0Fu) >> (8 * (4 - cnt));
+            const uint32_t u = (y & 0x00FF00FFu) + 10u * ((y >> 8) & 0x00FF00FFu);
+            return (u & 0xFFFFu) + 100u * (u >> 16);
+        };
+        t.ptr = dec4(a[0], pc);
+        const uint32_t s = pc + 1;                                        // the second number starts here: byte 2 .. 5 after '<'
+        const uint32_t f_lo = __builtin_amdgcn_alignbyte(a[1], a[0], s), f_hi = __builtin_amdgcn_alignbyte(a[2], a[1], s);   // (v_alignbyte uses s[1:0])
+        t.len = dec4(s < 4 ? f_lo : f_hi, pg - pc - 1);
+        t.tl = pg + 2; t.ok = true;
+        return t;
+    }
     const unsigned long long A0 = a[0] | ((unsigned long long)a[1] << 32), A1 = a[2] | ((unsigned long long)a[3] << 32),
                              A2 = a[4] | ((unsigned long long)a[5] << 32);
     auto dig = [&](uint32_t k) { const unsigned long long W = k < 8 ? A0 : k < 16 ? A1 : A2; return (uint32_t)(W >> (8 * (k & 7))) & 0xFu; };
