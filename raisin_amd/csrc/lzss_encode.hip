@@ -686,6 +686,37 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // computed by the vector units (this kernel is bound by the CU's one scalar unit)
 __device__ __forceinline__ uint32_t vec(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
+// W-periodic tiles (config 3 is nothing else): fc[q] == fc[q - W] for every q the tile's matches can reach, so every position p has the
+// key (min(W, E-p), W) (see k_match).  Found by a pass of its own, straight from memory and without LDS -- inside k_match_chain the same
+// check ran at that kernel's two blocks per CU and took 1.5 ms per GiB of periodic data; other tiles fail the first wavefront's sample
+// (64 x 16 bytes) and cost next to nothing.  Nobody writes a periodic tile's keys (4 bytes per position for nothing): k_chain_periodic
+// places the chain by arithmetic, k_tok_emit computes the key of a flagged position, k_chain_unknown stores them only if the general
+// parse has to take over.  Every tile's record is (re)initialised here: walked = 2 for a periodic tile, 0 otherwise.
+__global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict__ fc, uint32_t E, uint32_t W, uint32_t tile, TileChain *__restrict__ tchain) {
+    const int tid = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * tile;
+    bool ok = t0 >= (long long)W;                                         // (the first window has nothing to repeat)
+    if (ok) {
+        const long long q_end = min(t0 + (long long)tile + (long long)W - 1, (long long)E);
+        auto same16 = [&](long long q) {                                  // fc[q .. q+16) against the same bytes W earlier, clipped at q_end
+            if (q >= q_end) return true;
+            if ((W & 15u) == 0 && q + 16 <= q_end) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(fc + q), y = *reinterpret_cast<const uint4 *>(fc + q - W);
+                return x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+            }
+            bool eq = true;
+            for (long long k = q; k < min(q + 16, q_end); k++) eq = eq && fc[k] == fc[k - W];
+            return eq;
+        };
+        ok = tid >= 64 || same16(t0 + 16ll * tid);                        // the sample: the tile's first kilobyte
+        if (__syncthreads_and(ok)) {
+            for (long long q = t0 + 16ll * tid; q < q_end; q += 16ll * 256) ok = ok && same16(q);
+            ok = __syncthreads_and(ok);
+        } else ok = false;
+    }
+    if (tid == 0) tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0};
+}
+
 template <class C>
 __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = C::CS, CH = C::CH, NS = C::NS;
@@ -711,6 +742,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     uint32_t n_evals = 0, n_rounds = 0, n_ext = 0;
 #endif
+    if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
     for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
         const long long P = r0 + 16ll * v;
         uint4 x = {0, 0, 0, 0};
@@ -727,24 +759,6 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
     if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; }
     __syncthreads();
-
-    constexpr uint32_t T0 = HWMAX + CH;                                   // staged offset of the tile's first position
-    if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match)
-        bool ok = true;
-        const uint32_t qn = (uint32_t)min((long long)(CT + HLMAX), (long long)E - t0);
-        for (uint32_t q = tid; q < qn; q += CTH) ok = ok && sb[T0 + q] == sb[T0 + q - W];
-        if (__syncthreads_and(ok)) {
-            const long long q_end = min(t0 + (long long)CT + (long long)W - 1, (long long)E);
-            for (long long q = t0 + CT + HLMAX + tid; q < q_end; q += CTH) ok = ok && a.fc[q] == a.fc[q - W];
-            if (__syncthreads_and(ok)) {
-                // W-periodic: every position p has the key (min(W, E-p), W).  Nobody writes them (4 bytes per position for nothing):
-                // k_chain_periodic places the chain by arithmetic, k_tok_emit computes the key of a flagged position, and
-                // k_chain_unknown stores them only if the general parse has to take over.
-                if (tid == 0) chain_tail().tchain[bx] = TileChain{0, 0, 2u, 0};
-                return;
-            }
-        }
-    }
 
     // ---- group the staged positions by bigram (as k_match_hash): candidates are [rlo, rhi)
     const long long q0 = max(0ll, t0 - CH);                               // the warm-up chain starts here
@@ -1700,6 +1714,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // Nearly incompressible input is the one case where the chain walk loses (every tile walks a few dozen visits per wavefront,
     // gives up as dense, and the bucket search does it all again: 57 against 41 ms per GiB of random bytes).  Large inputs walk a
     // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
+    if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain);
     constexpr uint32_t SAMPLE_TILES = 64;
     static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
     if (chain_mode && !no_sample && n_pt >= 16 * SAMPLE_TILES) {
