@@ -130,7 +130,7 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
     def gpu_bytes(t):
         return bytes(t.cpu().numpy())
 
-    for name in names:
+    def one(name):
         src = W.config_input("4" if name == "4" else name, n, device)
         layers = {"2b": ["huffman"], "skewed": ["huffman"], "3": ["lzss"], "4": ["lzss", "huffman"]}[name]
         enc = {"huffman": huffman.compress_tensor, "lzss": lz.compress_tensor}
@@ -236,6 +236,13 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
         out[name] = ent
         del src, c, d, ebuf, dbuf
         torch.cuda.empty_cache()
+
+    for name in names:
+        try:
+            one(name)
+        except Exception as e:          # noqa: BLE001 -- reported in the line, the other configs still run
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     return out
 
 
@@ -410,22 +417,29 @@ def main():
             from oracle import oracle as O
             O.build()
             cores = O.host_cores()
+            # (everything below is extra information: whatever goes wrong there is reported in the line, never instead of it)
             if not args.no_cpu:
-                def make(k):
-                    return bytes(src[:min(k, n)].cpu().numpy())
-                cb = cpu_huffman(make, cores)
-                smp = cb["_s"]
-                pre = min(len(smp), 32 << 20)              # the threaded baseline's bytes on the whole sample, the plain oracle's on a prefix
-                ok = bytes(huffman.compress_tensor(src[:len(smp)].contiguous()).cpu().numpy()) == cb["_c"]
-                ok = ok and bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy()) == O.huffman_compress(smp[:pre])
-                out["bit_exact_vs_oracle_on_sample"] = bool(ok)
-                out["cpu_baseline"] = _public(cb)
+                try:
+                    def make(k):
+                        return bytes(src[:min(k, n)].cpu().numpy())
+                    cb = cpu_huffman(make, cores)
+                    smp = cb["_s"]
+                    pre = min(len(smp), 32 << 20)          # the threaded baseline's bytes on the whole sample, the plain oracle's on a prefix
+                    ok = bytes(huffman.compress_tensor(src[:len(smp)].contiguous()).cpu().numpy()) == cb["_c"]
+                    ok = ok and bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy()) == O.huffman_compress(smp[:pre])
+                    out["bit_exact_vs_oracle_on_sample"] = bool(ok)
+                    out["cpu_baseline"] = _public(cb)
+                except Exception as e:                      # noqa: BLE001
+                    out["cpu_baseline_error"] = "%s: %s" % (type(e).__name__, e)
             del comp_buf, dec_buf
             torch.cuda.empty_cache()
             if not args.no_others:
                 names = [x for x in args.others.split(",") if x]
-                out["other_configs"] = run_other_configs(torch, device, n, cores, not args.no_cpu, names)
-                out["other_configs_note"] = ALG_NOTE + "; one warm-up pass, then the mean of 2 timed passes per config"
+                try:
+                    out["other_configs"] = run_other_configs(torch, device, n, cores, not args.no_cpu, names)
+                    out["other_configs_note"] = ALG_NOTE + "; one warm-up pass, then the mean of 2 timed passes per config"
+                except Exception as e:                      # noqa: BLE001
+                    out["other_configs_error"] = "%s: %s" % (type(e).__name__, e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if gather_stuck:
