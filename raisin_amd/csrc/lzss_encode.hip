@@ -139,6 +139,22 @@ __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in
     drain_block(s_img, al, total, dst);
 }
 
+// The optimistic form: most inputs hold no byte that needs an escape (5C, FF) at all, and then the escaped stream is the input with
+// '<' mapped to FF (lzss.go:373-377), every byte in its place.  One pass writes exactly that and raises a flag if it met a 5C or FF;
+// only then do the counting pass, the scan and k_esc_write run (the flagged attempt cost one copy).
+__global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ fc, unsigned long long *__restrict__ flag) {
+    const size_t P = (size_t)blockIdx.x * ESC_TILE + threadIdx.x * 16;
+    uint32_t w[4]; int cnt;
+    load16(in, n, P, w, &cnt);                                             // (bytes beyond n read as zero: neither special nor '<')
+    uint32_t special = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); w[j] |= bytes_equal(w[j], 0x3Cu); }
+    if (__ballot(special != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1ull);
+    uint8_t *d = fc + P;
+    if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+}
+
 // ------------------------------------------------------------------ E2: match search
 struct MatchArgs {
     const uint8_t *fc; uint32_t E; uint32_t W; uint32_t DW;   // DW = diagonals per wave
@@ -1637,12 +1653,26 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     const uint32_t n_eb = (uint32_t)ceil_div(n, ESC_TILE);
     rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
     unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
-    RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
-    rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
-    RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipStreamSynchronize(s));
+    static const bool no_try = getenv("RSN_LZSS_ESC_TWO_PASS") != nullptr;   // A/B switch: always count, scan, write
+    bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
+    if (!no_try) {
+        rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
+        RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
+        RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
+        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1);
+        RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        copied = h64[0] == 0;
+        h64[0] = 0;
+    }
+    if (!copied) {
+        RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
+        rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+    }
     const size_t E64 = n + (size_t)h64[0];
     if (E64 >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: escaped stream too large for one call");
     const uint32_t E = (uint32_t)E64;
@@ -1652,8 +1682,10 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     if (W == 0) W = 1;
     rc = dev_buf(c, 9, (size_t)E + 64, &p); if (rc) return rc;
     uint8_t *d_fc = (uint8_t *)p;
-    RSN_HIP(hipMemsetAsync(d_fc + E, 0, 64, s));                      // readable padding behind the stream
-    RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+    if (!copied) {
+        RSN_HIP(hipMemsetAsync(d_fc + E, 0, 64, s));                  // readable padding behind the stream
+        RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+    }
     if (W > MAX_WINDOW) return lzss_encode_big(c, s, d_fc, E, W, d_out, out_cap, out_n);   // lzss_big.hip: exact at any window, not fast
     // ---- E2 + E3.  Chain mode (default, W <= 4096): keys only where greedy chains land, everything else
     //      KEY_UNKNOWN; if the parse finds the true chain on an unknown position, those strips are
