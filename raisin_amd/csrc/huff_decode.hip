@@ -28,6 +28,7 @@
 // two (single + multi) is what lets seven blocks share a CU in the counting pass instead of four: the walks
 // are bound by the latency of their own dependent LDS reads, i.e. by how many wavefronts are there to hide it.
 #include <chrono>
+#include <thread>
 #include "codecs.h"
 
 namespace rsn {
@@ -660,7 +661,18 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     HuffTree tree; HuffCodes codes;
     if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
     const auto t2 = now();
-    if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    // A large alphabet (config 2b: 3*10^5 runes) spends milliseconds both on the code lengths and on the lookup tables; neither needs
+    // the other -- more than 2^11 leaves means codes longer than any first-level table, so K is known -- so a second host thread
+    // builds the tables meanwhile.
+    static const int k_env = [] { const char *e = getenv("RSN_DEC_K"); return e ? std::min(std::max(atoi(e), 4), LUT_BITS_MAX) : LUT_BITS_MAX; }();   // tuning switch: index bits of the first-level table
+    static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
+    std::vector<uint32_t> lut, lut2; std::vector<int32_t> child;
+    const bool prebuilt = tree.n_leaves > 4096;
+    std::thread table_builder;
+    if (prebuilt) table_builder = std::thread([&] { build_tables(tree, k_env, lut, child); if (!no_lut2) build_second_level(child, k_env, false, lut, lut2); });
+    const bool codes_ok = assign_codes(tree, codes, msg);
+    if (prebuilt) table_builder.join();
+    if (!codes_ok) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
     const auto t3 = now();
     if (host_timing) fprintf(stderr, "huffman decode host: header of %zu bytes parsed in %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n", sep, ms(t0, t1), ms(t1, t2), ms(t2, t3), syms.size());
 
@@ -713,11 +725,9 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
 
     // ---- tables
-    static const int k_env = [] { const char *e = getenv("RSN_DEC_K"); return e ? std::min(std::max(atoi(e), 4), LUT_BITS_MAX) : LUT_BITS_MAX; }();   // tuning switch: index bits of the first-level table
     const int K = (int)std::min<unsigned>(codes.max_len, (unsigned)k_env);
     const bool short_codes = codes.max_len <= (unsigned)K;
-    std::vector<uint32_t> lut; std::vector<int32_t> child;
-    build_tables(tree, K, lut, child);
+    if (!prebuilt) build_tables(tree, K, lut, child);
     const auto t4 = now();
     // byte alphabets: the unified table (up to three whole codewords per K-bit window)
     static const bool no_multi = getenv("RSN_NO_MULTI") != nullptr;
@@ -742,9 +752,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             lut[v] = syms | (used << 21) | (nsym << 25) | (len1 << 27);           // nsym >= 1 here: the first codeword fits
         }
     }
-    std::vector<uint32_t> lut2;
-    static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
-    if (!short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
+    if (!prebuilt && !short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
     const auto t5 = now();
     {   // the device reads the stream LSB-first: first-level entry v moves to the index with v's K bits reversed
         //     (the second level is built in that order, see build_second_level)
