@@ -767,9 +767,18 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     uint32_t *d_lut = (uint32_t *)p;
     int32_t *d_child = (int32_t *)(d_lut + lut.size());
     uint32_t *d_lut2 = (uint32_t *)(d_child + child.size());
-    RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
-    RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
-    if (!lut2.empty()) RSN_HIP(hipMemcpyAsync(d_lut2, lut2.data(), lut2.size() * 4, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> packed;                                       // (small tables go up in one copy: a call on a few KB is all fixed costs)
+    if (lut.size() + child.size() + lut2.size() <= (64u << 10)) {
+        packed.reserve(lut.size() + child.size() + lut2.size());
+        packed.insert(packed.end(), lut.begin(), lut.end());
+        packed.insert(packed.end(), reinterpret_cast<const uint32_t *>(child.data()), reinterpret_cast<const uint32_t *>(child.data()) + child.size());
+        packed.insert(packed.end(), lut2.begin(), lut2.end());
+        RSN_HIP(hipMemcpyAsync(d_lut, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, s));
+    } else {
+        RSN_HIP(hipMemcpyAsync(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
+        RSN_HIP(hipMemcpyAsync(d_child, child.data(), child.size() * 4, hipMemcpyHostToDevice, s));
+        if (!lut2.empty()) RSN_HIP(hipMemcpyAsync(d_lut2, lut2.data(), lut2.size() * 4, hipMemcpyHostToDevice, s));
+    }
 
     DecArgs a{};
     a.base = d_in + A0; a.nbytes = n - A0;
@@ -810,7 +819,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // ---- D1: iterate to the fixed point
     a.pass = 0;
     rc = launch_sync(); if (rc) return rc;
-    for (uint32_t pass = 1;; pass++) {
+    for (uint32_t pass = 1; n_blk > 1; pass++) {                      // (a single block starts from the exact entry and iterates to its fixed point in LDS)
         if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
         a.pass = (int)pass;
         RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
