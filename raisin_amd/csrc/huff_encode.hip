@@ -755,6 +755,24 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
 // ======================================================================= host side
 namespace {
 
+// The rune histogram is 0x110000 counters of which a call uses a few dozen to a few 10^5: the present ones are compacted on the
+// device (flags, scan, scatter -- in rune order, which is the order the header wants) and only they cross PCIe; the code table goes
+// the other way the same way (a list of present runes scattered into the rune-indexed arrays, which are never cleared: absent runes
+// are never looked up).  The full-table round trips cost every non-ASCII call 1.1 ms, a 4 KB one included.
+__global__ void k_rune_flags(const unsigned long long *__restrict__ hist, unsigned long long *__restrict__ flag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < kMaxRune) flag[r] = hist[r] != 0;
+}
+__global__ void k_rune_pairs(const unsigned long long *__restrict__ hist, const unsigned long long *__restrict__ off, HuffSym *__restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < kMaxRune && hist[r]) { out[off[r]].rune = r; out[off[r]].freq = hist[r]; }
+}
+struct RuneCode { uint32_t rune, len; unsigned long long code; };
+__global__ void k_rune_table(const RuneCode *__restrict__ list, uint32_t k, unsigned long long *__restrict__ code64, uint8_t *__restrict__ len8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) { const RuneCode e = list[i]; code64[e.rune] = e.code; len8[e.rune] = (uint8_t)e.len; }
+}
+
 int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t *d_tile_hist,
                        std::vector<HuffSym> &syms, bool &ascii) {
     void *p;
@@ -763,7 +781,7 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     RSN_HIP(hipMemsetAsync(d_gh, 0, 256 * 8, s));
     const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 2048);     // persistent blocks (8 loads in flight / other grid sizes: within noise, r01d A/B)
     RSN_LAUNCH("huff_byte_hist", k_byte_hist<4>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
-    void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 8, &hp); if (rc) return rc;
+    void *hp; rc = pinned_buf(c, 256 * 8, &hp); if (rc) return rc;
     unsigned long long *h = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h, d_gh, 256 * 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
@@ -779,12 +797,29 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     RSN_HIP(hipMemsetAsync(d_rh, 0, (size_t)kMaxRune * 8, s));
     const size_t rounds = ceil_div(n, ROUND);
     RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh);
-    RSN_HIP(hipMemcpyAsync(h, d_rh, (size_t)kMaxRune * 8, hipMemcpyDeviceToHost, s));
+    // the present runes, compacted in rune order (see k_rune_flags)
+    const size_t bound = std::min<size_t>(n, kMaxRune);                // distinct runes never exceed the input's bytes
+    rc = dev_buf(c, 6, (size_t)kMaxRune * 16 + 16 + bound * sizeof(HuffSym) + 64, &p); if (rc) return rc;
+    unsigned long long *d_flag = (unsigned long long *)p, *d_off = d_flag + kMaxRune, *d_cnt = d_off + kMaxRune;
+    HuffSym *d_pairs = (HuffSym *)(d_cnt + 2);
+    const dim3 rg((kMaxRune + 255) / 256);
+    RSN_LAUNCH("huff_rune_hist", k_rune_flags, rg, dim3(256), 0, s, d_rh, d_flag);
+    rc = scan_u64(c, s, "huff_scan", d_flag, d_off, kMaxRune, d_cnt); if (rc) return rc;
+    RSN_LAUNCH("huff_rune_hist", k_rune_pairs, rg, dim3(256), 0, s, d_rh, d_off, d_pairs);
+    const bool one_trip = bound * sizeof(HuffSym) <= (1u << 20);      // small inputs: count and pairs in one copy
+    rc = pinned_buf(c, 16 + (one_trip ? bound * sizeof(HuffSym) : 0), &hp); if (rc) return rc;
+    h = (unsigned long long *)hp;
+    RSN_HIP(hipMemcpyAsync(h, d_cnt, 16 + (one_trip ? bound * sizeof(HuffSym) : 0), hipMemcpyDeviceToHost, s));   // (d_pairs follows d_cnt[2])
     RSN_HIP(hipStreamSynchronize(s));
-    size_t present = 0;
-    for (uint32_t r = 0; r < kMaxRune; r++) present += h[r] != 0;
-    syms.reserve(present);
-    for (uint32_t r = 0; r < kMaxRune; r++) if (h[r]) syms.push_back({r, h[r]});
+    const size_t present = (size_t)h[0];
+    if (!one_trip) {
+        rc = pinned_buf(c, 16 + present * sizeof(HuffSym), &hp); if (rc) return rc;
+        h = (unsigned long long *)hp;
+        RSN_HIP(hipMemcpyAsync(h + 2, d_pairs, present * sizeof(HuffSym), hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+    }
+    const HuffSym *hs = reinterpret_cast<const HuffSym *>(h + 2);
+    syms.assign(hs, hs + present);
     return RSN_OK;
 }
 
@@ -880,15 +915,17 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     EmitArgs a{};
     uint8_t *d_len8 = nullptr;
     if (mode == MODE_RUNE) {
-        void *hp; rc = pinned_buf(c, (size_t)kMaxRune * 9, &hp); if (rc) return rc;
-        unsigned long long *hc = (unsigned long long *)hp;
-        uint8_t *hl = (uint8_t *)hp + (size_t)kMaxRune * 8;
-        memset(hp, 0, (size_t)kMaxRune * 9);
-        for (uint32_t i = 0; i < tree.n_leaves; i++) { hc[tree.rune[i]] = codes.code[i]; hl[tree.rune[i]] = codes.len[i]; }
-        rc = dev_buf(c, 3, (size_t)kMaxRune * 9, &p); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(p, hp, (size_t)kMaxRune * 9, hipMemcpyHostToDevice, s));
+        // the present runes' codes go up as a list and are scattered into the rune-indexed arrays on the device (see k_rune_flags)
+        const uint32_t k = tree.n_leaves;
+        void *hp; rc = pinned_buf(c, (size_t)k * sizeof(RuneCode), &hp); if (rc) return rc;
+        RuneCode *hl = (RuneCode *)hp;
+        for (uint32_t i = 0; i < k; i++) hl[i] = RuneCode{tree.rune[i], codes.len[i], codes.code[i]};
+        rc = dev_buf(c, 3, (size_t)kMaxRune * 9 + 64 + (size_t)k * sizeof(RuneCode), &p); if (rc) return rc;
+        RuneCode *d_list = (RuneCode *)((uint8_t *)p + round_up((size_t)kMaxRune * 9, 64));
+        RSN_HIP(hipMemcpyAsync(d_list, hl, (size_t)k * sizeof(RuneCode), hipMemcpyHostToDevice, s));
         a.code64 = (const unsigned long long *)p;
         d_len8 = (uint8_t *)p + (size_t)kMaxRune * 8;
+        RSN_LAUNCH("huff_rune_table", k_rune_table, dim3((k + 255) / 256), dim3(256), 0, s, (const RuneCode *)d_list, k, (unsigned long long *)p, d_len8);
     } else {
         struct Tab { uint32_t t32[256]; unsigned long long c64[256]; uint8_t l8[256]; };
         void *hp; rc = pinned_buf(c, sizeof(Tab), &hp); if (rc) return rc;
