@@ -74,7 +74,9 @@ int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_
 int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 
 /* Batch form for independent chunks (one .rsn segment per chunk, as
- * engine.CompressFiles produces one file per input, engine.go:150-154). */
+ * engine.CompressFiles produces one file per input, engine.go:150-154): chunk k+1's
+ * upload, chunk k's encode and chunk k-1's download run at once.  Each outs[i] equals
+ * what rsn_huffman_compress() returns for ins[i]; on any error every outs[i] is NULL. */
 int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
                                uint8_t **outs, size_t *out_lens);
 

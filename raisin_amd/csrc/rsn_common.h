@@ -35,7 +35,7 @@ struct Ctx {
     std::vector<hipEvent_t> free_events;
 
     struct Buf { void *p = nullptr; size_t cap = 0; };
-    enum { N_BUFS = 28 };
+    enum { N_BUFS = 34 };   // 28..33: the batch pipeline's ring
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
 

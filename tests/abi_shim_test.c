@@ -116,6 +116,26 @@ int main(int argc, char **argv) {
         CHECK(rc == 0 && sn == out_lens[i] && memcmp(single, outs[i], sn) == 0);
         free(single); rsn_free(outs[i]); free(bufs[i]);
     }
+    /* a chunk whose segment outgrows the pipeline's output slot (50 000 distinct runes: the header alone is > 1 MB for
+     * 150 KB of input) between two ordinary ones, and a batch with an empty chunk (refused as the single call refuses it) */
+    {
+        enum { NR = 50000 };
+        uint8_t *wide = malloc(3 * NR);
+        for (int i = 0; i < NR; i++) { const unsigned r = 0x800u + (unsigned)i; wide[3 * i] = 0xE0 | (r >> 12); wide[3 * i + 1] = 0x80 | ((r >> 6) & 63); wide[3 * i + 2] = 0x80 | (r & 63); }
+        uint8_t *t0 = make_text(400000, 7u), *t1 = make_text(500000, 8u);
+        const uint8_t *in3[4] = {t0, wide, t1, t0}; size_t len3[4] = {400000, 3 * NR, 500000, 123457}; uint8_t *out3[4]; size_t on3[4];
+        CHECK(rsn_huffman_compress_batch(4, in3, len3, out3, on3) == 0);
+        CHECK(on3[1] > 3 * NR + 3 * NR / 8 + 65536);
+        for (int i = 0; i < 4; i++) {
+            size_t sn; uint8_t *single = rsn_call(rsn_huffman_compress, in3[i], len3[i], &sn, &rc);
+            CHECK(rc == 0 && sn == on3[i] && memcmp(single, out3[i], sn) == 0);
+            free(single); rsn_free(out3[i]);
+        }
+        len3[2] = 0;
+        CHECK(rsn_huffman_compress_batch(4, in3, len3, out3, on3) == RSN_ERR_EMPTY);
+        for (int i = 0; i < 4; i++) CHECK(out3[i] == NULL && on3[i] == 0);
+        free(wide); free(t0); free(t1);
+    }
     rsn_trim();
     printf("abi shim: ok\n");
     return 0;
