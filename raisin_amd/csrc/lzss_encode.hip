@@ -950,7 +950,9 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                 }
                 if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
                     // (the density test sits on this path because dense data comes through here all the time, text rarely)
-                    if (!(a.redo & 1u) && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
+                    // (not in tile 0: every stream begins with an empty window and a run of one-byte steps, and the second look that a
+                    //  tile which gave up costs -- a launch that waits for one tile -- is a third of a small call's time)
+                    if (!(a.redo & 1u) && bx != 0 && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
                     else {
                         const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
                         const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
@@ -1784,10 +1786,13 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         uint32_t *d_prev_part = (uint32_t *)pp;
         auto resolve = [&](bool second) -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
-            static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switch: the in-tile parse by pointer doubling in LDS
+            static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switches: the in-tile parse by pointer doubling in LDS,
+            static const bool serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;       //               or by one lane per tile whatever the size
             // (the second look concerns a handful of tiles, dense ones among them: a lone lane's 8 000 dependent loads would be all
-            //  the call waits for -- there the block-per-tile kernel, which returns at once everywhere else, is the faster one)
-            if (doubling || second) {
+            //  the call waits for -- there the block-per-tile kernel, which returns at once everywhere else, is the faster one.
+            //  The same holds for a whole small stream: 235 us for the lone lanes against 25 for the blocks, whose cost grows with
+            //  the tiles -- 1.9 against 3 ms per GiB)
+            if (doubling || second || (n_pt < 4096 && !serial)) {
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
             } else RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
