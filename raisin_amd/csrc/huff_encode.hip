@@ -27,6 +27,10 @@
 namespace rsn {
 
 constexpr int TILE = 65536;        // input bytes per tile
+constexpr int SMALL_TILE = 4096;   // ... of an input up to SMALL_INPUT bytes.  A tile is one block's work and a block takes a few microseconds per 4 KiB
+constexpr size_t SMALL_INPUT = (size_t)2 << 20;   // round whatever the input's size: 64 KiB as one tile is 16 rounds in a row on one CU beside 255 idle ones
+// (64 KiB of UTF-8 text 318 -> 144 us, 1 MiB 331 -> 153, ASCII 83 -> 58 and 74 -> 64; from 8 MiB the per-tile histograms cost the ASCII path more than the
+//  blocks gain -- 90 -> 121 us -- and at 64 MiB both paths lose: r02k A/B, scripts/huff_tile_ab.py)
 constexpr int HB = 256;            // threads per block (4 wavefronts)
 constexpr int ROUND = HB * 16;     // input bytes per block round (16 B per lane)
 
@@ -37,7 +41,7 @@ enum { MODE_ASCII = 0, MODE_ASCII_WIDE = 1, MODE_RUNE = 2 };
 // half-wavefront never collide whatever the data.  Only 7-bit symbols are counted: an input
 // with any byte >= 0x80 is merely flagged (ghist[128]) and re-histogrammed by the rune path,
 // whose symbols are runes, not bytes (huffman.go:309).
-template <int INFLIGHT>
+template <int INFLIGHT, int TB>   // TB: bytes per tile
 __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in, size_t n, uint32_t n_tiles,
                                                   uint32_t *__restrict__ tile_hist,
                                                   unsigned long long *__restrict__ ghist) {
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
     const uint32_t copy = tid & 31;
     unsigned long long mine = 0;
     uint32_t hi_any = 0;
+    static_assert(TB % ROUND == 0 && (TB / ROUND) % INFLIGHT == 0, "whole rounds, whole batches of loads");
     auto add16 = [&](const uint4 &v) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -60,12 +65,12 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         for (int i = tid; i < 128 * 32; i += HB) h[i] = 0;
         __syncthreads();
-        const size_t base = (size_t)t * TILE;
-        if (base + TILE <= n) {
+        const size_t base = (size_t)t * TB;
+        if (base + TB <= n) {
             // full tile: branch-free, INFLIGHT loads in flight per lane before the first LDS atomic
             const uint4 *src = reinterpret_cast<const uint4 *>(in + base) + tid;
 #pragma unroll
-            for (int k0 = 0; k0 < TILE / ROUND; k0 += INFLIGHT) {
+            for (int k0 = 0; k0 < TB / ROUND; k0 += INFLIGHT) {
                 uint4 v[INFLIGHT];
 #pragma unroll
                 for (int k = 0; k < INFLIGHT; k++) v[k] = src[(k0 + k) * HB];
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
                 for (int k = 0; k < INFLIGHT; k++) add16(v[k]);
             }
         } else {
-            for (int k = 0; k < TILE / ROUND; k++) {
+            for (int k = 0; k < TB / ROUND; k++) {
                 const size_t off = base + (size_t)(k * HB + tid) * 16;
                 if (off + 16 <= n) add16(*reinterpret_cast<const uint4 *>(in + off));
                 else if (off < n) for (size_t p = off; p < n; p++) { hi_any |= in[p]; atomicAdd(&h[((in[p] & 0x7F) << 5) | copy], 1u); }
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(HB) void k_tile_bits(const uint32_t *__restrict__ t
 
 // K2r: rune path -- re-reads the tile, sums len[rune] over rune starts
 __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict__ in, size_t n, const uint8_t *__restrict__ rlen,
-                                                       uint32_t n_tiles, unsigned long long *__restrict__ tile_bits) {
+                                                       uint32_t n_tiles, uint32_t tile, unsigned long long *__restrict__ tile_bits) {
     __shared__ unsigned long long part[HB / 64];
     __shared__ uint8_t s_len[2048];                                // code lengths of the dense runes: an LDS read instead of a global gather
     const int tid = threadIdx.x;
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict
     __syncthreads();
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         unsigned long long s = 0;
-        for (int k = 0; k < TILE / ROUND; k++) {
-            const size_t P = (size_t)t * TILE + (size_t)(k * HB + tid) * 16;
+        for (uint32_t k = 0; k < tile / ROUND; k++) {
+            const size_t P = (size_t)t * tile + (size_t)(k * HB + tid) * 16;
             if (P >= n) break;
             uint32_t rune[16];
             const uint32_t m = classify16(in, n, P, rune);
@@ -355,6 +360,7 @@ struct EmitArgs {
     unsigned long long base_bits;
     uint32_t tiles_per_block, n_tiles;
     uint32_t *out_words;
+    uint32_t tile;                       // input bytes per tile (TILE or SMALL_TILE)
 };
 
 // Per-lane bit packer into the block's LDS window (big-endian 32-bit words:
@@ -408,8 +414,8 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
     const uint32_t t0 = blockIdx.x * a.tiles_per_block;
     if (t0 >= a.n_tiles) return;
     const uint32_t t1 = min(t0 + a.tiles_per_block, a.n_tiles);
-    const size_t in0 = (size_t)t0 * TILE;
-    const size_t in1 = min((size_t)t1 * TILE, a.n);
+    const size_t in0 = (size_t)t0 * a.tile;
+    const size_t in1 = min((size_t)t1 * a.tile, a.n);
 
     if (MODE == MODE_ASCII && tid < 128) s_tab[tid] = a.tab32[tid];
     if (MODE == MODE_ASCII_WIDE) { s_code[tid] = a.code64[tid]; s_len[tid] = a.len8[tid]; }
@@ -540,8 +546,8 @@ __global__ __launch_bounds__(HB) void k_emit_ascii32(EmitArgs a) {
     const uint32_t t0 = blockIdx.x * a.tiles_per_block;
     if (t0 >= a.n_tiles) return;
     const uint32_t t1 = min(t0 + a.tiles_per_block, a.n_tiles);
-    const size_t in0 = (size_t)t0 * TILE;
-    const size_t in1 = min((size_t)t1 * TILE, a.n);
+    const size_t in0 = (size_t)t0 * a.tile;
+    const size_t in1 = min((size_t)t1 * a.tile, a.n);
     if (tid < 128) s_tab[tid] = a.tab32[tid];
     for (int i = tid; i < A32_WIN; i += HB) s_win[i] = 0;
     const unsigned long long bit0 = a.base_bits + a.tile_off[t0];
@@ -773,14 +779,15 @@ __global__ void k_rune_table(const RuneCode *__restrict__ list, uint32_t k, unsi
     if (i < k) { const RuneCode e = list[i]; code64[e.rune] = e.code; len8[e.rune] = (uint8_t)e.len; }
 }
 
-int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t *d_tile_hist,
+int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t tile, uint32_t *d_tile_hist,
                        std::vector<HuffSym> &syms, bool &ascii) {
     void *p;
     int rc = dev_buf(c, 1, 256 * 8, &p); if (rc) return rc;
     unsigned long long *d_gh = (unsigned long long *)p;
     RSN_HIP(hipMemsetAsync(d_gh, 0, 256 * 8, s));
     const uint32_t grid = (uint32_t)std::min<size_t>(n_tiles, 2048);     // persistent blocks (8 loads in flight / other grid sizes: within noise, r01d A/B)
-    RSN_LAUNCH("huff_byte_hist", k_byte_hist<4>, dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
+    if (tile == TILE) RSN_LAUNCH("huff_byte_hist", (k_byte_hist<4, TILE>), dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
+    else RSN_LAUNCH("huff_byte_hist", (k_byte_hist<1, SMALL_TILE>), dim3(grid), dim3(HB), 0, s, d_in, n, n_tiles, d_tile_hist, d_gh);
     void *hp; rc = pinned_buf(c, 256 * 8, &hp); if (rc) return rc;
     unsigned long long *h = (unsigned long long *)hp;
     RSN_HIP(hipMemcpyAsync(h, d_gh, 256 * 8, hipMemcpyDeviceToHost, s));
@@ -836,7 +843,9 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
                     HuffTree *tree_out, HuffCodes *codes_out) {
     if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
-    const uint32_t n_tiles = (uint32_t)ceil_div(n, TILE);
+    static const bool no_small_tiles = getenv("RSN_HUFF_NO_SMALL_TILES") != nullptr;   // A/B switch
+    const uint32_t tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
+    const uint32_t n_tiles = (uint32_t)ceil_div(n, tile);
     void *p;
     int rc = dev_buf(c, 0, (size_t)n_tiles * 128 * 4, &p); if (rc) return rc;
     uint32_t *d_tile_hist = (uint32_t *)p;
@@ -847,7 +856,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
-    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, d_tile_hist, syms, ascii); if (rc) return rc;
+    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, tile, d_tile_hist, syms, ascii); if (rc) return rc;
     const auto t1 = now();
 
     std::string hdr;
@@ -950,7 +959,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     unsigned long long *d_tile_bits = (unsigned long long *)p;
     unsigned long long *d_tile_off = d_tile_bits + n_tiles;
     if (mode == MODE_RUNE) {
-        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, d_tile_bits);
+        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, tile, d_tile_bits);
     } else {
         RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, d_tile_hist, d_len8, n_tiles, d_tile_bits);
     }
@@ -960,7 +969,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const uint32_t tiles_per_block = (uint32_t)std::max<size_t>(1, ceil_div(n_tiles, 2048));
     const uint32_t n_blocks = (uint32_t)ceil_div(n_tiles, tiles_per_block);
     a.in = d_in; a.n = n; a.tile_off = d_tile_off; a.base_bits = base_bits;
-    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out;
+    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out; a.tile = tile;
     RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
                (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + codes.total_bits);
     RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));

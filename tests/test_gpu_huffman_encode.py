@@ -85,6 +85,20 @@ def test_valid_utf8_text(huff, oracle):
     assert huff.Compress(t) == oracle.huffman_compress(t)
 
 
+def test_small_and_large_tiles(huff, oracle):
+    """Inputs up to 2 MiB are cut into 4 KiB tiles, larger ones into 64 KiB tiles (huff_encode.hip SMALL_INPUT): the
+    same bytes either side of the switch, on the byte, skewed-byte and rune paths, with multi-byte sequences across
+    tile edges of both sizes and ragged last tiles."""
+    rng = random.Random(77)
+    alphabet = "ab déf ✓ λ 𝄞 \n\\|01"
+    utf8 = "".join(rng.choice(alphabet) for _ in range(1 << 20)).encode("utf-8")
+    for n in ((2 << 20) - 1, 2 << 20, (2 << 20) + 1, (2 << 20) + 4097, 4096 * 3 + 1, 4096 * 5 - 2):
+        for data in (rnd_bytes(n, n, 0, 128), (utf8 * 3)[1:n + 1], rnd_bytes(n + 5, n)):
+            c = huff.Compress(data)
+            assert c == oracle.huffman_compress(data)
+            assert huff.Decompress(c) == oracle.huffman_decompress(c)
+
+
 def test_device_resident_api(huff, oracle):
     import torch
     data = rnd_bytes(3, 3 << 20, 0, 128)
