@@ -1748,10 +1748,14 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // Nearly incompressible input is the one case where the chain walk loses (every tile walks a few dozen visits per wavefront,
     // gives up as dense, and the bucket search does it all again: 57 against 41 ms per GiB of random bytes).  Large inputs walk a
     // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
+    // (From 8192 tiles = 64 MiB: the sample is a launch that waits for one tile plus a host sync, 0.12 ms -- 15 % of an 8 MiB call,
+    //  to save a stream of noise that size 0.13 ms.  RSN_LZSS_SAMPLE_MIN_TILES moves the threshold: the tests use it.)
     if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain);
     constexpr uint32_t SAMPLE_TILES = 64;
     static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
-    if (chain_mode && !no_sample && n_pt >= 16 * SAMPLE_TILES) {
+    const char *smin_env = getenv("RSN_LZSS_SAMPLE_MIN_TILES");
+    const uint32_t sample_min = smin_env ? std::max<uint32_t>((uint32_t)atoi(smin_env), 16 * SAMPLE_TILES) : 128 * SAMPLE_TILES;
+    if (chain_mode && !no_sample && n_pt >= sample_min) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);

@@ -1,4 +1,5 @@
 """GPU parity: librsn LZSS encode/decode (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
 import random
 
 import numpy as np
@@ -359,19 +360,28 @@ def test_escape_blocks_plain_and_mixed(lz, oracle, shift):
 
 
 def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
-    """Inputs of 1024 tiles and more walk a sample of 64 tiles first: all noise -> no chain walk at all; noise with
-    text in the second half -> the sample is split, the chain walk runs and hands the noisy strips back."""
+    """Large inputs (8192 tiles = 64 MiB and more; here the threshold is lowered to 1024) walk a sample of 64 tiles
+    first: all noise -> no chain walk at all; noise with text in the second half -> the sample is split, the chain
+    walk runs and hands the noisy strips back.  Below the threshold the same streams take the chain walk unsampled."""
     rng = np.random.default_rng(77)
     n = 9 << 20
     noise = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
     half = noise[: n // 2 + 12345] + text(78, n // 2)
-    for data, walks in ((noise, False), (half, True)):
+    want = {id(d): oracle.lzss_compress_mt(d, 4096, oracle.host_cores(), 4096) for d in (noise, half)}
+    os.environ["RSN_LZSS_SAMPLE_MIN_TILES"] = "1024"
+    try:
+        for data, walks in ((noise, False), (half, True)):
+            c, p = _prof(lz, data)
+            if _chain_mode():
+                assert p["lzss_sample"][0] == 2                            # the list and the 64-tile walk
+                assert ("lzss_match_chain" in p) == walks
+            assert c == want[id(data)]
+            assert lz.Decompress(c) == data
+    finally:
+        del os.environ["RSN_LZSS_SAMPLE_MIN_TILES"]
+    for data in (noise, half):
         c, p = _prof(lz, data)
-        if _chain_mode():
-            assert p["lzss_sample"][0] == 2                            # the list and the 64-tile walk
-            assert ("lzss_match_chain" in p) == walks
-        assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
-        assert lz.Decompress(c) == data
+        assert "lzss_sample" not in p and c == want[id(data)]
 
 
 def test_chain_entry_fixed_by_second_look(lz, oracle):
