@@ -311,7 +311,14 @@ __global__ __launch_bounds__(ZB) void k_lzd_gather(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------ L2: tile path
 constexpr int DT = 16384;               // escaped-stream bytes per resolve tile (8192 with twice the tiles per group: resolve 7 % faster, compose + chain 2x slower)
 constexpr int DTH = 1024;               // threads of the tile kernels: 16 bytes per lane
-constexpr int DGRP = 128;               // tiles per chain group (the serial chain walks E / (DT * DGRP) links)
+constexpr int DGRP = 128;               // most tiles per chain group: a block of k_lzd_compose / k_lzd_emit walks its group's tiles in order,
+                                        // 2.6 us each, so a stream gets about 512 groups if it has the tiles (see group_tiles)
+__host__ inline uint32_t group_tiles(uint32_t n_tiles) {
+    // 1 GiB = 65536 tiles in 512 groups of 128 (32 per group measured slower there: four times the group maps to scan); a 32 MiB
+    // stream in groups of 128 is 16 blocks on 256 CUs, each 330 us in a row -- groups of 4 are 10 us and a few more scan rounds
+    if (getenv("RSN_LZSS_DEC_GROUP128")) return DGRP;                      // A/B switch (read per call: the tests flip it)
+    return std::max<uint32_t>(4, std::min<uint32_t>(DGRP, n_tiles / 512));
+}
 constexpr uint32_t D_LOC = 0x4000u;     // descriptor: position inside the tile
 constexpr uint32_t D_EXT = 0x8000u;     // descriptor: position inside the previous tile's tail; otherwise the literal byte
 constexpr uint32_t D_PAY = 0x3FFFu;
@@ -537,13 +544,13 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
 }
 
 // C_g = the tail map of the group's last tile expressed in the tail that precedes the group
-__global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict__ desc, uint32_t TL, uint16_t *__restrict__ comp) {
+__global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t dgrp, uint16_t *__restrict__ comp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
     uint16_t *cur = reinterpret_cast<uint16_t *>(dsm), *nxt = cur + TL;
-    const size_t k0 = (size_t)blockIdx.x * DGRP;
+    const size_t k0 = (size_t)blockIdx.x * dgrp;
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) cur[j] = desc[k0 * DT + DT - TL + j];
     __syncthreads();
-    for (int t = 1; t < DGRP; t++) {
+    for (uint32_t t = 1; t < dgrp; t++) {
         const uint16_t *m = desc + (k0 + t) * DT + DT - TL;
         for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = m[j]; nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
         __syncthreads();
@@ -609,7 +616,7 @@ __device__ __forceinline__ uint32_t emit_bytes_equal(uint32_t w, uint32_t c) {
 
 // map_ff: the stream holds no 5C at all, so unescaping is the byte map FF -> '<' (lzss.go:391-406, '<' never occurs in the escaped
 // stream): applied to the stored bytes here, `esc` is the caller's output buffer and no unescape pass follows (summ unused).
-__global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t E,
+__global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t dgrp, uint32_t E,
                                                   const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ, int map_ff) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
     __shared__ uint32_t s_last[2][DT / ZTILE];                           // per ZTILE block of the tile: index past its last non-5C byte (by tile parity)
@@ -622,12 +629,12 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
         if (k < n_tiles && k * DT + x0 < E) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = p[0]; a1 = p[1]; }
     };
     uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, e0 = d0, e1 = d1;
-    load(g * DGRP, d0, d1);
+    load(g * dgrp, d0, d1);
     __syncthreads();
-    for (int t = 0; t < DGRP; t++) {
-        const uint32_t k = g * DGRP + t;
+    for (uint32_t t = 0; t < dgrp; t++) {
+        const uint32_t k = g * dgrp + t;
         if (k >= n_tiles) break;
-        load(k + 1 < (g + 1) * DGRP ? k + 1 : n_tiles, e0, e1);            // next tile's descriptors in flight during this one
+        load(k + 1 < (g + 1) * dgrp ? k + 1 : n_tiles, e0, e1);            // next tile's descriptors in flight during this one
         const uint32_t ts = k * DT, len = min((uint32_t)DT, E - ts);
         if (x0 < len) {
             const uint32_t w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -701,10 +708,9 @@ __global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ 
 
 // in_par[b] = parity of the 5C run that ends right before block b.  The (all-5C, parity)
 // summaries combine associatively, so one block of 1024 lanes scans them: every lane folds a
-// contiguous chunk, lane 0 chains the 1024 chunk summaries, every lane replays its chunk.
+// contiguous chunk, the 1024 chunk summaries are scanned by shuffles, every lane replays its chunk.
 __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ summ, uint32_t n_blk, uint8_t *__restrict__ in_par) {
-    __shared__ uint8_t s_chunk[1024];
-    __shared__ uint8_t s_in[1024];
+    __shared__ uint8_t s_w[16];
     const uint32_t per = ((n_blk + 1023) / 1024 + 15) & ~15u;           // a multiple of 16: chunks are read and written in 16-byte units
     const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, n_blk);
     auto fold = [](uint32_t &all, uint32_t &par, uint32_t v) { if (v & 2) par ^= v & 1; else { all = 0; par = v & 1; } };
@@ -717,14 +723,19 @@ __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ 
             for (int k = 0; k < 16; k++) fold(all, par, (w[k >> 2] >> (8 * (k & 3))) & 0xFF);
         } else for (uint32_t q = b; q < b1; q++) fold(all, par, summ[q]);
     }
-    s_chunk[threadIdx.x] = (uint8_t)(all | par);
+    // the chunk summaries' exclusive scan under the same fold (identity: all-5C, parity 0), by shuffles: one lane chaining 1024 of
+    // them was 20 us of every escaped stream's decode, a 4 KiB one included
+    auto comb = [](uint32_t a, uint32_t b) { return (b & 2) ? ((a & 2) | ((a ^ b) & 1)) : b; };   // a, then b
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = all | par;
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc = comb(y, inc); }
+    if (lane == 63) s_w[wv] = (uint8_t)inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t p = 0;
-        for (int k = 0; k < 1024; k++) { s_in[k] = (uint8_t)p; const uint32_t v = s_chunk[k]; p = (v & 2) ? p ^ (v & 1) : (v & 1); }
-    }
-    __syncthreads();
-    uint32_t p = s_in[threadIdx.x];
+    uint32_t before = 2;
+    for (uint32_t k = 0; k < wv; k++) before = comb(before, s_w[k]);
+    uint32_t exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 2;
+    uint32_t p = comb(before, exc) & 1;
     for (uint32_t b = b0; b < b1; b += 16) {
         if (b + 16 <= n_blk) {
             const uint4 v = *reinterpret_cast<const uint4 *>(summ + b);
@@ -872,7 +883,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
     uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + round_up(n_ub, 16);   // both 16-byte aligned
     // ---- L2
-    const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), n_groups = (uint32_t)ceil_div(n_tiles, DGRP);
+    const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), dgrp = group_tiles(n_tiles), n_groups = (uint32_t)ceil_div(n_tiles, dgrp);
     rc = dev_buf(c, 19, (size_t)n_tiles * 8 + 64, &p); if (rc) return rc;
     uint2 *d_tinfo = (uint2 *)p;
     uint32_t *d_maxptr = (uint32_t *)(d_flag + 2);
@@ -909,7 +920,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             attr_tl = (size_t)TL * 4;
         }
         if (n_groups > 1) {
-            RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, d_comp);
+            RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, dgrp, d_comp);
             static const bool serial_chain = getenv("RSN_LZSS_DEC_SERIAL_CHAIN") != nullptr;   // A/B switch: one block walks the groups in order
             const uint32_t n_links = n_groups - 1;
             if (serial_chain) RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_links, d_gtail);
@@ -926,7 +937,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             *out_n = E;
             if (!d_out || E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
         }
-        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0);
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (hflag[3]) tile_path = false;                                  // a tile's input did not fit (zero-length tokens): redo with the general path

@@ -134,10 +134,37 @@ def test_sizes_text_tile_edges(lz, oracle, n):
     assert lz.Decompress(c) == data
 
 
-@pytest.mark.parametrize("tiles", [1, 2, 127, 128, 129, 256, 257])
-def test_decode_tile_and_group_edges(lz, oracle, tiles):
-    """Escaped-stream lengths at, before and after the 16 KiB resolve tiles and the 128-tile chain
-    groups, on data whose copies chain across every tile (period) and on text."""
+@pytest.fixture(params=["groups by size", "groups of 128"])
+def group_mode(request):
+    """The decoder's chain groups: 4 tiles for streams up to 2048 tiles, n_tiles / 512 beyond, 128 from 1 GiB
+    (lzss_decode.hip group_tiles); RSN_LZSS_DEC_GROUP128 fixes them at 128 whatever the size."""
+    if request.param == "groups of 128":
+        os.environ["RSN_LZSS_DEC_GROUP128"] = "1"
+        yield request.param
+        del os.environ["RSN_LZSS_DEC_GROUP128"]
+    else:
+        yield request.param
+
+
+def test_decode_group_sizes_of_mid_streams(lz):
+    """2561 tiles (40 MiB, groups of 5) and 8195 tiles (128 MiB, groups of 16): copies that chain across every tile
+    and group, text between them; device-resident round trip."""
+    import torch
+    rng = np.random.default_rng(5)
+    vals = np.array([v for v in range(256) if v not in (0x5C, 0xFF, 0x3C)], dtype=np.uint8)
+    blk = vals[rng.integers(0, len(vals), size=4096)].tobytes()
+    unit = text(9, 300000) + blk * 40 + text(10, 100000) + blk * 3
+    for tiles in (2561, 8195):
+        n = tiles * 16384 - 7
+        src = torch.frombuffer(bytearray((unit * (n // len(unit) + 1))[:n]), dtype=torch.uint8).cuda()
+        c = lz.compress_tensor(src)
+        assert torch.equal(lz.decompress_tensor(c), src), tiles
+
+
+@pytest.mark.parametrize("tiles", [1, 2, 3, 4, 5, 127, 128, 129, 256, 257])
+def test_decode_tile_and_group_edges(lz, oracle, tiles, group_mode):
+    """Escaped-stream lengths at, before and after the 16 KiB resolve tiles and the chain groups (of 4 tiles at
+    these sizes, and of 128), on data whose copies chain across every tile (period) and on text."""
     rng = np.random.default_rng(tiles)
     vals = np.array([v for v in range(256) if v not in (0x5C, 0xFF, 0x3C)], dtype=np.uint8)
     blk = vals[rng.integers(0, len(vals), size=4096)].tobytes()
@@ -357,6 +384,16 @@ def test_escape_blocks_plain_and_mixed(lz, oracle, shift):
     c = lz.CompressAsync(data)
     assert c == oracle.lzss_compress(data, 4096)
     assert lz.Decompress(c, False) == data
+
+
+def test_unescape_parity_across_many_blocks(lz, oracle):
+    """Runs of backslashes far longer than an unescape block (4 KiB of escaped stream) and than one lane's chunk of
+    block summaries (16 blocks): whether a 5C escapes or is escaped depends on the parity of the run before it,
+    carried across blocks by k_une_carry's scan.  Odd and even run lengths, a run that ends the stream."""
+    for a, b in ((300001, 70000), (65536 * 3, 65537), (12345, 1)):
+        data = b"\\" * a + b"x\xff<" + b"\\" * b + text(a & 255, 50000) + b"\\" * (b // 3)
+        c = lz.CompressAsync(data)
+        assert lz.Decompress(c) == oracle.lzss_decompress(c) == data
 
 
 def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
