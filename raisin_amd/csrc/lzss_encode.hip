@@ -1794,9 +1794,10 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             static const bool serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;       //               or by one lane per tile whatever the size
             // (the second look concerns a handful of tiles, dense ones among them: a lone lane's 8 000 dependent loads would be all
             //  the call waits for -- there the block-per-tile kernel, which returns at once everywhere else, is the faster one.
-            //  The same holds for a whole small stream: 235 us for the lone lanes against 25 for the blocks, whose cost grows with
-            //  the tiles -- 1.9 against 3 ms per GiB)
-            if (doubling || second || (n_pt < 4096 && !serial)) {
+            //  The same holds for a whole stream below 256 MiB: a lone lane's walk is 235 us on short steps and 0.7 ms on text
+            //  however few the tiles, the blocks take 17-23 ns per tile -- text: 0.29 against 0.96 ms at 64 MiB, 0.56 against 0.95
+            //  at 127 MiB, level at 256 MiB, 3 against 1.9 ms at 1 GiB)
+            if (doubling || second || (n_pt < 32768 && !serial)) {
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
             } else RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);

@@ -349,8 +349,9 @@ def test_chain_periodic_stretches_between_text(lz, oracle):
 
 
 def test_chain_vs_allpos_switch(oracle):
-    """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes: separate process,
-    the switch is read once."""
+    """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes, and so does the in-tile parse by
+    one lane per tile (RSN_LZSS_TAIL_SERIAL: what streams of 256 MiB and more take; below, a block per tile does
+    it): separate processes, the switches are read once."""
     import os
     import subprocess
     import sys
@@ -361,12 +362,12 @@ def test_chain_vs_allpos_switch(oracle):
             "d = text(5, 150000) + long_copies(4, 60000)\n"
             "print(hashlib.sha256(lz.CompressAsync(d)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"RSN_LZSS_ALLPOS": "1"}):
+    for env in ({}, {"RSN_LZSS_ALLPOS": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1"}):
         e = dict(os.environ); e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
     import hashlib
     d = text(5, 150000) + long_copies(4, 60000)
-    assert outs[0] == outs[1] == hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
+    assert outs[0] == outs[1] == outs[2] == hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
 
 
 @pytest.mark.parametrize("shift", [0, 1, 2, 3, 4, 5])
