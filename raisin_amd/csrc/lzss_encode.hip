@@ -1800,7 +1800,14 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             if (doubling || second || (n_pt < 32768 && !serial)) {
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-            } else RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
+            } else {
+                // (tile 0 by a block of its own first: it is exempt from the density test, and the literal-heavy start of a stream --
+                //  config 3's first 4096 bytes match nothing -- is 8192 one-byte steps for a lone lane, 0.75 ms that every other
+                //  lane would wait for; the serial kernel then finds the tile resolved)
+                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
+            }
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
