@@ -237,9 +237,35 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
         del src, c, d, ebuf, dbuf
         torch.cuda.empty_cache()
 
+    def chunks_on_one_gpu(k=8):
+        """Config 5 as one GPU sees it: k independent chunks (seeds 0x5EED0050 + i), one complete .rsn segment each, encoded one
+        after the other (engine.CompressFiles' loop, engine.go:150-154); the multi-GPU form is `bench.py --gpus N`."""
+        srcs = [W.config_input("5", n, device, chunk=i) for i in range(k)]
+        outs = [torch.empty(n + n // 8 + (1 << 20), dtype=torch.uint8, device=device) for _ in range(k)]
+        for i in range(k):
+            huffman.compress_tensor(srcs[i], out=outs[i])
+        torch.cuda.synchronize(device)
+        reps, te = 2, 0.0
+        for _ in range(reps):
+            segs, t = _timed(lambda: [huffman.compress_tensor(srcs[i], out=outs[i]) for i in range(k)])
+            te += t
+        te = te / reps * 1e3
+        dec = torch.empty(n + (1 << 20), dtype=torch.uint8, device=device)
+        ok = all(bool(torch.equal(huffman.decompress_tensor(segs[i], out=dec), srcs[i])) for i in range(k))   # every segment decodes on its own
+        C = sum(int(x.numel()) for x in segs)
+        out["5"] = {"algorithm": "huffman", "chunks": k, "bytes": k * n, "encode_ms": round(te, 3), "encode_MBps": round(k * n / 1e6 / (te / 1e3), 1),
+                    "ratio_pct": round(100.0 * C / (k * n), 3), "lossless": ok,
+                    "encode_frac_of_hbm_peak": round((2 * k * n + C) / (te / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "note": "one GPU, chunks one after the other; the sharded form with its gather is the --gpus N run"}
+        del srcs, outs, segs, dec
+        torch.cuda.empty_cache()
+
     for name in names:
         try:
-            one(name)
+            if name == "5":
+                chunks_on_one_gpu()
+            else:
+                one(name)
         except Exception as e:          # noqa: BLE001 -- reported in the line, the other configs still run
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
@@ -254,7 +280,7 @@ def main():
     ap.add_argument("--mib", type=int, default=1024, help="buffer size per GPU (default: the 1 GiB of BASELINE.json)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs after the timed region")
-    ap.add_argument("--others", default="2b,skewed,3,4")
+    ap.add_argument("--others", default="2b,skewed,3,4,5")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
