@@ -839,7 +839,9 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     // chains loses: almost every position is visited, and a whole wavefront per visit costs more than
     // k_match_hash's one lane per position with its near-empty buckets.  A wavefront whose chain
     // advanced less than two positions per visit hands the strip to k_match_hash.
-    constexpr uint32_t DENSE_EVALS = 32;
+    // (64 visits: at 32, a few text tiles in every ten thousand -- two or three rare words in a row are a few dozen one-byte steps --
+    //  gave up, and each such tile costs the stream a second look; noise gives up at 64 as surely as at 32)
+    constexpr uint32_t DENSE_EVALS = 64;
     // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
     //  state machine and spends ~40 scalar instructions per visit on its masks, and scalar issue is this kernel's bound.)
     bool alive = true;
