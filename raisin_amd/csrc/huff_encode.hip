@@ -31,6 +31,7 @@ constexpr int SMALL_TILE = 4096;   // ... of an input up to SMALL_INPUT bytes.  
 constexpr size_t SMALL_INPUT = (size_t)2 << 20;   // round whatever the input's size: 64 KiB as one tile is 16 rounds in a row on one CU beside 255 idle ones
 // (64 KiB of UTF-8 text 318 -> 144 us, 1 MiB 331 -> 153, ASCII 83 -> 58 and 74 -> 64; from 8 MiB the per-tile histograms cost the ASCII path more than the
 //  blocks gain -- 90 -> 121 us -- and at 64 MiB both paths lose: r02k A/B, scripts/huff_tile_ab.py)
+constexpr size_t RUNE_SMALL_INPUT = (size_t)16 << 20;   // the same switch for inputs with bytes >= 0x80 (their kernels read no tile histogram; at 64 MiB: 636 -> 680 us)
 constexpr int HB = 256;            // threads per block (4 wavefronts)
 constexpr int ROUND = HB * 16;     // input bytes per block round (16 B per lane)
 
@@ -844,8 +845,8 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
     static const bool no_small_tiles = getenv("RSN_HUFF_NO_SMALL_TILES") != nullptr;   // A/B switch
-    const uint32_t tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
-    const uint32_t n_tiles = (uint32_t)ceil_div(n, tile);
+    uint32_t tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
+    uint32_t n_tiles = (uint32_t)ceil_div(n, tile);
     void *p;
     int rc = dev_buf(c, 0, (size_t)n_tiles * 128 * 4, &p); if (rc) return rc;
     uint32_t *d_tile_hist = (uint32_t *)p;
@@ -857,6 +858,10 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
     rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, tile, d_tile_hist, syms, ascii); if (rc) return rc;
+    if (!ascii && !no_small_tiles && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
+        tile = SMALL_TILE;
+        n_tiles = (uint32_t)ceil_div(n, tile);
+    }
     const auto t1 = now();
 
     std::string hdr;

@@ -97,6 +97,9 @@ def test_small_and_large_tiles(huff, oracle):
             c = huff.Compress(data)
             assert c == oracle.huffman_compress(data)
             assert huff.Decompress(c) == oracle.huffman_decompress(c)
+    for n in (16 << 20, (16 << 20) + 1):                          # the rune path keeps the small tiles up to 16 MiB
+        data = (utf8 * (n // len(utf8) + 2))[3:n + 3]
+        assert huff.Compress(data) == oracle.huffman_compress(data)
 
 
 def test_device_resident_api(huff, oracle):
