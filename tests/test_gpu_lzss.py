@@ -410,7 +410,7 @@ def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
     try:
         for data, walks in ((noise, False), (half, True)):
             c, p = _prof(lz, data)
-            if _chain_mode():
+            if _chain_mode() and not os.environ.get("RSN_LZSS_NO_SAMPLE"):
                 assert p["lzss_sample"][0] == 2                            # the list and the 64-tile walk
                 assert ("lzss_match_chain" in p) == walks
             assert c == want[id(data)]
