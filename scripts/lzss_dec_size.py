@@ -1,3 +1,4 @@
+"""LZSS decode of config 4's text at one size (MiB), three timed calls and the kernels of a fourth."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,4 @@
+"""LZSS encode of 16 MiB and 1 GiB of random bytes: the chain walk's dense hand-off to the bucket search."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
