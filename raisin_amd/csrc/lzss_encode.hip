@@ -842,6 +842,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     // (64 visits: at 32, a few text tiles in every ten thousand -- two or three rare words in a row are a few dozen one-byte steps --
     //  gave up, and each such tile costs the stream a second look; noise gives up at 64 as surely as at 32)
     constexpr uint32_t DENSE_EVALS = 64;
+    constexpr uint32_t LONG_CAP = 8;                                      // candidates with a common prefix of HLMAX bytes and more that a visit follows through memory
     // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
     //  state machine and spends ~40 scalar instructions per visit on its masks, and scalar issue is this kernel's bound.)
     bool alive = true;
@@ -869,7 +870,8 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             // (the bigram, its bucket index and tag stay in vector registers although they are wave-uniform: scalar issue is the bound)
             const uint32_t u_b0 = sb[u_irel], u_b1 = sb[u_irel + 1];
             uint32_t best = 0;
-            bool longm = false;
+            bool longm = false;                                               // a common prefix reached HLMAX bytes
+            uint32_t long_best = 0, long_far = 0, n_long = 0;                 // wave-uniform: the best of the long candidates that were followed up, the farthest of all, how many (LONG_CAP + 1: too many)
             {   // (a position with a single byte left needs no case of its own: the stage is zero behind the stream and L is capped at E - i)
                 const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
                 // (bucket bounds and the bisection's arithmetic stay in VECTOR registers although every lane holds the same values:
@@ -923,6 +925,30 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                             room = go ? (x2 == 0 ? room : 0u) : 0u;
                             if (__ballot((room ? off + 8 : 0u) >= HLMAX)) { longm = true; room = 0; }
                         }
+                        if (__ballot(x == 0 && off + 8 >= HLMAX)) {
+                            // The candidates that were still going when the cap stopped the loop (they advance in step, so they are the
+                            // lanes with eight equal bytes at the last offset) agree with the position for HLMAX bytes and more -- further
+                            // than the stage reaches.  Up to LONG_CAP of them per visit are followed through memory to their true end,
+                            // min(common prefix, distance, bytes left): a repeated block has a handful of earlier copies.  Runs and short
+                            // periods have thousands: there only the farthest is kept (see the commit below).  Their entries in `best`
+                            // stay as the lower bounds they are.
+                            const bool fl = x == 0 && off + 8 >= HLMAX;
+                            unsigned long long fm = __ballot(fl);
+                            long_far = max(long_far, wave_max_u32(fl ? dn : 0u));
+                            while (fm && n_long < LONG_CAP) {
+                                const int j = __builtin_ctzll(fm);
+                                fm &= fm - 1;
+                                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dn, j), limj = (uint32_t)__builtin_amdgcn_readlane((int)lim, j);
+                                const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)off, j) + 8;   // equal so far: bytes [0, from)
+                                uint32_t mm = limj;                            // first byte that differs, if any lies below the limit
+                                for (uint32_t k = from + lane; k < limj && mm == limj; k += 64)
+                                    if (a.fc[(size_t)u_ipos + k] != a.fc[(size_t)u_ipos - dj + k]) mm = k;
+                                mm = ~wave_max_u32(~mm);                       // the minimum over the lanes
+                                long_best = max(long_best, (mm << 16) | dj);
+                                n_long++;
+                            }
+                            if (fm) n_long = LONG_CAP + 1;                     // more of them than are followed up
+                        }
                         const uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
                         uint32_t len = min(off + n, lim);
                         if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
@@ -942,13 +968,19 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             if (best != 0 && !longm) commit(best);                            // the common case first, with nothing else on its path
             else {
                 bool giveup_heavy = false, giveup_dense = false;
-                if (longm) {   // a common prefix of HLMAX bytes: either the stream repeats with period W here -- then nothing beats
-                               // L = min(W, E-i) at the largest distance W (see k_match) -- or the strip goes to the sweep
-                    const uint32_t Lp = min(W, u_capE);
-                    bool eq = u_ipos >= W;
-                    if (eq) for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - W + k];
-                    if (__ballot(!eq)) giveup_heavy = true;
-                    else best = (Lp << 16) | W;
+                if (longm) {
+                    if (n_long <= LONG_CAP) best = max(best, long_best);             // every long candidate was followed to its end: the maximum is exact
+                    else {
+                        // More long candidates than are followed up: a run, a short period, the W-periodic stream of config 3.  No candidate's
+                        // L exceeds its distance, so if the FARTHEST long one matches over its whole distance (or to the end of the stream)
+                        // nothing beats it: the nearer ones are shorter, or tie and lose the tie (bytes.Index takes the leftmost,
+                        // lzss.go:419), and the farther ones stopped short of HLMAX bytes.  Otherwise the strip goes to the sweep.
+                        const uint32_t Lp = min(long_far, u_capE);
+                        bool eq = true;
+                        for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - long_far + k];
+                        if (__ballot(!eq)) giveup_heavy = true;
+                        else best = (Lp << 16) | long_far;
+                    }
                 }
                 if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
                     // (the density test sits on this path because dense data comes through here all the time, text rarely)

@@ -196,6 +196,37 @@ def test_bucket_search_hands_strips_back(lz, oracle):
         assert lz.CompressAsync(data[:120000], False, w) == oracle.lzss_compress(data[:120000], w)
 
 
+def test_long_matches_followed_through_memory(lz, oracle):
+    """Common prefixes of 256 bytes and more -- beyond what the chain walk's LDS stage holds.  Up to eight such candidates
+    per position are followed through memory to their true end (min of common prefix, distance, bytes left); with more
+    of them (runs, short periods) the farthest decides if it matches over its whole distance, else the strip goes to
+    the sweep.  Every case against the oracle: single copies, several earlier copies of different lengths (longest wins,
+    then farthest), more than eight copies, runs at the start / inside / at the end of a stream, short periods inside
+    text, a long match cut by the end of the stream, windows smaller than the copies' distances."""
+    rng = np.random.default_rng(123)
+
+    def noise(k):
+        return rng.integers(97, 123, size=k, dtype=np.uint8).tobytes()
+
+    blk = noise(2000)
+    cases = {
+        "one copy": text(1, 9000) + blk + text(2, 1500) + blk[:1000] + b"!" + text(3, 9000),
+        "copies of different lengths": text(4, 5000) + blk[:300] + b"1" + noise(200) + blk[:700] + b"2" + noise(150) + blk[:1900] + b"3" + noise(100)
+                                       + blk[:1200] + b"4" + text(5, 6000),
+        "equal lengths, farthest wins": text(6, 3000) + blk[:600] + b"A" + noise(50) + blk[:600] + b"B" + noise(70) + blk[:600] + b"C" + noise(20) + blk[:600] + b"D" + text(7, 3000),
+        "twelve copies": text(8, 2000) + b"".join(blk[:280] + bytes([65 + i]) + noise(10 + 3 * i) for i in range(12)) + blk[:280] + b"z" + text(9, 4000),
+        "run at the start": b"\x00" * 70000 + text(10, 20000),
+        "runs inside and at the end": text(11, 10000) + b"a" * 3000 + text(12, 300) + b"a" * 9000 + b"b" * 5000 + text(13, 8000) + b"q" * 12345,
+        "short periods inside text": text(14, 6000) + b"ab" * 4000 + text(15, 500) + b"xyz" * 3000 + text(16, 700) + (noise(7) * 2000) + text(17, 9000) + (noise(1000) * 9),
+        "cut by the end of the stream": text(18, 12000) + blk + text(19, 700) + blk[:900],
+    }
+    for name, data in cases.items():
+        for w in (4096, 1000):
+            c = lz.CompressAsync(data, False, w)
+            assert c == oracle.lzss_compress_mt(data, w, oracle.host_cores(), 4096), (name, w)
+        assert lz.Decompress(c) == data, name
+
+
 def test_match_table_against_oracle(lz, oracle):
     """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
     data = text(21, 50000)
