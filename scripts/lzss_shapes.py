@@ -20,6 +20,11 @@ def shapes(n, dev):
     yield "sawtooth 0..255", (ar % 256).to(torch.uint8)
     runs = torch.repeat_interleave(torch.randint(97, 101, (n // 37 + 1,), device=dev, generator=g, dtype=torch.uint8), 37)[:n].contiguous()
     yield "runs of 37", runs
+    small = torch.randint(0, 300, (n // 4 + 1,), device=dev, generator=g, dtype=torch.int32)
+    yield "int32 values below 300", small.view(torch.uint8)[:n].contiguous()
+    yield "four-letter alphabet, random", (torch.randint(0, 4, (n,), device=dev, generator=g, dtype=torch.uint8) * 3 + 65)
+    hexd = torch.randint(0, 16, (n,), device=dev, generator=g, dtype=torch.uint8)
+    yield "hex digits, random", torch.where(hexd < 10, hexd + 48, hexd + 87)
 
 for mib in [int(a) for a in sys.argv[1:]] or [16]:
     n = mib << 20
