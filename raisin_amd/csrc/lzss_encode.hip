@@ -1772,7 +1772,8 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     uint8_t *d_dump = nullptr;
     uint32_t *d_redo_list = nullptr;
-    const uint32_t redo_cap = std::max(64u, n_pt / 64);               // a second look is worth it for this many tiles at most (and room for the sample below)
+    const uint32_t redo_cap = n_pt + 64;                              // the list of a second look: every tile can be on it (and room for the sample below)
+    const uint32_t gave_cap = std::max(64u, n_pt / 64);               // ... which is worth it while this many tiles at most gave up as dense / heavy: beyond, the bucket search is the tool
     if (chain_mode) {
         void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
         d_dump = (uint8_t *)dp;
@@ -1858,9 +1859,16 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         // A few tiles gave up (a stretch of one- and two-byte steps looked "dense"), or entered on a chain that had not merged with the
         // true one yet: walk just those -- without that test / from the true entry, the tile before's exit -- and check again.  A joint
         // next to a tile that gave up can only be judged once that tile is resolved, hence up to three looks (each costs a few tiles).
+        // Joints by the thousand are data whose steps are long against the 128-position warm-up (runs of a few dozen bytes: a chain
+        // has three steps to merge in): the tile before's exit is still right -- its chain merged further in -- so one look from
+        // there mends them all, at the price of walking those tiles again (64 MiB of 37-byte runs: 65 ms through the general parse,
+        // 2258 of 8192 joints; 12 ms with the look).  Chains that keep their phase (a period that does not divide the window) do not
+        // converge: a look that leaves more than half of its list behind is the last, and a list of more than half the tiles is not tried.
+        uint32_t prev_list = 0xFFFFFFFFu;
         for (int look = 2; look <= 4 && !parsed && !no_fused; look++) {
-            const uint32_t n_list = (uint32_t)(h64[2] >> 32);
-            if (n_list == 0 || n_list > redo_cap) break;
+            const uint32_t n_list = (uint32_t)(h64[2] >> 32), n_gave = (uint32_t)h64[1];
+            if (n_list == 0 || n_list > redo_cap || n_gave > gave_cap || (n_list > 64 && n_list > prev_list / 2) || n_list > n_pt / 2 + 64) break;
+            prev_list = n_list;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(n_list), dim3(CC::CTH), 0, s, ha);
             rc = resolve(true); if (rc) return rc;

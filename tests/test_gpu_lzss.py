@@ -227,6 +227,19 @@ def test_long_matches_followed_through_memory(lz, oracle):
         assert lz.Decompress(c) == data, name
 
 
+def test_joints_by_the_hundred_are_mended_by_one_look(lz, oracle):
+    """Runs of 37 equal bytes from four letters: steps of 40 to 100 positions leave a tile's 128-position warm-up chain two or
+    three steps to merge with the true chain, and a quarter of the joints fail.  The tile before's exit is right all the
+    same (its chain merged further in), so one second look from there mends them all: no general parse."""
+    rng = np.random.default_rng(37)
+    data = np.repeat(rng.integers(97, 101, size=(3 << 20) // 37 + 1, dtype=np.uint8), 37)[: 3 << 20].tobytes()
+    c, p = _prof(lz, data)
+    assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
+    assert lz.Decompress(c) == data
+    if _chain_mode() and "RSN_LZSS_NO_FUSED_PARSE" not in os.environ:
+        assert p["lzss_match_chain"][0] >= 2 and "lzss_parse_mark" not in p, sorted(p)
+
+
 def test_match_table_against_oracle(lz, oracle):
     """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
     data = text(21, 50000)
