@@ -431,7 +431,7 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
 // 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
-struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; };   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
+struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; uint32_t *step; const uint32_t *redo_start; };   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
 struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
 __device__ __forceinline__ ChainTail chain_tail() {
     return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
@@ -708,7 +708,7 @@ __device__ __forceinline__ uint32_t vec(uint32_t x) { asm volatile("" : "+v"(x))
 // (64 x 16 bytes) and cost next to nothing.  Nobody writes a periodic tile's keys (4 bytes per position for nothing): k_chain_periodic
 // places the chain by arithmetic, k_tok_emit computes the key of a flagged position, k_chain_unknown stores them only if the general
 // parse has to take over.  Every tile's record is (re)initialised here: walked = 2 for a periodic tile, 0 otherwise.
-__global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict__ fc, uint32_t E, uint32_t W, uint32_t tile, TileChain *__restrict__ tchain) {
+__global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict__ fc, uint32_t E, uint32_t W, uint32_t tile, TileChain *__restrict__ tchain, uint32_t *__restrict__ step) {
     const int tid = threadIdx.x;
     const long long t0 = (long long)blockIdx.x * tile;
     bool ok = t0 >= (long long)W;                                         // (the first window has nothing to repeat)
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
             ok = __syncthreads_and(ok);
         } else ok = false;
     }
-    if (tid == 0) tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0};
+    if (tid == 0) { tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0}; step[blockIdx.x] = 0; }
 }
 
 template <class C>
@@ -745,6 +745,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __shared__ unsigned long long s_present[256];                         // per byte value: the 2^CSH-position blocks of the stage it occurs in
     __shared__ uint32_t s_part[CTH / 64];
     __shared__ uint32_t s_heavy, s_next, s_dense;
+    __shared__ uint32_t s_nstep, s_stepmin, s_stepmax;                    // commits whose match runs over its whole distance (L = distance >= HLMAX), and the range of those distances
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
     // the tile.  A partial launch takes it from a list (k_chain_verify's: the tiles that gave up as "dense", and -- top bit set -- the tiles
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
     for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) s_claim[i] = 0;
     for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
-    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; }
+    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; s_nstep = 0; s_stepmin = 0xFFFFFFFFu; s_stepmax = 0; }
     __syncthreads();
 
     // ---- group the staged positions by bigram (as k_match_hash): candidates are [rlo, rhi)
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0);
     const uint32_t kp_end = CH + npos;                                    // a chain stops when it leaves the tile
     uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                       // the warm-up start (CH in tile 0: the true start)
-    if (list_entry >> 31) kp_first = chain_tail().tchain[bx - 1].exit - (uint32_t)(t0 - CH);   // the true entry, known from the first look
+    if (list_entry >> 31) kp_first = chain_tail().redo_start[blockIdx.x] - (uint32_t)(t0 - CH);   // the true entry as k_chain_verify worked it out: the tile before's exit, or a whole-distance stretch's arithmetic
     const uint32_t nitems = 1 + (npos + CS - 1) / CS;
     // a wavefront that gives up (s_heavy) also pushes the start counter past every item: the others
     // finish the chain they are on (at most CS-odd positions) and find nothing more to start
@@ -974,12 +975,29 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                         // More long candidates than are followed up: a run, a short period, the W-periodic stream of config 3.  No candidate's
                         // L exceeds its distance, so if the FARTHEST long one matches over its whole distance (or to the end of the stream)
                         // nothing beats it: the nearer ones are shorter, or tie and lose the tie (bytes.Index takes the leftmost,
-                        // lzss.go:419), and the farther ones stopped short of HLMAX bytes.  Otherwise the strip goes to the sweep.
+                        // lzss.go:419), and the farther ones stopped short of HLMAX bytes.
                         const uint32_t Lp = min(long_far, u_capE);
-                        bool eq = true;
-                        for (uint32_t k = lane; k < Lp; k += 64) eq = eq && a.fc[(size_t)u_ipos + k] == a.fc[(size_t)u_ipos - long_far + k];
-                        if (__ballot(!eq)) giveup_heavy = true;
-                        else best = (Lp << 16) | long_far;
+                        uint32_t mm = Lp;                                     // the first byte in which the farthest long candidate differs
+                        for (uint32_t k = lane; k < Lp && mm == Lp; k += 64) if (a.fc[(size_t)u_ipos + k] != a.fc[(size_t)u_ipos - long_far + k]) mm = k;
+                        mm = ~wave_max_u32(~mm);
+                        if (mm == Lp) best = (Lp << 16) | long_far;
+                        else {
+                            // It stops after mm bytes (the end of a periodic stretch: all its candidates stop there).  Another candidate
+                            // does better only if it is more than mm back AND agrees with the position in byte mm -- those that stop at
+                            // the same byte tie and lose the tie to the farthest.  One byte per candidate settles it; if one does
+                            // agree there, the strip goes to the sweep after all.
+                            const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
+                            const uint32_t lo = u_h ? (uint32_t)ends[u_h - 1] : 0u, hi = ends[u_h];
+                            const uint32_t want = a.fc[(size_t)u_ipos + mm];
+                            bool other = false;
+                            for (uint32_t idx = lo + lane; idx < hi; idx += 64) {
+                                const uint32_t e = s_list[idx], dn = u_irel - (e & OFFM);
+                                const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ u_tag) << 20)) < W;
+                                if (ok && dn > mm && dn <= u_ipos && a.fc[(size_t)u_ipos - dn + mm] == want) other = true;
+                            }
+                            if (__ballot(other)) giveup_heavy = true;
+                            else best = max(best, (mm << 16) | long_far);
+                        }
                     }
                 }
                 if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
@@ -1005,6 +1023,9 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                         best = hit ? (1u << 16) : 0u;
                     }
                 }
+                if (longm && !giveup_heavy && (best >> 16) == (best & 0xFFFFu) && lane == 0) {   // (rare path: the counters cost the text walk nothing)
+                    atomicAdd(&s_nstep, 1u); atomicMin(&s_stepmin, best & 0xFFFFu); atomicMax(&s_stepmax, best & 0xFFFFu);
+                }
                 if (giveup_heavy || giveup_dense) {
                     // the start counter is pushed past every item; the other wavefronts finish the chain they are on (text: a handful
                     // of visits; dense data: they run into this test themselves within DENSE_EVALS visits) and find nothing more to start
@@ -1025,7 +1046,21 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     const ChainTail T = chain_tail();
     if (tid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
     if (tid == 0 && s_dense && !s_heavy) { T.dense[bx / (MATCH_STRIP / CT)] = 1; if (T.n_dense) atomicAdd(T.n_dense, 1u); }
-    if (s_heavy || s_dense) { if (tid == 0) T.tchain[bx] = TileChain{0, 0, 0, 0}; return; }
+    if (s_heavy || s_dense) { if (tid == 0) { T.tchain[bx] = TileChain{0, 0, 0, 0}; T.step[bx] = 0; } return; }
+    {   // Every visit of this tile a match over its whole distance, and the same distance d: the stretch repeats with a period that d is
+        // the largest multiple of inside the window, every chain in it steps by d and keeps its phase -- the chains of neighbouring tiles
+        // never join.  The tile says so (step = d): k_stretch_pred then places the true chain by arithmetic and the next look walks it.
+        uint32_t cl = 0;
+        for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
+        for (int dd = 32; dd; dd >>= 1) cl += __shfl_down(cl, dd);
+        if (lane == 0) s_part[wv] = cl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t all = 0;
+            for (int k = 0; k < CTH / 64; k++) all += s_part[k];
+            T.step[bx] = (s_nstep == all && all != 0 && s_stepmin == s_stepmax) ? s_stepmin : 0u;
+        }
+    }
 
     // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
     {
@@ -1202,7 +1237,8 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
 // arithmetic: from that tile's exit x the chain steps by W through the periodic stretch, so it enters this tile
 // at x + W * ceil((t0 - x) / W) -- valid because every tile in between is periodic too (checked) -- and the flags,
 // the output bytes and the tile's entry / exit follow.  k_chain_verify then checks the joints as for any tile.
-__global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t *__restrict__ prev, uint32_t *__restrict__ part) {
+__global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t *__restrict__ prev, uint32_t *__restrict__ part,
+                                                      const uint32_t *__restrict__ vals = nullptr) {   // vals: scan these (index + 1 or 0 per tile) instead of "walked"
     // one block per PREV_BLK tiles: the inclusive maximum inside the block; k_prev_fix brings in the blocks before
     constexpr int IT = PREV_BLK / 1024;
     __shared__ uint32_t wmax[16];
@@ -1210,7 +1246,7 @@ __global__ __launch_bounds__(1024) void k_prev_walked(const TileChain *__restric
     const uint32_t i0 = blockIdx.x * PREV_BLK + tid * IT;
     uint32_t x[IT], loc = 0;
 #pragma unroll
-    for (int k = 0; k < IT; k++) { x[k] = (i0 + k < n_tiles && tc[i0 + k].walked == 1) ? i0 + k + 1 : 0u; loc = max(loc, x[k]); }   // 0 = none yet; else tile index + 1
+    for (int k = 0; k < IT; k++) { x[k] = i0 + k >= n_tiles ? 0u : vals ? vals[i0 + k] : (tc[i0 + k].walked == 1 ? i0 + k + 1 : 0u); loc = max(loc, x[k]); }   // 0 = none yet; else tile index + 1
     uint32_t sfx = loc;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(sfx, d); if (lane >= d) sfx = max(sfx, y); }
     if (lane == 63) wmax[wv] = sfx;
@@ -1303,6 +1339,40 @@ __global__ __launch_bounds__(256) void k_chain_periodic(TileChain *__restrict__ 
     tc[k] = TileChain{(uint32_t)entry, (uint32_t)x, 2u, 1u};            // pad = 1: resolved
 }
 
+// Whole-distance stretches.  Where a stream repeats with a period p that does not divide the window, every position's match is the
+// farthest multiple of p inside the window, d, over d bytes; every chain steps by d and keeps its phase, so the chains that
+// neighbouring tiles walked from their own warm-up starts never join (k_tile_periodic's W-periodic tiles are the case d = W and have
+// their own arithmetic, k_chain_periodic).  k_match_chain reports such a tile (step[k] = d).  Here the true chain is placed through a
+// run of them: from the exit X of the tile just before the run, the chain enters the run's tile k at X + d * ceil((t0 - X) / d).
+// That is a prediction, not a proof: the next look walks the tile from there and k_chain_verify judges the joints as always; if X
+// itself changes in that look (the tile before the run was mended), the following look places the run again.
+__global__ void k_stretch_flags(const uint32_t *__restrict__ step, uint32_t n_tiles, uint32_t *__restrict__ brk) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tiles) return;
+    const uint32_t st = step[k];
+    brk[k] = (k == 0 || st == 0 || st != step[k - 1]) ? k + 1 : 0u;       // a run of equal steps begins here (index + 1, for k_prev_walked's inclusive max-scan)
+}
+__global__ void k_stretch_pred(const TileChain *__restrict__ tc, const uint32_t *__restrict__ step, const uint32_t *__restrict__ head_brk,
+                               uint32_t n_tiles, uint32_t tile, uint32_t E, uint32_t *__restrict__ pred) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tiles) return;
+    uint32_t out = 0xFFFFFFFFu;
+    const uint32_t st = step[k], hb = head_brk[k];
+    if (st != 0 && tc[k].walked == 1 && hb >= 2) {                        // the run of tiles that step by st begins at tile hb - 1; the tile before it hands the chain over
+        const uint32_t j = hb - 2;
+        const TileChain h = tc[j];
+        const uint32_t X = h.exit;
+        if ((h.walked == 1 || (h.walked == 2 && h.pad == 1)) && X != 0xFFFFFFFFu && X < E && (unsigned long long)X >= (unsigned long long)(j + 1) * tile &&
+            (unsigned long long)X < (unsigned long long)(j + 2) * tile) {
+            const unsigned long long t0 = (unsigned long long)k * tile;
+            unsigned long long x = X;
+            if (x < t0) x += (unsigned long long)st * ((t0 - x + st - 1) / st);
+            if (x < t0 + tile && x < E) out = (uint32_t)x;
+        }
+    }
+    pred[k] = out;
+}
+
 // Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
 // tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
 __global__ void k_sample_tiles(uint32_t *__restrict__ list, uint32_t n, uint32_t n_tiles) {   // n tiles spread evenly over the stream (not tile 0: it has no window)
@@ -1310,7 +1380,7 @@ __global__ void k_sample_tiles(uint32_t *__restrict__ list, uint32_t n, uint32_t
 }
 
 __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad,
-                               uint32_t *__restrict__ redo_list, uint32_t redo_cap) {
+                               uint32_t *__restrict__ redo_list, uint32_t redo_cap, uint32_t *__restrict__ redo_start, const uint32_t *__restrict__ pred) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = k < n_tiles;
     const TileChain c = live ? tc[k] : TileChain{0, 0, 1u, 0};
@@ -1329,21 +1399,29 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
         const unsigned long long m = __ballot(live && !ok && cls == q);
         if (m && (threadIdx.x & 63) == 0) atomicAdd(&bad[q], (uint32_t)__builtin_popcountll(m));
     }
-    // The list: a tile that gave up is walked again without the density test; a walked tile whose entry is not the exit of the
-    // (resolved) tile before it -- its warm-up chain had not merged with the true chain yet -- is walked again from that exit.
+    // The list (every tile decides for itself): a tile that gave up is walked again without the density test; a walked tile whose entry
+    // is not the exit of the (resolved) tile before it -- its warm-up chain had not merged with the true chain yet -- is walked again
+    // from that exit; a tile of a whole-distance stretch (pred, see k_stretch_pred) from the arithmetic entry -- or not at all if it
+    // is on that phase already, whatever the tile before it says.  bad[4] counts the entries of the last kind.
     const bool gave = live && cls == 0;
-    bool fix = false;
-    if (live && !gave && k + 1 < n_tiles && c.entry != 0xFFFFFFFFu && (c.walked == 1 || c.pad == 1)) {
-        const TileChain nx = tc[k + 1];
-        fix = nx.walked == 1 && nx.entry != c.exit && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile &&
-              (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && c.exit < E;
+    uint32_t start = 0xFFFFFFFFu;
+    bool predicted = false;
+    if (live && !gave && c.walked == 1 && k > 0) {
+        const TileChain q = tc[k - 1];
+        if ((q.walked == 1 || q.pad == 1) && q.entry != 0xFFFFFFFFu && q.exit != c.entry && (unsigned long long)q.exit >= (unsigned long long)k * tile &&
+            (unsigned long long)q.exit < (unsigned long long)(k + 1) * tile && q.exit < E) start = q.exit;
+        const uint32_t pr = pred ? pred[k] : 0xFFFFFFFFu;
+        if (pr != 0xFFFFFFFFu) { start = pr != c.entry ? pr : 0xFFFFFFFFu; predicted = start != 0xFFFFFFFFu; }
     }
+    const bool fix = start != 0xFFFFFFFFu;
+    const unsigned long long mp = __ballot(predicted);
+    if (mp && (threadIdx.x & 63) == 0) atomicAdd(&bad[4], (uint32_t)__builtin_popcountll(mp));
     const unsigned long long ml = __ballot(gave || fix);
     if (ml) {
         uint32_t at = 0;
         if ((threadIdx.x & 63) == 0) at = atomicAdd(&bad[3], (uint32_t)__builtin_popcountll(ml));
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__builtin_popcountll(ml & ((1ull << (threadIdx.x & 63)) - 1ull));
-        if ((gave || fix) && at < redo_cap) redo_list[at] = gave ? k : ((k + 1) | 0x80000000u);
+        if ((gave || fix) && at < redo_cap) { redo_list[at] = gave ? k : (k | 0x80000000u); redo_start[at] = start; }
     }
 }
 
@@ -1771,21 +1849,24 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     bool parsed = false;                                              // flags + tile offsets + total are final
     using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     uint8_t *d_dump = nullptr;
-    uint32_t *d_redo_list = nullptr;
+    uint32_t *d_redo_list = nullptr, *d_redo_start = nullptr, *d_step = nullptr, *d_sbrk = nullptr, *d_hbrk = nullptr, *d_pred = nullptr;
     const uint32_t redo_cap = n_pt + 64;                              // the list of a second look: every tile can be on it (and room for the sample below)
     const uint32_t gave_cap = std::max(64u, n_pt / 64);               // ... which is worth it while this many tiles at most gave up as dense / heavy: beyond, the bucket search is the tool
     if (chain_mode) {
         void *dp; rc = dev_buf(c, 19, (size_t)n_pt * CC::DUMP_BYTES + 64, &dp); if (rc) return rc;   // (slot 19 is the decoder's too: never live at the same time)
         d_dump = (uint8_t *)dp;
-        void *rl; rc = dev_buf(c, 26, (size_t)redo_cap * 4 + 64, &rl); if (rc) return rc;
+        void *rl; rc = dev_buf(c, 26, (size_t)redo_cap * 8 + (size_t)n_pt * 16 + 64, &rl); if (rc) return rc;
         d_redo_list = (uint32_t *)rl;
+        d_redo_start = d_redo_list + redo_cap;                           // the entry each listed tile is walked from
+        d_step = d_redo_start + redo_cap;                                 // per tile: its whole-distance step (k_match_chain), then k_stretch_*'s scratch
+        d_sbrk = d_step + n_pt; d_hbrk = d_sbrk + n_pt; d_pred = d_hbrk + n_pt;
     }
     // Nearly incompressible input is the one case where the chain walk loses (every tile walks a few dozen visits per wavefront,
     // gives up as dense, and the bucket search does it all again: 57 against 41 ms per GiB of random bytes).  Large inputs walk a
     // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
     // (From 8192 tiles = 64 MiB: the sample is a launch that waits for one tile plus a host sync, 0.12 ms -- 15 % of an 8 MiB call,
     //  to save a stream of noise that size 0.13 ms.  RSN_LZSS_SAMPLE_MIN_TILES moves the threshold: the tests use it.)
-    if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain);
+    if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain, d_step);
     constexpr uint32_t SAMPLE_TILES = 64;
     static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
     const char *smin_env = getenv("RSN_LZSS_SAMPLE_MIN_TILES");
@@ -1794,7 +1875,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
-        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3)}};
+        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start}};
         RSN_LAUNCH("lzss_sample", k_match_chain<CC>, dim3(SAMPLE_TILES), dim3(CC::CTH), 0, s, hs);
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -1802,7 +1883,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     }
     if (chain_mode) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
-        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr}};
+        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
@@ -1823,7 +1904,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
         uint32_t *d_prev_part = (uint32_t *)pp;
-        auto resolve = [&](bool second) -> int {                                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
+        auto resolve = [&](bool second, bool with_pred) -> int {                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
             static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switches: the in-tile parse by pointer doubling in LDS,
             static const bool serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;       //               or by one lane per tile whatever the size
@@ -1846,13 +1927,21 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
             RSN_LAUNCH("lzss_chain_periodic", k_chain_periodic, dim3(n_pt), dim3(256), 0, s, d_tchain, d_entry, n_pt, E, W, (uint32_t)PT, d_flags, d_tbytes);
-            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1), d_redo_list, redo_cap);
+            if (with_pred) {                                              // whole-distance stretches: where the true chain enters their tiles (k_stretch_pred)
+                const dim3 tg((uint32_t)ceil_div(n_pt, 256));
+                RSN_LAUNCH("lzss_chain_stretch", k_stretch_flags, tg, dim3(256), 0, s, (const uint32_t *)d_step, n_pt, d_sbrk);
+                RSN_LAUNCH("lzss_chain_stretch", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_hbrk, d_prev_part, (const uint32_t *)d_sbrk);
+                if (n_prev > 1) RSN_LAUNCH("lzss_chain_stretch", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_hbrk, n_pt, (const uint32_t *)d_prev_part);
+                RSN_LAUNCH("lzss_chain_stretch", k_stretch_pred, tg, dim3(256), 0, s, d_tchain, d_step, d_hbrk, n_pt, (uint32_t)PT, E, d_pred);
+            }
+            RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1), d_redo_list, redo_cap,
+                       d_redo_start, (const uint32_t *)(with_pred ? d_pred : nullptr));
             rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
-            RSN_HIP(hipMemcpyAsync(h64, d_ttot, 24, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipMemcpyAsync(h64, d_ttot, 32, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
             return RSN_OK;
         };
-        rc = resolve(false); if (rc) return rc;
+        rc = resolve(false, false); if (rc) return rc;
         parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
@@ -1864,16 +1953,41 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         // there mends them all, at the price of walking those tiles again (64 MiB of 37-byte runs: 65 ms through the general parse,
         // 2258 of 8192 joints; 12 ms with the look).  Chains that keep their phase (a period that does not divide the window) do not
         // converge: a look that leaves more than half of its list behind is the last, and a list of more than half the tiles is not tried.
-        uint32_t prev_list = 0xFFFFFFFFu;
-        for (int look = 2; look <= 4 && !parsed && !no_fused; look++) {
-            const uint32_t n_list = (uint32_t)(h64[2] >> 32), n_gave = (uint32_t)h64[1];
-            if (n_list == 0 || n_list > redo_cap || n_gave > gave_cap || (n_list > 64 && n_list > prev_list / 2) || n_list > n_pt / 2 + 64) break;
-            prev_list = n_list;
+        // Joints that fail by the hundred may also be whole-distance stretches (k_stretch_pred): the list is then drawn up again with the
+        // true chain placed through them by arithmetic, and the look walks every tile of a stretch from its predicted entry.
+        static const bool no_pred = getenv("RSN_LZSS_NO_STRETCH") != nullptr;   // A/B switch
+        bool use_pred = false;
+        if (!parsed && !no_fused && !no_pred && (uint32_t)(h64[1] >> 32) > 64 && (uint32_t)h64[1] <= gave_cap) {   // (with more tiles given up than a look takes, none follows)
+            use_pred = true;
+            rc = resolve(true, true); if (rc) return rc;
+            if (dbg) fprintf(stderr, "lzss chain walk, stretches placed: list of %u tiles, %u of them by arithmetic\n", (uint32_t)(h64[2] >> 32), (uint32_t)h64[3]);
+        }
+        uint32_t prev_plain = 0xFFFFFFFFu;
+        for (int look = 2; look <= (use_pred ? 7 : 4) && !parsed && !no_fused; look++) {   // (a stretch is placed in the look after the one that mends the tile before it)
+            const uint32_t n_list = (uint32_t)(h64[2] >> 32), n_gave = (uint32_t)h64[1], n_arith = use_pred ? (uint32_t)h64[3] : 0u;
+            const uint32_t n_plain = n_list - std::min(n_list, n_arith);         // entries that are not placed by arithmetic: tiles that gave up, joints to mend
+            if (n_list == 0 || n_list > redo_cap || n_gave > gave_cap || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
+            prev_plain = n_plain;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(n_list), dim3(CC::CTH), 0, s, ha);
-            rc = resolve(true); if (rc) return rc;
+            rc = resolve(true, use_pred); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
             if (dbg) fprintf(stderr, "lzss chain walk, look %d: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", look, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
+            if (dbg && !parsed) {                                         // the first few tiles still on the list, with their neighbours' records
+                const uint32_t nl = std::min<uint32_t>((uint32_t)(h64[2] >> 32), 4);
+                uint32_t hl[4], hs[4];
+                RSN_HIP(hipMemcpy(hl, d_redo_list, nl * 4, hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(hs, d_redo_start, nl * 4, hipMemcpyDeviceToHost));
+                for (uint32_t q = 0; q < nl; q++) {
+                    const uint32_t k = hl[q] & 0x7FFFFFFFu, k0 = k ? k - 1 : 0;
+                    TileChain tcs[3] = {}; uint32_t st[3] = {}, pd[3] = {};
+                    const uint32_t cnt = std::min<uint32_t>(3, n_pt - k0);
+                    RSN_HIP(hipMemcpy(tcs, d_tchain + k0, cnt * sizeof(TileChain), hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(st, d_step + k0, cnt * 4, hipMemcpyDeviceToHost));
+                    if (use_pred) RSN_HIP(hipMemcpy(pd, d_pred + k0, cnt * 4, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "   listed tile %u (%s, start %u):", k, hl[q] >> 31 ? "joint" : "gave up", hs[q]);
+                    for (uint32_t u = 0; u < cnt; u++) fprintf(stderr, "  [%u: entry %u exit %u walked %u step %u pred %u]", k0 + u, tcs[u].entry, tcs[u].exit, tcs[u].walked, st[u], pd[u]);
+                    fprintf(stderr, "\n");
+                }
+            }
         }
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
             RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);

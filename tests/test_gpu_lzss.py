@@ -240,6 +240,30 @@ def test_joints_by_the_hundred_are_mended_by_one_look(lz, oracle):
         assert p["lzss_match_chain"][0] >= 2 and "lzss_parse_mark" not in p, sorted(p)
 
 
+@pytest.mark.parametrize("period", [3, 7, 258, 1000])
+def test_whole_distance_stretches_placed_by_arithmetic(lz, oracle, period):
+    """A stretch that repeats with a period which does not divide the window: every match there is the farthest multiple of
+    the period inside the window, over that whole distance, every chain steps by it and keeps its phase -- the per-tile
+    chains never join.  k_match_chain reports such tiles, k_stretch_pred places the true chain through the run of them,
+    one more look walks it: the oracle's bytes without the general parse.  Text before, between and after; a second
+    stretch with another period; a stretch that runs to the end of the stream."""
+    rng = np.random.default_rng(period)
+    per = rng.integers(97, 123, size=period, dtype=np.uint8).tobytes()
+    per2 = rng.integers(65, 91, size=period + 2, dtype=np.uint8).tobytes()
+    data = text(period, 20000) + (per * (700000 // period + 1))[:700000] + text(period + 1, 30000) + (per2 * (650000 // len(per2) + 1))[:650000]
+    for tail in (text(period + 2, 9000), b""):
+        d = data + tail
+        c, p = _prof(lz, d)
+        assert c == oracle.lzss_compress_mt(d, 4096, oracle.host_cores(), 4096)
+        assert lz.Decompress(c) == d
+        if _chain_mode() and not any(os.environ.get(k) for k in ("RSN_LZSS_NO_FUSED_PARSE", "RSN_LZSS_NO_STRETCH")):
+            assert "lzss_chain_stretch" in p
+            # (a last match that runs to the very end of the stream can jump over the final partial tile: that tile has no chain
+            #  position to enter on, the joint cannot be judged and the general parse takes over -- exact, but not what is tested here)
+            if tail:
+                assert "lzss_parse_mark" not in p, sorted(p)
+
+
 def test_match_table_against_oracle(lz, oracle):
     """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
     data = text(21, 50000)
