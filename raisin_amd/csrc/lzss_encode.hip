@@ -1386,10 +1386,20 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
     const TileChain c = live ? tc[k] : TileChain{0, 0, 1u, 0};
     bool ok = c.walked == 1 || (c.walked == 2 && c.pad == 1);           // walked, or periodic and placed by k_chain_periodic
     if (ok && live) {
+        // (A last match that runs to the very end of the stream can jump over the final, partial tile: that tile then holds no chain
+        //  position at all -- its parse reports no entry, or one beyond the stream, and flagged nothing -- and is in order as it is.)
+        const bool over = c.exit != 0xFFFFFFFFu && c.exit >= E;           // this tile's chain leaves the stream
+        const bool empty = c.walked == 1 && (c.entry == 0xFFFFFFFFu || c.entry >= E);
         if (k == 0) ok = c.entry == 0;
-        if (k + 1 < n_tiles) { const TileChain nx = tc[k + 1]; ok = ok && (nx.walked == 1 || (nx.walked == 2 && nx.pad == 1)) && c.exit == nx.entry && (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile && (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile; }
-        else ok = ok && c.exit >= E && c.exit != 0xFFFFFFFFu;
-        ok = ok && c.entry != 0xFFFFFFFFu;
+        if (k + 1 < n_tiles) {
+            const TileChain nx = tc[k + 1];
+            if (over) ok = ok && k + 2 == n_tiles && nx.walked == 1 && (nx.entry == 0xFFFFFFFFu || nx.entry >= E) && c.entry != 0xFFFFFFFFu;
+            else ok = ok && (nx.walked == 1 || (nx.walked == 2 && nx.pad == 1)) && c.exit == nx.entry && (unsigned long long)c.exit < (unsigned long long)(k + 2) * tile &&
+                      (unsigned long long)c.exit >= (unsigned long long)(k + 1) * tile && c.entry != 0xFFFFFFFFu;
+        } else if (empty && k > 0) {
+            const TileChain q = tc[k - 1];
+            ok = (q.walked == 1 || (q.walked == 2 && q.pad == 1)) && q.exit != 0xFFFFFFFFu && q.exit >= E;
+        } else ok = ok && over && c.entry != 0xFFFFFFFFu;
     }
     // bad[0]: tiles that gave up (dense / heavy), bad[1]: chains that do not join, bad[2]: periodic tiles that could not be placed,
     // bad[3]: length of the list for a second look (one atomic per wavefront and class: config 3's first look fails 131071 times)
