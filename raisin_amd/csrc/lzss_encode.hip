@@ -1050,15 +1050,18 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     {   // Every visit of this tile a match over its whole distance, and the same distance d: the stretch repeats with a period that d is
         // the largest multiple of inside the window, every chain in it steps by d and keeps its phase -- the chains of neighbouring tiles
         // never join.  The tile says so (step = d): k_stretch_pred then places the true chain by arithmetic and the next look walks it.
-        uint32_t cl = 0;
-        for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
-        for (int dd = 32; dd; dd >>= 1) cl += __shfl_down(cl, dd);
-        if (lane == 0) s_part[wv] = cl;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t all = 0;
-            for (int k = 0; k < CTH / 64; k++) all += s_part[k];
-            T.step[bx] = (s_nstep == all && all != 0 && s_stepmin == s_stepmax) ? s_stepmin : 0u;
+        if (s_nstep == 0 || s_stepmin != s_stepmax) { if (tid == 0) T.step[bx] = 0; }   // (text: no such visit at all -- nothing to count)
+        else {
+            uint32_t cl = 0;
+            for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
+            for (int dd = 32; dd; dd >>= 1) cl += __shfl_down(cl, dd);
+            if (lane == 0) s_part[wv] = cl;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t all = 0;
+                for (int k = 0; k < CTH / 64; k++) all += s_part[k];
+                T.step[bx] = s_nstep == all ? s_stepmin : 0u;
+            }
         }
     }
 
