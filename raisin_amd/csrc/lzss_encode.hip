@@ -751,7 +751,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     // the tile.  A partial launch takes it from a list (k_chain_verify's: the tiles that gave up as "dense", and -- top bit set -- the tiles
     // whose warm-up chain had not merged with the true chain by the time it entered them: those start from the tile before's exit instead)
     const uint32_t list_entry = (a.redo & 2u) ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;
-    const uint32_t bx = list_entry & 0x7FFFFFFFu;
+    const uint32_t bx = list_entry & 0x3FFFFFFFu;                         // (bit 31: walk from redo_start; bit 30: that chain alone, see nitems)
     const long long t0 = (long long)bx * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
@@ -832,7 +832,9 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     const uint32_t kp_end = CH + npos;                                    // a chain stops when it leaves the tile
     uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                       // the warm-up start (CH in tile 0: the true start)
     if (list_entry >> 31) kp_first = chain_tail().redo_start[blockIdx.x] - (uint32_t)(t0 - CH);   // the true entry as k_chain_verify worked it out: the tile before's exit, or a whole-distance stretch's arithmetic
-    const uint32_t nitems = 1 + (npos + CS - 1) / CS;
+    // (a tile of a whole-distance stretch walked from its predicted entry: the chain is two or three visits long, and the other 64
+    //  starts would each verify a 4 KiB match for nothing -- should the prediction be wrong, the one chain walks the tile alone)
+    const uint32_t nitems = (list_entry & 0x40000000u) ? 1u : 1 + (npos + CS - 1) / CS;
     // a wavefront that gives up (s_heavy) also pushes the start counter past every item: the others
     // finish the chain they are on (at most CS-odd positions) and find nothing more to start
     constexpr uint32_t GIVE_UP = 0x40000000u;
@@ -1434,7 +1436,7 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
         uint32_t at = 0;
         if ((threadIdx.x & 63) == 0) at = atomicAdd(&bad[3], (uint32_t)__builtin_popcountll(ml));
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__builtin_popcountll(ml & ((1ull << (threadIdx.x & 63)) - 1ull));
-        if ((gave || fix) && at < redo_cap) { redo_list[at] = gave ? k : (k | 0x80000000u); redo_start[at] = start; }
+        if ((gave || fix) && at < redo_cap) { redo_list[at] = gave ? k : (k | 0x80000000u | (predicted ? 0x40000000u : 0u)); redo_start[at] = start; }
     }
 }
 
@@ -1991,7 +1993,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 uint32_t hl[4], hs[4];
                 RSN_HIP(hipMemcpy(hl, d_redo_list, nl * 4, hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(hs, d_redo_start, nl * 4, hipMemcpyDeviceToHost));
                 for (uint32_t q = 0; q < nl; q++) {
-                    const uint32_t k = hl[q] & 0x7FFFFFFFu, k0 = k ? k - 1 : 0;
+                    const uint32_t k = hl[q] & 0x3FFFFFFFu, k0 = k ? k - 1 : 0;
                     TileChain tcs[3] = {}; uint32_t st[3] = {}, pd[3] = {};
                     const uint32_t cnt = std::min<uint32_t>(3, n_pt - k0);
                     RSN_HIP(hipMemcpy(tcs, d_tchain + k0, cnt * sizeof(TileChain), hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(st, d_step + k0, cnt * 4, hipMemcpyDeviceToHost));
