@@ -1385,7 +1385,7 @@ __global__ void k_sample_tiles(uint32_t *__restrict__ list, uint32_t n, uint32_t
 }
 
 __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tiles, uint32_t E, uint32_t tile, uint32_t *__restrict__ bad,
-                               uint32_t *__restrict__ redo_list, uint32_t redo_cap, uint32_t *__restrict__ redo_start, const uint32_t *__restrict__ pred) {
+                               uint32_t *__restrict__ redo_list, uint32_t redo_cap, uint32_t *__restrict__ redo_start, const uint32_t *__restrict__ pred, uint32_t list_gave) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = k < n_tiles;
     const TileChain c = live ? tc[k] : TileChain{0, 0, 1u, 0};
@@ -1418,10 +1418,10 @@ __global__ void k_chain_verify(const TileChain *__restrict__ tc, uint32_t n_tile
     // is not the exit of the (resolved) tile before it -- its warm-up chain had not merged with the true chain yet -- is walked again
     // from that exit; a tile of a whole-distance stretch (pred, see k_stretch_pred) from the arithmetic entry -- or not at all if it
     // is on that phase already, whatever the tile before it says.  bad[4] counts the entries of the last kind.
-    const bool gave = live && cls == 0;
+    const bool gave = live && cls == 0 && list_gave;                       // (not listed when too many of them gave up for a look: those are the bucket search's)
     uint32_t start = 0xFFFFFFFFu;
     bool predicted = false;
-    if (live && !gave && c.walked == 1 && k > 0) {
+    if (live && c.walked == 1 && k > 0) {
         const TileChain q = tc[k - 1];
         if ((q.walked == 1 || q.pad == 1) && q.entry != 0xFFFFFFFFu && q.exit != c.entry && (unsigned long long)q.exit >= (unsigned long long)k * tile &&
             (unsigned long long)q.exit < (unsigned long long)(k + 1) * tile && q.exit < E) start = q.exit;
@@ -1919,6 +1919,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
         uint32_t *d_prev_part = (uint32_t *)pp;
+        bool list_gave = true;                                                    // tiles that gave up are on the look's list (until there are too many of them)
         auto resolve = [&](bool second, bool with_pred) -> int {                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
             static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switches: the in-tile parse by pointer doubling in LDS,
@@ -1950,7 +1951,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 RSN_LAUNCH("lzss_chain_stretch", k_stretch_pred, tg, dim3(256), 0, s, d_tchain, d_step, d_hbrk, n_pt, (uint32_t)PT, E, d_pred);
             }
             RSN_LAUNCH("lzss_chain_verify", k_chain_verify, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, d_tchain, n_pt, E, (uint32_t)PT, (uint32_t *)(d_ttot + 1), d_redo_list, redo_cap,
-                       d_redo_start, (const uint32_t *)(with_pred ? d_pred : nullptr));
+                       d_redo_start, (const uint32_t *)(with_pred ? d_pred : nullptr), list_gave ? 1u : 0u);
             rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(h64, d_ttot, 32, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
@@ -1972,7 +1973,11 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         // true chain placed through them by arithmetic, and the look walks every tile of a stretch from its predicted entry.
         static const bool no_pred = getenv("RSN_LZSS_NO_STRETCH") != nullptr;   // A/B switch
         bool use_pred = false;
-        if (!parsed && !no_fused && !no_pred && (uint32_t)(h64[1] >> 32) > 64 && (uint32_t)h64[1] <= gave_cap) {   // (with more tiles given up than a look takes, none follows)
+        // (With more tiles given up than a look takes -- sections of noise -- the stream ends in the general parse whatever happens; the
+        //  looks still mend the joints and place the stretches of the rest, so that the parse finds the chain on evaluated positions
+        //  there and does not send those strips to the bucket search and the sweep as well.)
+        list_gave = (uint32_t)h64[1] <= gave_cap;
+        if (!parsed && !no_fused && !no_pred && (uint32_t)(h64[1] >> 32) > 64) {
             use_pred = true;
             rc = resolve(true, true); if (rc) return rc;
             if (dbg) fprintf(stderr, "lzss chain walk, stretches placed: list of %u tiles, %u of them by arithmetic\n", (uint32_t)(h64[2] >> 32), (uint32_t)h64[3]);
@@ -1981,7 +1986,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         for (int look = 2; look <= (use_pred ? 7 : 4) && !parsed && !no_fused; look++) {   // (a stretch is placed in the look after the one that mends the tile before it)
             const uint32_t n_list = (uint32_t)(h64[2] >> 32), n_gave = (uint32_t)h64[1], n_arith = use_pred ? (uint32_t)h64[3] : 0u;
             const uint32_t n_plain = n_list - std::min(n_list, n_arith);         // entries that are not placed by arithmetic: tiles that gave up, joints to mend
-            if (n_list == 0 || n_list > redo_cap || n_gave > gave_cap || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
+            if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
             prev_plain = n_plain;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
             RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(n_list), dim3(CC::CTH), 0, s, ha);
