@@ -262,6 +262,21 @@ def test_whole_distance_stretches_placed_by_arithmetic(lz, oracle, period):
             assert "lzss_chain_stretch" in p and "lzss_parse_mark" not in p, sorted(p)
 
 
+def test_noise_sections_do_not_keep_the_looks_from_the_rest(lz, oracle):
+    """More tiles give up as dense (two sections of noise) than a look takes: the stream ends in the general parse, but the
+    joints and the whole-distance stretch of the other sections are still mended and placed first.  Oracle's bytes."""
+    rng = np.random.default_rng(99)
+    noise = rng.integers(0, 256, size=560000, dtype=np.uint8).tobytes()
+    per = rng.integers(97, 123, size=7, dtype=np.uint8).tobytes()
+    runs = np.repeat(rng.integers(97, 101, size=300000 // 37 + 1, dtype=np.uint8), 37)[:300000].tobytes()
+    data = text(1, 30000) + noise[:280000] + (per * 90000)[:600000] + text(2, 20000) + noise[280000:] + runs + text(3, 10000)
+    c, p = _prof(lz, data)
+    assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
+    assert lz.Decompress(c) == data
+    if _chain_mode() and not any(os.environ.get(k) for k in ("RSN_LZSS_NO_FUSED_PARSE", "RSN_LZSS_NO_STRETCH")):
+        assert "lzss_chain_stretch" in p and p["lzss_match_chain"][0] >= 2, sorted(p)
+
+
 def test_match_table_against_oracle(lz, oracle):
     """Chain-independent check: the oracle's greedy parse only ever looks at chain positions."""
     data = text(21, 50000)
