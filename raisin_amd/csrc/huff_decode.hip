@@ -658,6 +658,13 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const auto t0 = now();
     if (!parse_header(head.data(), sep, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
     const auto t1 = now();
+    if (!d_out) {   // the size query, answered from the header alone (before any tree is built): every symbol as often as the header says,
+                    // which is what a stream this library wrote decodes to
+        size_t expect = 0;
+        for (const HuffSym &sy : syms) expect += (size_t)sy.freq * (size_t)utf8_len(sy.rune);
+        *out_n = round_up(expect, 16) + 16;
+        return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes by the header's counts", expect);
+    }
     HuffTree tree; HuffCodes codes;
     if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
     const auto t2 = now();

@@ -149,8 +149,17 @@ def decompress_tensor(src, out=None, stream=None):
     import torch
     n = src.numel()
     st = _own_stream(src, stream)
+    if out is None and n < (1 << 20):
+        out = torch.empty(8 * n + (1 << 16), dtype=torch.uint8, device=src.device)   # small: a generous guess costs less than a second call
     if out is None:
-        out = torch.empty(8 * n + (1 << 16), dtype=torch.uint8, device=src.device)
+        # the size query first (d_out NULL): a guess of the expansion would be a buffer of many times the input, held by the view returned
+        try:
+            need = _lib.call_dev(_lib.lib().rsn_huffman_decompress_dev, src.data_ptr(), n, None, 0, st)
+        except _lib.RsnError as e:
+            if e.code != _lib.RSN_ERR_CAPACITY:
+                raise
+            need = e.needed
+        out = torch.empty(max(need, 16), dtype=torch.uint8, device=src.device)
     try:
         got = _lib.call_dev(_lib.lib().rsn_huffman_decompress_dev, src.data_ptr(), n, out.data_ptr(), out.numel(), st)
     except _lib.RsnError as e:
