@@ -42,6 +42,30 @@ def test_no_cpu_fallback(built):
         assert e.value.code == -4 and "no CPU fallback" in str(e.value)
 
 
+def test_batch_entry_point_checks_its_arguments_before_any_device(built):
+    """rsn_huffman_compress_batch: null arrays and an empty chunk are refused before a device is looked for (an empty
+    chunk as the single call refuses it, huffman.go:102); with good arguments and no device it fails like the single call,
+    and every outs[i] is NULL either way."""
+    import ctypes
+    import torch
+    from raisin_amd import _lib
+    L = _lib.lib()
+    k = 3
+    bufs = [b"abc" * 10, b"", b"xyz" * 5]
+    ins = (ctypes.c_char_p * k)(*bufs)
+    lens = (ctypes.c_size_t * k)(*[len(b) for b in bufs])
+    outs = (ctypes.POINTER(ctypes.c_uint8) * k)()
+    olens = (ctypes.c_size_t * k)()
+    assert L.rsn_huffman_compress_batch(k, None, lens, outs, olens) == -1
+    assert L.rsn_huffman_compress_batch(k, ins, lens, outs, olens) == -2 and b"empty" in L.rsn_last_error()
+    assert all(not outs[i] for i in range(k)) and all(olens[i] == 0 for i in range(k))
+    if not torch.cuda.is_available():
+        lens[1] = 1
+        ins[1] = b"q"
+        assert L.rsn_huffman_compress_batch(k, ins, lens, outs, olens) == -4 and b"no CPU fallback" in L.rsn_last_error()
+        assert all(not outs[i] for i in range(k))
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "raisin_amd")):
         for f in files:
