@@ -225,6 +225,25 @@ def test_threaded_baseline_is_the_oracle(oracle, samiam):
     assert oracle.lzss_compress_mt(samiam, 0, 4, 64) == oracle.lzss_compress(samiam, 0)
 
 
+def test_oracle_forms_agree_on_low_entropy_shapes(oracle):
+    """The GPU tests of runs, short periods and long copies check against the threaded every-position form; here it is held
+    against the lazy single-thread form and, on short prefixes, the literal all-positions form -- three formulations of
+    lzss.go:109-184 on the shapes where a longest match is thousands of bytes and ties are everywhere."""
+    rng = random.Random(77)
+    per3, per7, per1000 = (bytes(rng.randrange(97, 123) for _ in range(p)) for p in (3, 7, 1000))
+    blk = bytes(rng.randrange(97, 123) for _ in range(1500))
+    runs = b"".join(bytes([rng.randrange(97, 101)]) * 37 for _ in range(1200))
+    shapes = [b"\x00" * 11000, (per3 * 9000)[:10000] + b"tail", b"head " + (per7 * 4000)[:10000], (per1000 * 30)[:11000], runs[:12000],
+              b"".join(blk[:300 + 200 * i] + bytes([65 + i]) + bytes(rng.randrange(97, 123) for _ in range(50)) for i in range(6)),
+              bytes(range(256)) * 40]
+    for d in shapes:
+        for w in (4096, 700):
+            ref = oracle.lzss_compress(d, w)
+            assert oracle.lzss_compress_mt(d, w, 8, 512) == ref
+            assert oracle.lzss_decompress(ref) == d
+        assert oracle.lzss_compress_allpos(d[:2500]) == oracle.lzss_compress(d[:2500])
+
+
 def test_workload_generators():
     """workloads.py: splitmix64 as published, prefix-stable, and inside the alphabets BASELINE.md 3 names."""
     import numpy as np
