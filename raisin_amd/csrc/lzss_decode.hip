@@ -874,6 +874,10 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (h64[0] >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
+    if (!d_out) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens
+        *out_n = round_up((size_t)E, 16) + 16;
+        return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %u bytes", E);
+    }
     static const bool no_plain = getenv("RSN_LZSS_DEC_UNESCAPE") != nullptr;   // A/B switch: always the separate unescape passes
     const bool plain = hflag[4] == 0 && !no_plain;                      // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
     rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
