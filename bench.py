@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: BASELINE.json configs[1] (config 5's per-GPU chunk when --gpus > 1).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its N ranks itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Timed workload (per GPU): `-algorithm=huffman` on a 1 GiB uniform-random buffer (config "2a": bytes uniform
 over 0x00..0x7F so that the reference's rune-level Huffman is lossless; splitmix64 seed 0x5EED0002, rank r
@@ -36,20 +37,30 @@ TRACE_NAME = {"huff_emit": "k_emit_flat", "huff_dec_flat": "k_dec_flat", "huff_b
 
 
 def load_traffic(prof_name):
-    """HBM bytes per launch of one kernel from the newest committed PMC profile (scripts/profile.sh + summarize_prof.py:
-    FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, separate passes): a constant of that profile, not a
-    measurement of this run."""
+    """HBM bytes per launch of one headline kernel from the newest committed PMC summary of the HEADLINE workload
+    (profiles/<tag>_pmc_headline.json: scripts/profile.sh <tag> headline + summarize_prof.py -- FETCH_SIZE doubled per the gfx950
+    note + WRITE_SIZE, separate passes, the kernel's largest launch): a constant of that profile, not a measurement of this run;
+    the file's name is reported next to it."""
     import glob
     want = TRACE_NAME.get(prof_name)
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_headline.json"))):
         try:
             d = json.load(open(p))
         except Exception:
             continue
         for k, v in d.items():
-            if want and k.startswith(want):
-                best = v
+            if want and k.startswith(want) and isinstance(v, dict) and v.get("hbm_max"):
+                best = (v["hbm_max"], os.path.basename(p))
+    if best is None:                                     # the older summaries (r01/r02: one mean per kernel name)
+        for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+            try:
+                d = json.load(open(p))
+            except Exception:
+                continue
+            for k, v in d.items():
+                if want and k.startswith(want):
+                    best = (v, os.path.basename(p))
     return best
 
 
@@ -272,6 +283,24 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher's parent -- it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a CHILD (one rank per GPU over RCCL), lets the
+    child's stdout (rank 0's JSON line) through and returns its exit code.  Nothing here imports torch or touches the GPU: a process
+    that has initialised the GPU must never be replaced or re-exec'ed on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,13 +313,15 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))            # plain `python bench.py --gpus N`: start the N ranks ourselves (nothing has touched the GPU yet)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        print("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); for N > 1 run under "
-              "`python -m torch.distributed.run --nproc-per-node N`" % (args.gpus, world), file=sys.stderr)
+        print("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     dist = None
     if world > 1:
@@ -299,6 +330,10 @@ def main():
             local_rank = 0                       # test mode: every rank drives GPU 0, collectives run on host tensors
             dist.init_process_group("gloo")
         else:
+            if local_rank >= torch.cuda.device_count():
+                print("bench.py: rank %d has no GPU of its own (%d visible): one rank per GPU; `--dist-backend gloo` shares GPU 0 "
+                      "for a control-flow check" % (local_rank, torch.cuda.device_count()), file=sys.stderr)
+                sys.exit(2)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
@@ -413,7 +448,8 @@ def main():
         traffic = load_traffic(dom)
         roofline = {
             "kernel": dom, "bound": "hbm", "achieved": round(alg[dom] / per[dom] / 1e6, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(alg[dom] / per[dom] / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(alg[dom] / per[dom] / 1e6 / HBM_PEAK_GBPS, 4), "traffic": traffic[0] if traffic else None,
+            "traffic_source": ("profiles/" + traffic[1]) if traffic else None, "algorithmic_bytes": alg[dom],
         }
         enc_ms = t_enc / K * 1e3
         dec_ms = (elapsed - t_enc) / K * 1e3

@@ -1,4 +1,5 @@
 //go:build rsn
+// +build rsn
 
 // Overlay for go-compression/raisin compressor/huffman: Compress/Decompress backed by librsn
 // (include/rsn.h).  Build tags select whole FILES, and huffman.go also defines Writer, Reader,
@@ -37,11 +38,18 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 		panic("librsn: " + C.GoString(C.rsn_last_error())) // the reference panics via check(e)
 	}
 	defer C.rsn_free(unsafe.Pointer(out))
-	// Not C.GoBytes: its length is a C.int, and results reach 2 GiB and more (librsn takes 5 GiB
-	// Huffman calls).  unsafe.Slice takes an int (64-bit here); Go >= 1.17.
+	// Not C.GoBytes (its length is a C.int: results reach 2 GiB and more, librsn takes 5 GiB Huffman calls) and not
+	// unsafe.Slice (Go >= 1.17; the reference's go.mod says `go 1.15`, under which it is a compile error whatever the
+	// toolchain): the C block is viewed through the classic array-pointer conversion, at most 1 GiB at a time.
 	res := make([]byte, int(n))
-	if n > 0 {
-		copy(res, unsafe.Slice((*byte)(unsafe.Pointer(out)), int(n)))
+	const view = 1 << 30
+	for off := 0; off < int(n); off += view {
+		m := int(n) - off
+		if m > view {
+			m = view
+		}
+		src := (*[view]byte)(unsafe.Pointer(uintptr(unsafe.Pointer(out)) + uintptr(off)))[:m:m]
+		copy(res[off:], src)
 	}
 	return res
 }

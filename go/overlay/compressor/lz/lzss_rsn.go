@@ -1,4 +1,5 @@
 //go:build rsn
+// +build rsn
 
 // Overlay for go-compression/raisin compressor/lz: CompressAsync / Compress / Decompress backed by
 // librsn (include/rsn.h).  lzss.go also defines Writer, Reader, NewWriter, NewWriterLevel,
@@ -38,9 +39,18 @@ func rsnCall(in []byte, f func(p *C.uint8_t, n C.size_t, out **C.uint8_t, outN *
 		panic("librsn: " + C.GoString(C.rsn_last_error()))
 	}
 	defer C.rsn_free(unsafe.Pointer(out))
-	res := make([]byte, int(n)) // not C.GoBytes: C.int truncates results of 2 GiB and more
-	if n > 0 {
-		copy(res, unsafe.Slice((*byte)(unsafe.Pointer(out)), int(n)))
+	// Not C.GoBytes (its length is a C.int: results reach 2 GiB and more) and not unsafe.Slice (Go >= 1.17; the
+	// reference's go.mod says `go 1.15`, under which it is a compile error whatever the toolchain): the C block is
+	// viewed through the classic array-pointer conversion, at most 1 GiB at a time.
+	res := make([]byte, int(n))
+	const view = 1 << 30
+	for off := 0; off < int(n); off += view {
+		m := int(n) - off
+		if m > view {
+			m = view
+		}
+		src := (*[view]byte)(unsafe.Pointer(uintptr(unsafe.Pointer(out)) + uintptr(off)))[:m:m]
+		copy(res[off:], src)
 	}
 	return res
 }

@@ -40,7 +40,8 @@ extern "C" {
 #define RSN_LZSS_DEFAULT_WINDOW 4096 /* lzss.go:35 DefaultWindowSize */
 
 /* ---- library / device ------------------------------------------------- */
-/* Select the HIP device used by the calling thread (default 0). */
+/* Select the HIP device used by the calling thread.  A thread that never calls this uses device 0,
+ * or what RSN_DEVICE says: a number, or "rr" = new thread contexts take the visible devices in turn. */
 int rsn_device_set(int device);
 /* Number of visible HIP devices, or a negative error. */
 int rsn_device_count(void);
@@ -66,6 +67,9 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
  * search buffer (lzss.go:125).  The progress-bar argument has no equivalent. */
 int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
 /* replaces lz.Compress([]byte, bool, int) []byte      lzss.go:224 -- the older synchronous encoder.
+ * FOR SMALL INPUTS ONLY: it is the reference's O(n * window) loop (O(n^2) for window <= 0) on the calling
+ * thread; inputs above 64 MiB (above 1 MiB for window <= 0 or > 65536) return RSN_ERR_LIMIT instead of
+ * blocking a cgo call for hours (RSN_LEGACY_NO_LIMIT=1 lifts the bound).
  * Not on the .rsn path (the engine calls CompressAsync) and not accelerated: a host-side
  * restatement for API completeness, quirks included (every-second-byte FindReverse :425-431,
  * offsets computed from the unsliced buffer :249-257, `<=` token threshold :272).  Needs no device. */
@@ -74,9 +78,13 @@ int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_
 int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 
 /* Batch form for independent chunks (one .rsn segment per chunk, as
- * engine.CompressFiles produces one file per input, engine.go:150-154): chunk k+1's
- * upload, chunk k's encode and chunk k-1's download run at once.  Each outs[i] equals
- * what rsn_huffman_compress() returns for ins[i]; on any error every outs[i] is NULL. */
+ * engine.CompressFiles produces one file per input, engine.go:150-154).  The chunks are
+ * dealt out over the visible devices -- chunk k -> worker k mod G, worker w on device
+ * (calling thread's device + w) mod G, G = rsn_device_count() capped by RSN_BATCH_DEVICES --
+ * and on each device chunk k+1's upload, chunk k's encode and chunk k-1's download run at
+ * once.  Nothing is exchanged between devices.  Each outs[i] equals what
+ * rsn_huffman_compress() returns for ins[i]; on any error every outs[i] is NULL.
+ * (RSN_BATCH_WORKERS, RSN_BATCH_LANES, RSN_BATCH_KEEP_MIB: see rsn_api.hip / INTEGRATION.md.) */
 int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
                                uint8_t **outs, size_t *out_lens);
 

@@ -15,6 +15,12 @@
  *                    position ranges handed to the threads (grain 1 = one task per position, the
  *                    goroutine-per-byte form), then the serial compaction of lzss.go:134-151
  *   LZSS decode      serial, as the reference (lzss.go:323-364)
+ *   LZSS check       "is this candidate stream the oracle's output?" at sizes where producing that output takes minutes:
+ *                    the candidate is cut right after tokens (a position right after a token lies on the greedy chain if
+ *                    the token's start does), every segment is re-encoded by the oracle's own loop from its start, and must
+ *                    reproduce the candidate's bytes AND land exactly on the next segment's start -- by induction from
+ *                    position 0 the candidate then equals rsn_oracle_lzss_compress()'s output byte for byte.  Only chain
+ *                    positions are evaluated (a fifth of all on text) and segments are independent: 1 GiB in seconds.
  * Inputs with bytes >= 0x80 (rune != byte) fall back to the single-threaded oracle.
  */
 #include <pthread.h>
@@ -29,6 +35,7 @@ int rsn_oracle_huffman_parse(const uint8_t *in, size_t n, size_t *payload_off, u
                              uint32_t **rune, int32_t *root, uint32_t *n_nodes);
 int rsn_oracle_lzss_matches_range(const uint8_t *esc, size_t e, int64_t window, size_t lo, size_t hi, uint32_t *off, uint32_t *size);
 int rsn_oracle_lzss_compact(const uint8_t *esc, size_t e, const uint32_t *off, const uint32_t *size, uint8_t **out, size_t *out_n);
+int rsn_oracle_lzss_compress_range(const uint8_t *esc, size_t e, int64_t window, size_t start, size_t stop, uint8_t **out, size_t *out_n, size_t *landed);
 
 typedef void (*job_fn)(void *ctx, int t, int nt);
 typedef struct { job_fn fn; void *ctx; int t, nt; } job_t;
@@ -211,5 +218,57 @@ int rsn_baseline_lzss_compress_mt(const uint8_t *in, size_t n, int64_t window, i
     run_threads(lz_worker, &z, threads < 1 ? 1 : threads);
     const int rc = rsn_oracle_lzss_compact(esc, e, z.off, z.size, out, out_n);
     free(z.off); free(z.size); rsn_oracle_free(esc);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ LZSS check (see the header comment) */
+typedef struct { size_t c0, f0; } cut_t;
+typedef struct { const uint8_t *esc; size_t e; int64_t window; const uint8_t *cand; size_t cand_n; const cut_t *cuts; size_t n_cuts; _Atomic size_t next; _Atomic size_t bad; } lzc_t;
+static void lzc_worker(void *c, int t, int nt) {
+    lzc_t *z = c; (void)t; (void)nt;
+    for (;;) {
+        const size_t k = atomic_fetch_add(&z->next, 1);
+        if (k + 1 >= z->n_cuts) break;
+        const cut_t a = z->cuts[k], b = z->cuts[k + 1];
+        uint8_t *o; size_t on, landed;
+        rsn_oracle_lzss_compress_range(z->esc, z->e, z->window, a.f0, b.f0, &o, &on, &landed);
+        const int ok = landed == b.f0 && on == b.c0 - a.c0 && memcmp(o, z->cand + a.c0, on) == 0;
+        rsn_oracle_free(o);
+        if (!ok) { size_t cur = atomic_load(&z->bad); while (a.c0 < cur && !atomic_compare_exchange_weak(&z->bad, &cur, a.c0)) {} }
+    }
+}
+/* 0 = `cand` is exactly the oracle's CompressAsync output for `in`; 1 = it is not (*bad_at = candidate offset of the first
+ * segment that differs, or cand_n if the candidate does not even parse to the escaped length).  seg = escaped bytes per segment. */
+int rsn_baseline_lzss_check(const uint8_t *in, size_t n, int64_t window, int threads, size_t seg, const uint8_t *cand, size_t cand_n, size_t *bad_at) {
+    uint8_t *esc; size_t e;
+    if (rsn_oracle_lzss_escape(in, n, &esc, &e)) return RSN_ORACLE_ERR;
+    if (!seg) seg = 1u << 18;
+    size_t cap = e / seg + 4, nc = 0;
+    cut_t *cuts = malloc(cap * sizeof *cuts);
+    cuts[nc++] = (cut_t){0, 0};
+    size_t f = 0, i = 0; int okparse = 1;
+    while (i < cand_n) {                                             /* lzss.go:323-364's state machine, positions only */
+        if (cand[i] != '<') { f++; i++; continue; }
+        size_t j = i + 1; unsigned long long off = 0, len = 0; int d1 = 0, d2 = 0;
+        while (j < cand_n && cand[j] >= '0' && cand[j] <= '9' && d1 < 19) { off = off * 10 + (cand[j] - '0'); j++; d1++; }
+        if (j >= cand_n || cand[j] != ',' || !d1) { okparse = 0; break; }
+        j++;
+        while (j < cand_n && cand[j] >= '0' && cand[j] <= '9' && d2 < 19) { len = len * 10 + (cand[j] - '0'); j++; d2++; }
+        if (j >= cand_n || cand[j] != '>' || !d2) { okparse = 0; break; }
+        (void)off;
+        f += (size_t)len; i = j + 1;
+        if (f - cuts[nc - 1].f0 >= seg && i < cand_n) { if (nc + 2 > cap) { cap *= 2; cuts = realloc(cuts, cap * sizeof *cuts); } cuts[nc++] = (cut_t){i, f}; }
+    }
+    int rc = 0;
+    if (!okparse || f != e) { *bad_at = cand_n; rc = 1; }
+    else {
+        cuts[nc++] = (cut_t){cand_n, e};
+        lzc_t z; memset(&z, 0, sizeof z);
+        z.esc = esc; z.e = e; z.window = window; z.cand = cand; z.cand_n = cand_n; z.cuts = cuts; z.n_cuts = nc;
+        atomic_store(&z.bad, (size_t)-1);
+        run_threads(lzc_worker, &z, threads < 1 ? 1 : threads);
+        if (atomic_load(&z.bad) != (size_t)-1) { *bad_at = atomic_load(&z.bad); rc = 1; }
+    }
+    free(cuts); rsn_oracle_free(esc);
     return rc;
 }

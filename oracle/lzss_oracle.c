@@ -106,6 +106,21 @@ int rsn_oracle_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_
     *out = o.p; *out_n = o.n; return RSN_ORACLE_OK;
 }
 
+/* The same greedy loop (lzss.go:134-151) over the ESCAPED stream from position `start` until it first lands at or beyond
+ * `stop`: the output of that stretch and where it landed.  If `start` lies on the chain of the whole stream, these are the
+ * whole stream's bytes for the stretch -- the unit of work of rsn_baseline_lzss_check (oracle/cpu_baseline.c). */
+int rsn_oracle_lzss_compress_range(const uint8_t *esc, size_t e, int64_t window, size_t start, size_t stop, uint8_t **out, size_t *out_n, size_t *landed) {
+    buf_t o = {0};
+    size_t i = start;
+    while (i < e && i < stop) {
+        size_t off, size; match_at(esc, e, i, window, &off, &size);
+        compact_emit(&o, esc, i, off, size);
+        i += size ? size : 1;
+    }
+    if (!o.p) o.p = malloc(1);
+    *out = o.p; *out_n = o.n; *landed = i; return RSN_ORACLE_OK;
+}
+
 /* positions [lo, hi) only: the unit of work of oracle/cpu_baseline.c's threads */
 int rsn_oracle_lzss_matches_range(const uint8_t *esc, size_t e, int64_t window, size_t lo, size_t hi, uint32_t *off, uint32_t *size) {
     for (size_t i = lo; i < hi && i < e; i++) { size_t o, s; match_at(esc, e, i, window, &o, &s); off[i] = (uint32_t)o; size[i] = (uint32_t)s; }

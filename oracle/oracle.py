@@ -62,6 +62,9 @@ def lib():
             f.restype = ctypes.c_int
         L.rsn_baseline_lzss_compress_mt.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, outp, szp]
         L.rsn_baseline_lzss_compress_mt.restype = ctypes.c_int
+        L.rsn_baseline_lzss_check.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t,
+                                              ctypes.c_char_p, ctypes.c_size_t, szp]
+        L.rsn_baseline_lzss_check.restype = ctypes.c_int
         L.rsn_oracle_lzss_matches.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -132,6 +135,18 @@ def huffman_decompress_mt(data, threads):
 def lzss_compress_mt(data, window=4096, threads=1, grain=4096):
     """grain = positions per task; 1 = one task per position, the reference's goroutine-per-byte shape (lzss.go:117-130)."""
     return _call(lib().rsn_baseline_lzss_compress_mt, data, window, int(threads), int(grain))
+
+
+def lzss_check(data, candidate, window=4096, threads=None, seg=1 << 18):
+    """True iff `candidate` is byte for byte lzss_compress(data, window) -- decided by induction over segments cut after the
+    candidate's tokens, each re-encoded by the oracle's own greedy loop on its own thread (oracle/cpu_baseline.c): what makes
+    an oracle-exact comparison affordable at 1 GiB.  Returns (ok, offset of the first differing segment in `candidate`)."""
+    bad = ctypes.c_size_t(0)
+    data, candidate = bytes(data), bytes(candidate)
+    rc = lib().rsn_baseline_lzss_check(data, len(data), window, int(threads or host_cores()), int(seg), candidate, len(candidate), ctypes.byref(bad))
+    if rc < 0:
+        raise OracleError(lib().rsn_oracle_last_error().decode("utf-8", "replace"))
+    return rc == 0, bad.value
 
 
 def lzss_matches(escaped, window=4096):

@@ -87,6 +87,11 @@ int rsn_baseline_huffman_decompress_mt(const uint8_t *in, size_t n, int threads,
 /* grain = positions per task (1 = one task per position, lzss.go:117-130) */
 int rsn_baseline_lzss_compress_mt(const uint8_t *in, size_t n, int64_t window, int threads, size_t grain, uint8_t **out, size_t *out_n);
 
+/* Is `cand` byte for byte what rsn_oracle_lzss_compress(in, n, window) returns?  Decided without producing that output
+ * serially: by induction over segments cut right after the candidate's tokens, each re-encoded by the oracle's own greedy
+ * loop (cpu_baseline.c).  Returns 0 = identical, 1 = not (*bad_at = candidate offset of the first differing segment). */
+int rsn_baseline_lzss_check(const uint8_t *in, size_t n, int64_t window, int threads, size_t seg, const uint8_t *cand, size_t cand_n, size_t *bad_at);
+
 void rsn_oracle_free(void *p);
 const char *rsn_oracle_last_error(void);
 

@@ -658,12 +658,34 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const auto t0 = now();
     if (!parse_header(head.data(), sep, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
     const auto t1 = now();
+    const size_t sn = n - sep - 2;                       // bytes after the separator
+    const unsigned diff = sn ? head[sep + 2] : 0;         // byteArr[0] (huffman.go:275)
+    const unsigned long long nbits = sn ? (unsigned long long)(sn - 1) * 8 : 0;
+    if (diff > nbits) return c.fail(RSN_ERR_FORMAT, "huffman: pad exceeds the payload (reference: slice bounds out of range, huffman.go:294)");
+    const unsigned long long max = nbits - diff;
     if (!d_out) {   // the size query, answered from the header alone (before any tree is built): every symbol as often as the header says,
-                    // which is what a stream this library wrote decodes to
-        size_t expect = 0;
-        for (const HuffSym &sy : syms) expect += (size_t)sy.freq * (size_t)utf8_len(sy.rune);
-        *out_n = round_up(expect, 16) + 16;
-        return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes by the header's counts", expect);
+                    // which is what a stream this library wrote decodes to.  The cheap format checks come first, so that a malformed
+                    // stream is refused here and not only on the call that follows, and the sum cannot wrap: with two symbols and more
+                    // every one takes at least a bit of the payload, so counts that add up to more than the payload has bits (a foreign
+                    // header; parse_header saturates a count at 2^63-1) are answered by the payload's own bound, not by exabytes.
+        if (syms.empty()) return c.fail(RSN_ERR_FORMAT, "huffman: empty header (reference panics in heap.Pop, huffman.go:102)");
+        if (syms.size() == 1) {
+            if (max > 0) return c.fail(RSN_ERR_FORMAT, "huffman: single-symbol tree with a non-empty payload (reference recurses without end, huffman.go:139-140)");
+            *out_n = 32;
+            return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %d bytes by the header's counts", utf8_len(syms[0].rune));
+        }
+        if (max == 0) return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
+        unsigned long long total = 0, expect = 0;
+        bool beyond = false;                                    // the header counts more symbols than the payload has bits: a foreign stream
+        for (const HuffSym &sy : syms) {                        // (the counts only shape the tree, huffman.go:196-227 -- still decodable)
+            if (sy.freq > max - total) { beyond = true; break; }
+            total += sy.freq;
+            expect += sy.freq * (unsigned long long)utf8_len(sy.rune);     // <= 4 * max: cannot wrap
+        }
+        if (beyond) expect = 4 * max;                           // what the payload can decode to at most: a bit per symbol, four bytes per rune
+        *out_n = round_up((size_t)expect, 16) + 16;
+        return c.fail(RSN_ERR_CAPACITY, beyond ? "huffman: output needs at most %llu bytes (the header counts more symbols than the payload holds)"
+                                               : "huffman: output needs %llu bytes by the header's counts", expect);
     }
     HuffTree tree; HuffCodes codes;
     if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
@@ -682,12 +704,6 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (!codes_ok) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
     const auto t3 = now();
     if (host_timing) fprintf(stderr, "huffman decode host: header of %zu bytes parsed in %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n", sep, ms(t0, t1), ms(t1, t2), ms(t2, t3), syms.size());
-
-    const size_t sn = n - sep - 2;                       // bytes after the separator
-    const unsigned diff = sn ? head[sep + 2] : 0;         // byteArr[0] (huffman.go:275)
-    const unsigned long long nbits = sn ? (unsigned long long)(sn - 1) * 8 : 0;
-    if (diff > nbits) return c.fail(RSN_ERR_FORMAT, "huffman: pad exceeds the payload (reference: slice bounds out of range, huffman.go:294)");
-    const unsigned long long max = nbits - diff;
 
     if (tree.n_leaves == 1) {                             // bare-leaf tree (huffman.go:136-143)
         if (max > 0) return c.fail(RSN_ERR_FORMAT, "huffman: single-symbol tree with a non-empty payload (reference recurses without end, huffman.go:139-140)");

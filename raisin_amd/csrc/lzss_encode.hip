@@ -982,7 +982,9 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
                         uint32_t mm = Lp;                                     // the first byte in which the farthest long candidate differs
                         for (uint32_t k = lane; k < Lp && mm == Lp; k += 64) if (a.fc[(size_t)u_ipos + k] != a.fc[(size_t)u_ipos - long_far + k]) mm = k;
                         mm = ~wave_max_u32(~mm);
-                        if (mm == Lp) best = (Lp << 16) | long_far;
+                        // (a maximum, not an assignment: where the END OF THE STREAM binds -- Lp = capE < long_far -- a candidate farther back
+                        //  that is not "long" may match all capE bytes too; `best` then already holds its exact key and the leftmost wins)
+                        if (mm == Lp) best = max(best, (Lp << 16) | long_far);
                         else {
                             // It stops after mm bytes (the end of a periodic stretch: all its candidates stop there).  Another candidate
                             // does better only if it is more than mm back AND agrees with the position in byte mm -- those that stop at

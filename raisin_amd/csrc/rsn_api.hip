@@ -30,6 +30,42 @@ struct Parked {
 };
 std::mutex g_park_mu;
 std::vector<Parked> *g_parked = nullptr;      // heap-allocated and never destroyed: still valid while other threads unwind at exit
+
+void release_parked(Parked &pk) {              // (HIP calls: only from a live thread, never from a thread-exit destructor)
+    if (hipSetDevice(pk.device) != hipSuccess) return;
+    for (auto &b : pk.bufs) if (b.p) (void)hipFree(b.p);
+    if (pk.pinned) (void)hipHostFree(pk.pinned);
+    for (auto e : pk.events) (void)hipEventDestroy(e);
+    if (pk.stream) (void)hipStreamDestroy(pk.stream);
+}
+
+// A storm of short-lived caller threads (a Go runtime under load retires and creates OS threads) must not leave an unbounded
+// number of parked scratch arenas in HBM: beyond RSN_MAX_PARKED (default 8) the OLDEST ones are released by the next thread
+// that initialises a context.
+size_t max_parked() { static const size_t v = getenv("RSN_MAX_PARKED") ? (size_t)std::max(0, atoi(getenv("RSN_MAX_PARKED"))) : 8; return v; }
+
+void trim_parked_excess(int restore_device) {
+    std::vector<Parked> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        if (!g_parked) return;
+        while (g_parked->size() > max_parked()) { victims.push_back(std::move(g_parked->front())); g_parked->erase(g_parked->begin()); }
+    }
+    if (victims.empty()) return;
+    for (auto &pk : victims) release_parked(pk);
+    (void)hipSetDevice(restore_device);
+}
+
+// The device of a thread that never called rsn_device_set(): 0, or RSN_DEVICE=<n>; RSN_DEVICE=rr hands the visible devices
+// out round-robin, one per new thread context -- how a Go host whose goroutines land on different OS threads
+// (runtime.LockOSThread in the shim) spreads its concurrent calls over the GPUs of a node without any API of its own.
+std::atomic<unsigned> g_rr{0};
+int default_device(int cnt) {
+    const char *e = getenv("RSN_DEVICE");
+    if (!e || !*e) return 0;
+    if (!strcmp(e, "rr") || !strcmp(e, "all")) return (int)(g_rr.fetch_add(1) % (unsigned)cnt);
+    return atoi(e);
+}
 }  // namespace
 
 Ctx::~Ctx() {
@@ -54,8 +90,10 @@ int ctx_init(Ctx &c) {
     hipError_t e = hipGetDeviceCount(&cnt);
     if (e != hipSuccess || cnt <= 0)
         return c.fail(RSN_ERR_DEVICE, "no HIP device available (%s); librsn has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-    if (c.device >= cnt) return c.fail(RSN_ERR_DEVICE, "device %d out of range (%d visible)", c.device, cnt);
+    if (!c.device_chosen) { c.device = default_device(cnt); c.device_chosen = true; }
+    if (c.device < 0 || c.device >= cnt) return c.fail(RSN_ERR_DEVICE, "device %d out of range (%d visible)", c.device, cnt);
     RSN_HIP(hipSetDevice(c.device));
+    trim_parked_excess(c.device);
     {
         std::lock_guard<std::mutex> lk(g_park_mu);
         if (g_parked)
@@ -246,6 +284,7 @@ int rsn_device_set(int device) {
         c.inited = false;
     }
     c.device = device;
+    c.device_chosen = true;
     return ctx_init(c);
 }
 
@@ -272,13 +311,7 @@ void rsn_trim(void) {
         std::lock_guard<std::mutex> lk(g_park_mu);
         if (g_parked) parked.swap(*g_parked);
     }
-    for (auto &pk : parked) {
-        if (hipSetDevice(pk.device) != hipSuccess) continue;
-        for (auto &b : pk.bufs) if (b.p) (void)hipFree(b.p);
-        if (pk.pinned) (void)hipHostFree(pk.pinned);
-        for (auto e : pk.events) (void)hipEventDestroy(e);
-        if (pk.stream) (void)hipStreamDestroy(pk.stream);
-    }
+    for (auto &pk : parked) release_parked(pk);
     if (c.inited) (void)hipSetDevice(c.device);
     std::vector<std::pair<size_t, void *>> pool;
     {
@@ -351,6 +384,13 @@ int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_
     Ctx &c = ctx();
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
+    {   // an O(n * W) serial loop that cannot be interrupted from Go: refuse what would run for hours (rsn.h)
+        static const bool no_limit = getenv("RSN_LEGACY_NO_LIMIT") != nullptr;
+        const size_t bound = (window <= 0 || window > 65536) ? ((size_t)1 << 20) : ((size_t)64 << 20);
+        if (!no_limit && n > bound)
+            return c.fail(RSN_ERR_LIMIT, "lz.Compress (legacy, host code): %zu bytes with window %lld is above the %zu-byte bound of this serial O(n*W) path; "
+                          "use rsn_lzss_compress (CompressAsync), or set RSN_LEGACY_NO_LIMIT=1", n, (long long)window, bound);
+    }
     std::string res;
     lzss_compress_legacy_host(in, n, window, res);
     uint8_t *buf = (uint8_t *)result_alloc(res.size());
@@ -369,11 +409,19 @@ int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
 
 // Independent chunks, one complete .rsn segment each (engine.CompressFiles: one file per input,
 // engine.go:150-154).  A single host call is PCIe-bound -- ~4.7 ms per 256 MiB each way against 0.3 ms
-// of kernels -- and PCIe is full duplex, so the batch is a three-stage pipeline over a ring of device
-// buffers: the caller's thread uploads chunk k+1 while a second thread encodes chunk k and a third copies
-// chunk k-1's segment down.  (Lanes that each run whole calls fall into step -- all uploading, then all
-// downloading -- and overlap little: 58.6 ms against the serial loop's 73.5 on 8 x 256 MiB, r02k.)
-// RSN_BATCH_LANES=1 gives the serial loop (A/B).
+// of kernels -- and PCIe is full duplex, so on ONE device the batch is a three-stage pipeline over a ring of
+// device buffers: one thread uploads chunk k+1 while a second encodes chunk k and a third copies chunk k-1's
+// segment down.  (Lanes that each run whole calls fall into step -- all uploading, then all downloading -- and
+// overlap little: 58.6 ms against the serial loop's 73.5 on 8 x 256 MiB, r02k.)
+// On a node with several GPUs the chunks are dealt out first: chunk k -> worker k mod G, worker w on device
+// (caller's device + w) mod visible devices, every worker its own pipeline and its own PCIe link; results land in the
+// caller's host arrays, so there is nothing to exchange between devices (no data-path collective).
+//   RSN_BATCH_DEVICES=<d>  use at most d devices (default: all visible)
+//   RSN_BATCH_WORKERS=<w>  number of pipelines (default: one per device used); more workers than devices share
+//                          devices round-robin -- how the split is exercised on a one-GPU box
+//   RSN_BATCH_LANES=1      no pipeline: each worker is a serial loop of rsn_huffman_compress calls (A/B; any other value = pipeline)
+//   RSN_BATCH_KEEP_MIB=<m> ring buffers above m MiB per worker (default 1024) are released when the batch ends instead of
+//                          staying with the worker's (parked) context for the next batch
 namespace {
 struct BatchPipe {
     enum { RING = 3 };
@@ -387,32 +435,24 @@ struct BatchPipe {
     bool wait(const size_t &counter, size_t want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return rc != RSN_OK || counter >= want; }); return rc == RSN_OK; }
     void done(size_t &counter) { { std::lock_guard<std::mutex> lk(mu); counter++; } cv.notify_all(); }
 };
-}  // namespace
 
-int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
-    Ctx &c = ctx();
-    if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
-    for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
-    size_t max_len = 0;
-    for (size_t i = 0; i < n_chunks; i++) {
-        if (!ins[i] && lens[i]) return c.fail(RSN_ERR_ARG, "null argument");
-        if (lens[i] == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
-        max_len = std::max(max_len, lens[i]);
-    }
-    int rc0 = ctx_init(c); if (rc0) return rc0;
-    static const int lanes_env = getenv("RSN_BATCH_LANES") ? atoi(getenv("RSN_BATCH_LANES")) : 3;
-    auto undo = [&](int rc, const char *msg) {
-        for (size_t k = 0; k < n_chunks; k++) { if (outs[k]) rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; }
-        return c.fail(rc, "%s", msg);
-    };
-    if (lanes_env == 1 || n_chunks < 2) {
-        for (size_t i = 0; i < n_chunks; i++) {
+int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+
+// The chunks `idx` through one device's pipeline, on the calling thread's context (already initialised on its device).
+// On failure the chunks this worker has produced stay in outs[] for the caller to undo; the message is in c.err.
+int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+    const size_t m = idx.size();
+    if (m == 0) return RSN_OK;
+    if (env_int("RSN_BATCH_LANES", 3) == 1 || m < 2) {
+        for (size_t j = 0; j < m; j++) {
+            const size_t i = idx[j];
             const int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
-            if (rc != RSN_OK) { const std::string m = rsn_last_error(); return undo(rc, m.c_str()); }
+            if (rc != RSN_OK) return rc;
         }
         return RSN_OK;
     }
-
+    size_t max_len = 0;
+    for (size_t i : idx) max_len = std::max(max_len, lens[i]);
     BatchPipe P;
     const size_t in_cap = round_up(max_len, 16) + 64, out_cap = max_len + max_len / 8 + (1 << 16);   // typical outputs are < n; a chunk that needs more gets its own block
     for (int r = 0; r < BatchPipe::RING; r++) {
@@ -426,9 +466,10 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
     std::thread encoder([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(RSN_ERR_DEVICE, rsn_last_error()); return; }
         Ctx &ce = ctx(); hipStream_t s = ce.own_stream;
-        for (size_t i = 0; i < n_chunks; i++) {
-            if (!P.wait(P.uploaded, i + 1)) return;
-            const int r = (int)(i % BatchPipe::RING);
+        for (size_t j = 0; j < m; j++) {
+            if (!P.wait(P.uploaded, j + 1)) return;
+            const size_t i = idx[j];
+            const int r = (int)(j % BatchPipe::RING);
             size_t got = 0;
             int rc = huff_encode_dev(ce, s, (const uint8_t *)P.d_in[r], lens[i], (uint8_t *)P.d_out[r], out_cap, &got, nullptr, nullptr);
             if (rc == RSN_ERR_CAPACITY && got > out_cap) {
@@ -438,16 +479,17 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
             if (rc == RSN_OK && hipStreamSynchronize(s) != hipSuccess) { rc = RSN_ERR_DEVICE; ce.fail(rc, "hipStreamSynchronize after encode failed"); }
             if (rc != RSN_OK) { P.fail(rc, rsn_last_error()); return; }
             P.got[r] = got;
-            if (timing) fprintf(stderr, "batch chunk %zu encoded at %.2f ms\n", i, stamp());
+            if (timing) fprintf(stderr, "batch dev %d chunk %zu encoded at %.2f ms\n", device, i, stamp());
             P.done(P.encoded);
         }
     });
     std::thread downloader([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(RSN_ERR_DEVICE, rsn_last_error()); return; }
         hipStream_t s = ctx().own_stream;
-        for (size_t i = 0; i < n_chunks; i++) {
-            if (!P.wait(P.encoded, i + 1)) return;
-            const int r = (int)(i % BatchPipe::RING);
+        for (size_t j = 0; j < m; j++) {
+            if (!P.wait(P.encoded, j + 1)) return;
+            const size_t i = idx[j];
+            const int r = (int)(j % BatchPipe::RING);
             const size_t got = P.got[r];
             uint8_t *res = (uint8_t *)result_alloc(got);
             if (!res) { P.fail(RSN_ERR_NOMEM, "allocating a result block failed"); return; }
@@ -456,26 +498,77 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (P.d_tmp[r]) { (void)hipFree(P.d_tmp[r]); P.d_tmp[r] = nullptr; }
             if (e != hipSuccess) { P.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); return; }
-            if (timing) fprintf(stderr, "batch chunk %zu down at %.2f ms\n", i, stamp());
+            if (timing) fprintf(stderr, "batch dev %d chunk %zu down at %.2f ms\n", device, i, stamp());
             P.done(P.downloaded);
         }
     });
-    // the caller's thread uploads
-    for (size_t i = 0; i < n_chunks; i++) {
-        if (i >= BatchPipe::RING && !P.wait(P.downloaded, i + 1 - BatchPipe::RING)) break;   // the ring slot is free once its segment is down
-        const int r = (int)(i % BatchPipe::RING);
+    // this thread uploads
+    for (size_t j = 0; j < m; j++) {
+        if (j >= BatchPipe::RING && !P.wait(P.downloaded, j + 1 - BatchPipe::RING)) break;   // the ring slot is free once its segment is down
+        const size_t i = idx[j];
+        const int r = (int)(j % BatchPipe::RING);
         hipStream_t s = c.own_stream;
         hipError_t e = hipMemsetAsync((uint8_t *)P.d_in[r] + (lens[i] & ~(size_t)15), 0, 64, s);
         if (e == hipSuccess) e = hipMemcpyAsync(P.d_in[r], ins[i], lens[i], hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { P.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); break; }
-        if (timing) fprintf(stderr, "batch chunk %zu up at %.2f ms\n", i, stamp());
+        if (timing) fprintf(stderr, "batch dev %d chunk %zu up at %.2f ms\n", device, i, stamp());
         P.done(P.uploaded);
     }
     encoder.join();
     downloader.join();
     for (int r = 0; r < BatchPipe::RING; r++) if (P.d_tmp[r]) (void)hipFree(P.d_tmp[r]);
-    if (P.rc != RSN_OK) return undo(P.rc, P.msg.c_str());
+    if ((in_cap + out_cap) * BatchPipe::RING > ((size_t)std::max(0, env_int("RSN_BATCH_KEEP_MIB", 1024)) << 20))
+        for (int k = 28; k < 28 + 2 * BatchPipe::RING; k++) { if (c.bufs[k].p) (void)hipFree(c.bufs[k].p); c.bufs[k].p = nullptr; c.bufs[k].cap = 0; }
+    if (P.rc != RSN_OK) return c.fail(P.rc, "%s", P.msg.c_str());
+    return RSN_OK;
+}
+}  // namespace
+
+int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+    Ctx &c = ctx();
+    if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
+    for (size_t i = 0; i < n_chunks; i++) {
+        if (!ins[i] && lens[i]) return c.fail(RSN_ERR_ARG, "null argument");
+        if (lens[i] == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    }
+    int rc0 = ctx_init(c); if (rc0) return rc0;
+    auto undo = [&](int rc, const char *msg) {
+        for (size_t k = 0; k < n_chunks; k++) { if (outs[k]) rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; }
+        return c.fail(rc, "%s", msg);
+    };
+    int visible = 1;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) visible = 1;
+    const int n_dev = std::max(1, std::min(visible, env_int("RSN_BATCH_DEVICES", visible)));
+    const size_t n_workers = std::min<size_t>((size_t)std::max(1, env_int("RSN_BATCH_WORKERS", n_dev)), std::max<size_t>(n_chunks, 1));
+    if (n_workers <= 1) {                                        // one device, one pipeline, on the caller's own context
+        std::vector<size_t> idx(n_chunks);
+        for (size_t i = 0; i < n_chunks; i++) idx[i] = i;
+        const int rc = batch_on_device(c, idx, ins, lens, outs, out_lens);
+        if (rc != RSN_OK) { const std::string m = c.err; return undo(rc, m.c_str()); }
+        return RSN_OK;
+    }
+    // chunk k -> worker k mod G; worker w -> device (caller's + w mod n_dev) mod visible
+    std::vector<int> rcs(n_workers, RSN_OK);
+    std::vector<std::string> msgs(n_workers);
+    std::vector<std::thread> workers;
+    const int base = c.device;
+    for (size_t w = 0; w < n_workers; w++)
+        workers.emplace_back([&, w] {
+            const int dev = (base + (int)(w % (size_t)n_dev)) % visible;
+            int rc = rsn_device_set(dev);
+            if (rc == RSN_OK) {
+                std::vector<size_t> idx;
+                for (size_t k = w; k < n_chunks; k += n_workers) idx.push_back(k);
+                rc = batch_on_device(ctx(), idx, ins, lens, outs, out_lens);
+            }
+            rcs[w] = rc;
+            if (rc != RSN_OK) msgs[w] = rsn_last_error();
+        });
+    for (auto &t : workers) t.join();
+    (void)hipSetDevice(c.device);
+    for (size_t w = 0; w < n_workers; w++) if (rcs[w] != RSN_OK) return undo(rcs[w], msgs[w].c_str());
     return RSN_OK;
 }
 

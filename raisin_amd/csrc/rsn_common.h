@@ -27,6 +27,7 @@ struct ProfSlot {
 // buffers and pinned staging.  Nothing here is shared between threads.
 struct Ctx {
     int device = 0;
+    bool device_chosen = false;     // by rsn_device_set(); otherwise the first call picks RSN_DEVICE's (rsn_api.hip)
     bool inited = false;
     hipStream_t own_stream = nullptr;
     std::string err;

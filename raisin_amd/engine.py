@@ -193,7 +193,9 @@ def BenchmarkSuite(files, algorithms, out=None, timeout=None):
     context per calling thread), the suite waits at most `timeout` (1 minute, :216,246, util.go:15)
     and every entry that has not delivered by then gets a ">1m0s" DNF row (:256-263) while its
     thread is left running.  Per file one table: header, finished rows in the reference's order,
-    failed rows as DNF, the File/Size footer.  Returns the flat list of results."""
+    failed rows as DNF, the File/Size footer.  Returns the flat list of results.
+    An entry that misses the deadline keeps running on its daemon thread -- like the reference's goroutine -- so it goes on
+    using the device (and holds its thread's scratch arena) while the next file is timed."""
     import sys
     import threading
     out = out or sys.stdout
@@ -208,7 +210,7 @@ def BenchmarkSuite(files, algorithms, out=None, timeout=None):
             print("Benchmarking", name, file=out)
             box = []
             slots[name] = box                                   # resultChans[algorithmsString] (:240): a repeated entry shares its slot
-            t = threading.Thread(target=lambda layer=layer, box=box: box.append(AsyncBenchmarkFile(layer, f)), daemon=True)
+            t = threading.Thread(target=lambda layer=layer, box=box, f=f: box.append(AsyncBenchmarkFile(layer, f)), daemon=True)
             t.start()
             threads.append(t)
         deadline = time.monotonic() + timeout                   # waitTimeout(&wg, timeout)

@@ -14,6 +14,26 @@ def Decompress(fileContents):
     return _lib.call_host(_lib.lib().rsn_huffman_decompress, fileContents)
 
 
+def CompressBatch(chunks):
+    """One complete .rsn segment per chunk, as engine.CompressFiles writes one file per input (engine.go:150-154):
+    rsn_huffman_compress_batch deals the chunks out over the visible GPUs (chunk k -> device k mod G) and pipelines
+    upload / encode / download per device.  Each result equals Compress(chunk)."""
+    import ctypes
+    L = _lib.lib()
+    chunks = [bytes(c) for c in chunks]
+    k = len(chunks)
+    ins = (ctypes.c_char_p * k)(*chunks)
+    lens = (ctypes.c_size_t * k)(*[len(c) for c in chunks])
+    outs = (ctypes.POINTER(ctypes.c_uint8) * k)()
+    olens = (ctypes.c_size_t * k)()
+    _lib.check(L.rsn_huffman_compress_batch(k, ins, lens, outs, olens))
+    try:
+        return [ctypes.string_at(outs[i], olens[i]) for i in range(k)]
+    finally:
+        for i in range(k):
+            L.rsn_free(outs[i])
+
+
 class Writer:
     """huffman.go:368-386: Write compresses the whole buffer once and returns len(compressed)."""
 

@@ -28,8 +28,39 @@ def test_abi_shim_compiles_and_host_only_part_runs(tmp_path):
 
 
 @pytest.mark.gpu
-def test_abi_shim_call_sequence(tmp_path):
+@pytest.mark.parametrize("env", [{}, {"RSN_BATCH_WORKERS": "3"}, {"RSN_BATCH_WORKERS": "2", "RSN_BATCH_LANES": "1"},
+                                 {"RSN_DEVICE": "rr", "RSN_MAX_PARKED": "1"}, {"RSN_BATCH_KEEP_MIB": "0", "RSN_BATCH_WORKERS": "8"}],
+                         ids=["default", "3 workers", "2 serial workers", "round-robin devices, 1 parked", "8 workers, ring released"])
+def test_abi_shim_call_sequence(tmp_path, env):
+    """The shim's call sequence, also with the batch split over several per-device workers (on a one-GPU box they share the
+    device: the dealing-out, the per-worker rings and the error path are the same code a multi-GPU node runs), with the default
+    device handed out round-robin and with the parked-context pool capped at one."""
     exe = _build(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "abi shim: ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_batch_split_over_workers_equals_single_calls(monkeypatch):
+    """rsn_huffman_compress_batch with chunk k -> worker k mod G (engine.go:150-154): every segment equals the single
+    call's, whatever the number of workers/devices, ragged chunk sizes, byte and rune alphabets mixed."""
+    import numpy as np
+
+    from raisin_amd import _lib, huffman
+    rng = np.random.default_rng(5)
+    chunks = [rng.integers(0, 128, size=200000 + 33333 * i, dtype=np.uint8).tobytes() for i in range(7)]
+    chunks[3] = ("\u0416\u0443\u043a " * 40000).encode()          # a rune-path chunk between byte chunks
+    chunks.append(b"z")                                          # single-symbol chunk
+    single = [huffman.Compress(c) for c in chunks]
+    for workers in ("1", "2", "3", "8", "64"):
+        monkeypatch.setenv("RSN_BATCH_WORKERS", workers)
+        assert huffman.CompressBatch(chunks) == single, workers
+    monkeypatch.delenv("RSN_BATCH_WORKERS")
+    monkeypatch.setenv("RSN_BATCH_DEVICES", "1")
+    assert huffman.CompressBatch(chunks) == single
+    assert _lib.lib().rsn_device_count() >= 1
+    # an error in one worker's chunk undoes the whole batch
+    monkeypatch.setenv("RSN_BATCH_WORKERS", "3")
+    with pytest.raises(_lib.RsnError):
+        huffman.CompressBatch(chunks[:4] + [b""] + chunks[4:])

@@ -131,6 +131,109 @@ def test_config5_eight_chunks_on_one_gpu(oracle):
     assert len(set(sizes)) > 1 or len(sizes) == 8                   # different seeds, independent segments
 
 
+def _oracle_says_identical(oracle, host, got, what):
+    ok, bad = oracle.lzss_check(host, got)
+    assert ok, "%s: differs from the oracle's CompressAsync output in the segment at compressed offset %d" % (what, bad)
+
+
+def test_lzss_oracle_exact_where_the_code_changes_path(oracle):
+    """the LZSS encoder switches path by size with the DEFAULT thresholds -- the 64-tile sample from 8192 tiles
+    (64 MiB), one lane per tile in the in-tile parse from 32768 tiles (256 MiB), decode groups of n_tiles/512 above 32 MiB -- and a
+    round trip cannot tell a different valid parse from the reference's.  288 MiB of config 4's text and 288 MiB of mixed
+    text / noise / periodic sections, default switches, bytes == the oracle's: by the segment induction of
+    oracle.lzss_check (every segment re-encoded by the oracle's own greedy loop), and against the threaded oracle's complete
+    output (lzss_compress_mt: a Reference for every position, lzss.go:117-151) where the host has the cores for it."""
+    import time
+
+    import torch
+    import workloads as W
+    from raisin_amd import lz
+    n = 288 << 20
+    text = W.config_input("4", n, "cuda")
+    got = lz.compress_tensor(text)
+    host, gb = bytes(text.cpu().numpy()), bytes(got.cpu().numpy())
+    _oracle_says_identical(oracle, host, gb, "config 4 text, 288 MiB")
+    back = lz.decompress_tensor(got)
+    assert back.numel() == n and torch.equal(back, text)
+    # the whole output from the every-position oracle, when a 4 MiB probe says it fits the budget (256 host threads: ~45 s)
+    cores = oracle.host_cores()
+    t0 = time.time()
+    oracle.lzss_compress_mt(host[:4 << 20], 4096, cores, 4096)
+    est = (time.time() - t0) * (n / (4 << 20))
+    if est < 240:
+        assert gb == oracle.lzss_compress_mt(host, 4096, cores, 4096)
+    else:
+        print("lzss_compress_mt at 288 MiB would take ~%.0f s on %d cores: segment induction only" % (est, cores))
+    del text, got, back
+    # mixed: 1 MiB sections of text, noise (all 256 values: escapes too), 4096-periodic data, runs, a period of 1000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    parts = []
+    tx = W.config_input("4", 96 << 20, "cuda")
+    per = W.config_input("3", 32 << 20, "cuda")
+    for k in range(288):
+        kind = k % 6
+        if kind in (0, 3):
+            parts.append(tx[(k // 3) << 20:((k // 3) + 1) << 20])
+        elif kind == 1:
+            parts.append(torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, device="cuda", generator=g))
+        elif kind == 2:
+            parts.append(per[(k % 32) << 20:((k % 32) + 1) << 20])
+        elif kind == 4:
+            parts.append(torch.randint(97, 101, ((1 << 20) // 37 + 1,), dtype=torch.uint8, device="cuda", generator=g).repeat_interleave(37)[:1 << 20])
+        else:
+            parts.append(torch.randint(32, 127, (1000,), dtype=torch.uint8, device="cuda", generator=g).repeat(1049)[:1 << 20])
+    mixed = torch.cat(parts)
+    del parts, tx, per
+    assert mixed.numel() == n
+    got = lz.compress_tensor(mixed)
+    _oracle_says_identical(oracle, bytes(mixed.cpu().numpy()), bytes(got.cpu().numpy()), "mixed sections, 288 MiB")
+    back = lz.decompress_tensor(got)
+    assert back.numel() == n and torch.equal(back, mixed)
+
+
+def test_lzss_1GiB_text_is_the_oracles_output_and_the_allpos_paths(oracle, tmp_path):
+    """Config 4's LZSS layer at the full 1 GiB: the default path's bytes are the oracle's (segment induction, every segment
+    re-encoded by the oracle's greedy loop -- seconds on the host's cores), and their sha256 equals that of the same call under
+    RSN_LZSS_ALLPOS=1 (the bucket search at EVERY position + the general parse: no chain walk, no sample, no looks) run in a
+    process of its own."""
+    import hashlib
+
+    import workloads as W
+    from raisin_amd import lz
+    src = W.config_input("4", GIB, "cuda")
+    got = bytes(lz.compress_tensor(src).cpu().numpy())
+    host = bytes(src.cpu().numpy())
+    del src
+    _oracle_says_identical(oracle, host, got, "config 4 text, 1 GiB")
+    del host
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import workloads as W\nfrom raisin_amd import lz\n"
+            "c = lz.compress_tensor(W.config_input('4', 1 << 30, 'cuda'))\n"
+            "print(hashlib.sha256(bytes(c.cpu().numpy())).hexdigest())\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, RSN_LZSS_ALLPOS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-1] == hashlib.sha256(got).hexdigest()
+
+
+@pytest.mark.parametrize("name", ["2a", "skewed"])
+def test_huffman_1GiB_byte_for_byte_against_the_threaded_oracle(oracle, name):
+    """Configs 2a (flat 7-bit code: k_emit_flat / k_dec_flat) and `skewed` (general kernels) at the full 1 GiB, every byte of
+    both directions against oracle/cpu_baseline.c's threaded restatement (same bytes as the plain oracle: tests/test_oracle.py)."""
+    import torch
+    import workloads as W
+    from raisin_amd import huffman
+    src = W.config_input(name, GIB, "cuda")
+    c = huffman.compress_tensor(src)
+    host = bytes(src.cpu().numpy())
+    cores = oracle.host_cores()
+    ref = oracle.huffman_compress_mt(host, cores)
+    assert bytes(c.cpu().numpy()) == ref
+    d = huffman.decompress_tensor(c)
+    assert d.numel() == GIB and torch.equal(d, src)
+    del d, c, src
+    assert oracle.huffman_decompress_mt(ref, cores) == host          # and the oracle's decode of those bytes is the input
+
+
 def test_bench_two_ranks_control_flow():
     """bench.py's world-size-2 path on one GPU (gloo collectives, both ranks on GPU 0)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -143,6 +246,19 @@ def test_bench_two_ranks_control_flow():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["lossless"] is True and j["scaling"] == "weak"
     assert j["config"]["chunks"] == 2 and "gather_ms" in j and j["value"] > 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it -- the way the driver calls it: bench.py starts the two ranks
+    itself (a child `torch.distributed.run`), forwards rank 0's line and the exit code (this used to exit 2)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--mib", "64", "--dist-backend", "gloo"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                               # ONE JSON line, rank 0's
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["lossless"] is True and j["config"]["chunks"] == 2 and j["value"] > 0
 
 
 def test_beyond_4GiB_offsets():

@@ -227,6 +227,25 @@ def test_long_matches_followed_through_memory(lz, oracle):
         assert lz.Decompress(c) == data, name
 
 
+def test_long_candidates_where_the_end_of_the_stream_binds(lz, oracle):
+    """A stream that ends in a run of zeros, an earlier zero run of 250..256 bytes inside the window, and the chain landing
+    250..256 bytes before the end: there the many candidates of the run are capped by the bytes LEFT, not by their distance, and
+    a candidate farther back than the farthest "long" one (the start of the earlier, shorter run) matches all of them too --
+    bytes.Index takes that leftmost occurrence (lzss.go:419).  ADVICE r2: the farthest-long-candidate rule used to overwrite it."""
+    rng = np.random.default_rng(77)
+    head = rng.integers(97, 123, size=3000, dtype=np.uint8).tobytes()
+    for run in (250, 252, 255, 256):
+        for k in (1, 2, 5):
+            for r in (0, 1, 3, 6, 8):
+                for gap in (b"q", b"q" + head[:700]):
+                    data = head + b"q" + b"\x00" * run + gap + b"\x00" * (256 * k + r)
+                    c = lz.CompressAsync(data)
+                    assert c == oracle.lzss_compress(data), (run, k, r, len(gap))
+    data = head + b"q" + b"\x00" * 256 + b"q" + b"\x00" * (256 * 40)
+    assert lz.CompressAsync(data) == oracle.lzss_compress(data)
+    assert lz.Decompress(lz.CompressAsync(data)) == data
+
+
 def test_joints_by_the_hundred_are_mended_by_one_look(lz, oracle):
     """Runs of 37 equal bytes from four letters: steps of 40 to 100 positions leave a tile's 128-position warm-up chain two or
     three steps to merge with the true chain, and a quarter of the joints fail.  The tile before's exit is right all the

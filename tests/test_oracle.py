@@ -275,3 +275,31 @@ def test_workload_generators():
     assert 0.2 < words.count(top) / len(words) < 0.35                            # p(1) = 1 / sum k^-1.3 = 0.27
     s = W.skewed_bytes(200000).numpy()
     assert s.min() >= 32 and s.max() <= 127 and np.bincount(s)[32] > 4 * np.bincount(s)[32 + 12] * 0.9
+
+
+def test_lzss_check_by_segments_is_an_equality_test(oracle):
+    """oracle.lzss_check (cpu_baseline.c): True exactly for the oracle's own output -- a stream that round-trips but
+    takes a nearer occurrence, a raw copy in place of a token, a truncated or extended stream are all refused."""
+    import random
+    rng = random.Random(3)
+    words = [bytes(rng.choice(b"abcdefghij") for _ in range(rng.randint(2, 8))) for _ in range(40)]
+    data = b" ".join(rng.choice(words) for _ in range(60000)) + b"<x\\y\xff" * 30
+    c = oracle.lzss_compress(data)
+    for seg in (1 << 10, 1 << 14, 1 << 30):
+        for th in (1, 3):
+            assert oracle.lzss_check(data, c, threads=th, seg=seg) == (True, 0)
+    assert oracle.lzss_check(b"", b"") == (True, 0)
+    assert not oracle.lzss_check(data, c[:-1])[0] and not oracle.lzss_check(data[:-1], c)[0]
+    a, b = "abcdefg1abcdefg2abcdefg3", "abcdefg1<8,7>2<16,7>3"      # SURVEY 8a: the farthest occurrence, not the nearest
+    assert oracle.lzss_compress(a.encode()) == b.encode()
+    assert oracle.lzss_check(a.encode(), b.encode())[0]
+    near = b"abcdefg1<8,7>2<8,7>3"
+    assert oracle.lzss_decompress(near) == a.encode() and not oracle.lzss_check(a.encode(), near)[0]
+    k = c.index(b"<", len(c) // 2)
+    j = c.index(b">", k)
+    off, ln = (int(x) for x in c[k + 1:j].split(b","))
+    raw = oracle.lzss_decompress(c[:k])                               # the escaped prefix, unescaped again...
+    esc = oracle.lzss_escape(data)
+    pos = len(oracle.lzss_escape(raw))
+    lit = c[:k] + esc[pos:pos + ln] + c[j + 1:]                       # the token's bytes written out raw: still decodes to data
+    assert oracle.lzss_decompress(lit) == data and not oracle.lzss_check(data, lit, seg=1 << 12)[0]
