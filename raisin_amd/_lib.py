@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsn.so")
+LIB_PATH = os.environ.get("RSN_LIB_PATH") or os.path.join(_HERE, "librsn.so")   # RSN_LIB_PATH: another BUILD of librsn (A/B of compile-time switches)
 
 RSN_OK = 0
 RSN_ERR_CAPACITY = -7

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
         constexpr int PER = (WORDS + DB - 1) / DB;
         uint32_t v[PER];
 #pragma unroll
-        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) v[k] = src[i]; }
+        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) v[k] = ld4<(RSN_NT_MASK & 8) != 0>(src + i); }
 #pragma unroll
         for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) s_data[swz(i)] = __builtin_bswap32(v[k]); }
     } else {
@@ -518,8 +518,8 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     }
     uint8_t *dst = a.out + s_first;
     if (s_first + FLAT_LANE_SYMS <= a.n_sym) {
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+        st16<(RSN_NT_MASK & 16) != 0>(reinterpret_cast<uint4 *>(dst), make_uint4(o[0], o[1], o[2], o[3]));
+        st16<(RSN_NT_MASK & 16) != 0>(reinterpret_cast<uint4 *>(dst + 16), make_uint4(o[4], o[5], o[6], o[7]));
     } else {
         const uint32_t cnt = (uint32_t)(a.n_sym - s_first);
         for (uint32_t k = 0; k < cnt; k++) dst[k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));

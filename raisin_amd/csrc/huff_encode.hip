@@ -74,7 +74,7 @@ __global__ __launch_bounds__(HB) void k_byte_hist(const uint8_t *__restrict__ in
             for (int k0 = 0; k0 < TB / ROUND; k0 += INFLIGHT) {
                 uint4 v[INFLIGHT];
 #pragma unroll
-                for (int k = 0; k < INFLIGHT; k++) v[k] = src[(k0 + k) * HB];
+                for (int k = 0; k < INFLIGHT; k++) v[k] = ld16<(RSN_NT_MASK & 1) != 0>(src + (k0 + k) * HB);
 #pragma unroll
                 for (int k = 0; k < INFLIGHT; k++) add16(v[k]);
             }
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
         uint32_t w[8];
         if (first + 32 <= a.n) {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.in + first);
-            const uint4 x = src[0], y = src[1];
+            const uint4 x = ld16<(RSN_NT_MASK & 2) != 0>(src), y = ld16<(RSN_NT_MASK & 2) != 0>(src + 1);
             w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
         } else {
 #pragma unroll
@@ -728,8 +728,7 @@ __global__ __launch_bounds__(HB) void k_emit_flat(FlatEmitArgs a) {
         for (int q = tid; q < HB * L / 4; q += HB) {
             const int i = 4 * q;                                   // 4 | 32: the four words never straddle a swizzle step
             const uint32_t *sp = s_o + i + (i >> 5);
-            struct __attribute__((packed, aligned(4))) W4 { uint32_t x, y, z, w; };
-            *reinterpret_cast<W4 *>(a.out_words + wbase + i) = W4{sp[0], sp[1], sp[2], sp[3]};
+            st16_a4<(RSN_NT_MASK & 4) != 0>(a.out_words + wbase + i, sp[0], sp[1], sp[2], sp[3]);
         }
     } else
     for (int i = tid; i < HB * L; i += HB) {

@@ -91,6 +91,41 @@ struct ProfScope {
         RSN_HIP(hipGetLastError());                                                                \
     } while (0)
 
+// Streaming (touched-once) global accesses as `nt` loads / stores.  Which of the headline kernels' streams use them is a
+// build-time A/B mask (Makefile: EXTRA=-DRSN_NT_MASK=<bits>, scripts/ab_nt.sh):
+//   1 k_byte_hist loads   2 k_emit_flat loads   4 k_emit_flat stores   8 k_dec_flat loads   16 k_dec_flat stores
+// Measured (r03, 1 GiB, step = encode + decode in a loop; gpurun_out/ab_nt*.txt): only bit 1 pays -- k_byte_hist
+// 0.231 -> 0.185 ms (5.8 TB/s) and the step 1.175 -> 1.137 ms.  The three kernels trade the write-back of the previous kernel's
+// dirty lines among themselves (nt stores in k_dec_flat: that kernel +0.05 ms, the histogram after it -0.035; nt loads in the
+// histogram: k_emit_flat +0.015 because the decoder's dirty lines are then still in the cache when it starts), so every other
+// bit moves time between kernels and loses a little in total; walking k_emit_flat's chunks from the end (to meet what the
+// histogram read last in the Infinity Cache) changed nothing.
+#ifndef RSN_NT_MASK
+#define RSN_NT_MASK 1
+#endif
+#ifdef __HIPCC__
+typedef uint32_t rsn_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t rsn_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const uint4 *p) {
+    if constexpr (NT) { const rsn_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const rsn_u32x4 *>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    else return *p;
+}
+template <bool NT> __device__ __forceinline__ uint32_t ld4(const uint32_t *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT> __device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
+    if constexpr (NT) { rsn_u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<rsn_u32x4 *>(p)); }
+    else *p = v;
+}
+// four dwords to an address that is only dword-aligned (global stores accept that)
+template <bool NT> __device__ __forceinline__ void st16_a4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c_, uint32_t d) {
+    rsn_u32x4_a4 x = {a, b, c_, d};
+    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<rsn_u32x4_a4 *>(p));
+    else *reinterpret_cast<rsn_u32x4_a4 *>(p) = x;
+}
+#endif
+
 static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 static inline size_t round_up(size_t a, size_t b) { return ceil_div(a, b) * b; }
 
