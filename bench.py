@@ -250,16 +250,38 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
 
     def chunks_on_one_gpu(k=8):
         """Config 5 as one GPU sees it: k independent chunks (seeds 0x5EED0050 + i), one complete .rsn segment each, encoded one
-        after the other (engine.CompressFiles' loop, engine.go:150-154); the multi-GPU form is `bench.py --gpus N`."""
-        srcs = [W.config_input("5", n, device, chunk=i) for i in range(k)]
-        outs = [torch.empty(n + n // 8 + (1 << 20), dtype=torch.uint8, device=device) for _ in range(k)]
+        after the other (engine.CompressFiles' loop, engine.go:150-154); the multi-GPU form is `bench.py --gpus N`.
+        Inputs and outputs are ONE allocation each, touched by two warm-up passes (r02: 16 separate 1 GiB blocks from torch's
+        caching allocator gave 5.6 ms on one box and 7.9 on the driver's); every chunk's time is reported."""
+        cap = n + n // 8 + (1 << 20)
+        cap = (cap + 255) & ~255
+        src_all = torch.empty(k * n, dtype=torch.uint8, device=device)
+        out_all = torch.empty(k * cap, dtype=torch.uint8, device=device)
+        srcs = [src_all[i * n:(i + 1) * n] for i in range(k)]
+        outs = [out_all[i * cap:(i + 1) * cap] for i in range(k)]
         for i in range(k):
-            huffman.compress_tensor(srcs[i], out=outs[i])
+            srcs[i].copy_(W.config_input("5", n, device, chunk=i))
+        for _ in range(2):
+            for i in range(k):
+                huffman.compress_tensor(srcs[i], out=outs[i])
         torch.cuda.synchronize(device)
-        reps, te = 2, 0.0
+        reps, te = 3, 0.0
+        per_chunk = [0.0] * k
+        passes = []
+        _lib.prof_enable(True)
+        _lib.prof_reset()
         for _ in range(reps):
-            segs, t = _timed(lambda: [huffman.compress_tensor(srcs[i], out=outs[i]) for i in range(k)])
-            te += t
+            t_pass = 0.0
+            segs = []
+            for i in range(k):
+                seg, t = _timed(lambda i=i: huffman.compress_tensor(srcs[i], out=outs[i]))
+                segs.append(seg)
+                per_chunk[i] += t
+                t_pass += t
+            passes.append(t_pass * 1e3)
+            te += t_pass
+        prof5 = _lib.prof_get()
+        _lib.prof_enable(False)
         te = te / reps * 1e3
         dec = torch.empty(n + (1 << 20), dtype=torch.uint8, device=device)
         ok = all(bool(torch.equal(huffman.decompress_tensor(segs[i], out=dec), srcs[i])) for i in range(k))   # every segment decodes on its own
@@ -267,8 +289,11 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
         out["5"] = {"algorithm": "huffman", "chunks": k, "bytes": k * n, "encode_ms": round(te, 3), "encode_MBps": round(k * n / 1e6 / (te / 1e3), 1),
                     "ratio_pct": round(100.0 * C / (k * n), 3), "lossless": ok,
                     "encode_frac_of_hbm_peak": round((2 * k * n + C) / (te / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
-                    "note": "one GPU, chunks one after the other; the sharded form with its gather is the --gpus N run"}
-        del srcs, outs, segs, dec
+                    "per_chunk_ms": [round(x / reps * 1e3, 4) for x in per_chunk], "pass_ms": [round(x, 3) for x in passes],
+                    "kernels_ms_per_chunk": {kk: round(v[1] / (reps * k), 4) for kk, v in sorted(prof5.items())},
+                    "note": "one GPU, chunks one after the other, wall time per call; one allocation for the 8 inputs and one for the 8 outputs, "
+                            "two warm-up passes; the sharded form with its gather is the --gpus N run"}
+        del srcs, outs, segs, dec, src_all, out_all
         torch.cuda.empty_cache()
 
     for name in names:

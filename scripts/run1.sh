@@ -1,6 +1,13 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(timeout 1500 python -m pytest tests/test_gpu_abi_shim.py tests/test_gpu_full_size.py "tests/test_gpu_lzss.py::test_long_candidates_where_the_end_of_the_stream_binds" tests/test_gpu_huffman_decode.py -m gpu -x -q --durations=12 2>&1 | tail -40) > gpurun_out/t1.log 2>&1
-tail -30 gpurun_out/t1.log
-(timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_r03a.json 2> gpurun_out/bench_r03a.err; echo rc=$?) 
-tail -c 1500 gpurun_out/bench_r03a.json
+(timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -25) > gpurun_out/t_full.log 2>&1
+tail -25 gpurun_out/t_full.log
+(timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_r03b.json 2> gpurun_out/bench_r03b.err; echo rc=$?)
+python - <<'PY'
+import json
+j=json.loads(open("gpurun_out/bench_r03b.json").read().strip().splitlines()[-1])
+print({k:j[k] for k in ("value","ms_per_step","encode_ms","decode_ms","roofline")})
+print({k:(v.get("ms"),v.get("frac_of_hbm_peak")) for k,v in j["kernels"].items()})
+for k,v in j["other_configs"].items():
+    print(k, {x:v.get(x) for x in ("encode_ms","decode_ms","lossless","bit_exact_vs_oracle_on_sample","per_chunk_ms","pass_ms","error")})
+PY
