@@ -1088,9 +1088,11 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
 // CAP = claimed positions the block has room for.  Two instantiations run back to back: CAP = half of all positions
 // (34 KB of LDS, four blocks per CU) resolves every ordinary tile; a tile with more claims than that -- a stretch of
 // one- and two-byte steps -- is left to the second, full-size one (64 KB), which returns at once everywhere else.
+constexpr uint32_t NO_LIST = 0xFFFFFFFFu;                            // ccnt[tile]: the tile has no compact key list (k_tok_emit reads its flags and keys)
 template <class C, int CAP>
 __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ dump, const uint32_t *__restrict__ keys, uint32_t E,
-                                                    TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+                                                    TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
+                                                    uint32_t *__restrict__ ccnt) {
     constexpr int CT = C::CT, CH = C::CH, NKP = CH + CT, NW = NKP / 32, TT = 512;
     constexpr uint32_t OUT = 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];
@@ -1184,6 +1186,7 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
         unsigned long long tb = 0;
         for (int k = 0; k < TT / 64; k++) tb += s_part[k];
         tile_bytes[blockIdx.x] = tb;
+        if (ccnt) ccnt[blockIdx.x] = NO_LIST;                             // (a list k_chain_serial may have left for an earlier walk of this tile is stale)
         // a tile the chain jumps over entirely cannot happen (L <= W <= 4096 < CT); a chain that ends inside the warm-up zone can (last tile)
         tchain[blockIdx.x] = TileChain{s_entry == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + s_entry, s_exit == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + s_exit, 1u, 0u};
     }
@@ -1196,9 +1199,13 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
 // on the scalar unit, which is what bounded k_chain_tail (0.76 of its roofline: loop and mask bookkeeping of sixteen rounds).
 // (Four lanes per tile, one per quarter with its own warm-up, measured slower -- 3.3 vs 2.95 ms: the kernel is bound by cache-line
 //  requests, not by the length of a lane's chain.)
+// The lane also leaves the keys it met inside the tile, in chain order, as a compact list (clist[tile * CT ..], ccnt[tile] entries): what
+// k_tok_emit needs of the 4 bytes per position of the key array is these -- one position in six on text -- and their positions follow
+// from the tile's entry by adding up max(1, L).
 template <class C>
 __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict__ keys, uint32_t E, uint32_t n_tiles, TileChain *__restrict__ tchain,
-                                                     uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes) {
+                                                     uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
+                                                     uint32_t *__restrict__ clist, uint32_t *__restrict__ ccnt) {
     constexpr uint32_t CT = C::CT, CH = C::CH, WORDS = CT / 32;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n_tiles) return;
@@ -1221,18 +1228,32 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
     while (p < t0) p += max(1u, key_at(p) >> 16);                         // the warm-up chain: merged with the true one long before the tile
     const unsigned long long entry = p;
     uint32_t *fw = flags + (size_t)k * WORDS;
-    uint32_t wi = 0, word = 0;
+    uint32_t *cl = clist ? clist + (size_t)k * CT : nullptr;
+    uint32_t wi = 0, word = 0, n_on = 0;
+    uint4 pend = {0, 0, 0, 0}, pend2 = {0, 0, 0, 0};
     unsigned long long bytes = 0;
     while (p < t1) {
         const uint32_t key = key_at(p), L = key >> 16, r = (uint32_t)(p - t0);
         while (wi < (r >> 5)) { fw[wi++] = word; word = 0; }              // (every word of the tile is written exactly once, in order)
         word |= 1u << (r & 31);
+        // (eight keys at a time, two 16-byte stores: a 4-byte store per step to 64 lanes' 64 different lines made this kernel three times
+        //  slower -- 5.7 against 1.9 ms per GiB of text; four at a time 2.6)
+        const uint32_t sl = n_on & 7u;
+        if (sl == 0) pend.x = key; else if (sl == 1) pend.y = key; else if (sl == 2) pend.z = key; else if (sl == 3) pend.w = key;
+        else if (sl == 4) pend2.x = key; else if (sl == 5) pend2.y = key; else if (sl == 6) pend2.z = key; else pend2.w = key;
+        n_on++;
+        if (cl && sl == 7) { *reinterpret_cast<uint4 *>(cl + n_on - 8) = pend; *reinterpret_cast<uint4 *>(cl + n_on - 4) = pend2; }
         const uint32_t el = enc_len(key & 0xFFFFu, L);
         bytes += L == 0 ? 1u : (el < L ? el : L);                         // token only if strictly shorter than the bytes it stands for (lzss.go:143)
         p += max(1u, L);
     }
     while (wi < WORDS) { fw[wi++] = word; word = 0; }
     tile_bytes[k] = bytes;
+    if (cl && (n_on & 7u)) {                                            // (the list has room for CT entries and n_on <= CT: a whole group of eight always fits)
+        *reinterpret_cast<uint4 *>(cl + (n_on & ~7u)) = pend;
+        if ((n_on & 7u) > 4) *reinterpret_cast<uint4 *>(cl + (n_on & ~7u) + 4) = pend2;
+    }
+    if (ccnt) ccnt[k] = n_on;
     tchain[k] = TileChain{(uint32_t)entry, (uint32_t)p, 1u, 0u};
 }
 
@@ -1681,17 +1702,79 @@ __device__ __forceinline__ uint8_t *put_dec(uint8_t *o, uint32_t v) {
     return o;
 }
 
+// Two forms per tile.  LIST: the tile's chain keys arrive as k_chain_serial's compact list (ccnt[tile] entries from clist[tile * PT]); positions
+// and output offsets are two running sums over it, literals and short raw copies come from the tile's staged bytes.  Per GiB of text that is
+// 0.6 GB of list + 1 GB of stream instead of 4.3 GB of keys + flags + 1 GB (profiles/r03a_pmc_config4.json: k_tok_emit fetched 5.6 GB).
+// FLAGS: the r02 form -- the tile's flag bitmap says which of its PT keys count -- for tiles without a list (W-periodic tiles, tiles resolved
+// by k_chain_tail, everything after the general parse).
 __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc, const uint32_t *__restrict__ keys, uint32_t E,
                                                  const uint32_t *__restrict__ flags, const unsigned long long *__restrict__ tile_off,
-                                                 uint8_t *__restrict__ out, const TileChain *__restrict__ tchain, uint32_t W) {
+                                                 uint8_t *__restrict__ out, const TileChain *__restrict__ tchain, uint32_t W,
+                                                 const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt) {
     constexpr int RP = LB * 16;                                    // positions per round
+    constexpr int LE = 4, LR = LB * LE;                            // list form: entries per lane and per round (a round emits at most 11 * LR bytes)
     __shared__ uint32_t wsum[LB / 64];
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[RP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_fc[RP + 16];   // a raw copy of a short match runs at most 10 bytes past the round
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[RP + 64];  // a round emits at most RP + 10 bytes
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[RP * 4 + (RP + 16) + (RP + 64)];
+    static_assert(sizeof(s_raw) >= (size_t)(PT + 32) + 11 * LR + 64, "the list form's stage and image fit the same memory");
+    uint32_t *s_keys = reinterpret_cast<uint32_t *>(s_raw);
+    uint8_t *s_fc = s_raw + RP * 4;                                  // a raw copy of a short match runs at most 10 bytes past the round
+    uint8_t *s_img = s_raw + RP * 4 + (RP + 16);                     // a round emits at most RP + 10 bytes
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t base = blockIdx.x * PT;
     unsigned long long run = tile_off[blockIdx.x];
+    const uint32_t n_list = ccnt ? ccnt[blockIdx.x] : NO_LIST;
+    if (n_list != NO_LIST) {
+        if (n_list == 0) return;                                    // (a last match can jump over the final partial tile)
+        uint8_t *l_fc = s_raw, *l_img = s_raw + PT + 32;            // the tile's bytes (+ 10 of the next); the round's output
+        for (int v = tid; v < (PT + 32) / 16; v += LB) {
+            const uint32_t p = base + 16 * v;
+            uint4 x = {0, 0, 0, 0};
+            if (p + 16 <= E) x = *reinterpret_cast<const uint4 *>(fc + p);
+            else if (p < E) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t k = 0; p + k < E; k++) w[k >> 2] |= (uint32_t)fc[p + k] << (8 * (k & 3)); x = {w[0], w[1], w[2], w[3]}; }
+            reinterpret_cast<uint4 *>(l_fc)[v] = x;
+        }
+        const uint32_t *cl = clist + (size_t)blockIdx.x * PT;
+        uint32_t pos0 = tchain[blockIdx.x].entry - base;            // tile-relative position of the round's first entry
+        for (uint32_t r0 = 0; r0 < n_list; r0 += LR) {
+            const uint32_t i0 = r0 + LE * tid;
+            uint32_t kk[LE] = {0, 0, 0, 0};
+            if (i0 + LE <= n_list) { const uint4 v = *reinterpret_cast<const uint4 *>(cl + i0); kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w; }
+            else for (int u = 0; u < LE; u++) if (i0 + u < n_list) kk[u] = cl[i0 + u];
+            uint32_t mine = 0;                                       // steps << 16 | bytes, summed over the lane's entries (a tile's steps add up to < PT + 4096)
+#pragma unroll
+            for (int u = 0; u < LE; u++) {
+                if (i0 + u >= n_list) break;
+                const uint32_t L = kk[u] >> 16, e = enc_len(kk[u] & 0xFFFF, L);
+                mine += (max(1u, L) << 16) | (L == 0 ? 1u : (e < L ? e : L));   // lzss.go:143
+            }
+            uint32_t incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();                                         // (the first round: the staged bytes are in place too)
+            uint32_t pre = 0, tot = 0;
+            for (int k = 0; k < LB / 64; k++) { if (k < wv) pre += wsum[k]; tot += wsum[k]; }
+            const uint32_t ex = pre + incl - mine;
+            uint8_t *dst = out + run;
+            const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
+            uint8_t *o = l_img + al + (ex & 0xFFFF);
+            uint32_t q = pos0 + (ex >> 16);
+#pragma unroll
+            for (int u = 0; u < LE; u++) {
+                if (i0 + u >= n_list) break;
+                const uint32_t L = kk[u] >> 16, off = kk[u] & 0xFFFF;
+                if (L == 0) { *o++ = l_fc[q]; q++; continue; }
+                if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
+                else for (uint32_t j = 0; j < L; j++) *o++ = l_fc[q + j];
+                q += L;
+            }
+            __syncthreads();
+            drain_block(l_img, al, tot & 0xFFFF, dst);
+            run += tot & 0xFFFF;
+            pos0 += tot >> 16;
+            __syncthreads();
+        }
+        return;
+    }
     const bool periodic = tchain && tchain[blockIdx.x].walked == 2;     // a W-periodic tile of the chain walk: its keys are arithmetic, not stored
     auto key_at = [&](uint32_t p) { return periodic ? (min(W, E - p) << 16) | W : keys[p]; };
     for (int r = 0; r < PT / RP; r++) {
@@ -1866,6 +1949,8 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     bool parsed = false;                                              // flags + tile offsets + total are final
     using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     uint8_t *d_dump = nullptr;
+    uint32_t *d_clist = nullptr, *d_ccnt = nullptr;
+    bool parsed_by_walk = false;                                      // the chain walk's own per-tile parse was accepted: its lists are valid
     uint32_t *d_redo_list = nullptr, *d_redo_start = nullptr, *d_step = nullptr, *d_sbrk = nullptr, *d_hbrk = nullptr, *d_pred = nullptr;
     const uint32_t redo_cap = n_pt + 64;                              // the list of a second look: every tile can be on it (and room for the sample below)
     const uint32_t gave_cap = std::max(64u, n_pt / 64);               // ... which is worth it while this many tiles at most gave up as dense / heavy: beyond, the bucket search is the tool
@@ -1917,6 +2002,16 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         }
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
+        // k_chain_serial's compact key lists (k_tok_emit's input where a tile has one): in the memory the general parse would use for its
+        // exits -- the lists are read only if that parse never runs.  RSN_LZSS_NO_LIST: always the flag form (A/B).
+        static const bool no_list = getenv("RSN_LZSS_NO_LIST") != nullptr;
+        if (!no_list) {
+            void *lp; rc = dev_buf(c, 11, std::max((size_t)E * 2, (size_t)n_pt * PT * 4) + 64, &lp); if (rc) return rc;
+            d_clist = (uint32_t *)lp;
+            rc = dev_buf(c, 27, (size_t)n_pt * 4 + 64, &lp); if (rc) return rc;
+            d_ccnt = (uint32_t *)lp;
+            RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 4, s));
+        }
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
@@ -1932,15 +2027,15 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             //  however few the tiles, the blocks take 17-23 ns per tile -- text: 0.29 against 0.96 ms at 64 MiB, 0.56 against 0.95
             //  at 127 MiB, level at 256 MiB, 3 against 1.9 ms at 1 GiB)
             if (doubling || second || (n_pt < 32768 && !serial)) {
-                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
+                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
+                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
             } else {
                 // (tile 0 by a block of its own first: it is exempt from the density test, and the literal-heavy start of a stream --
                 //  config 3's first 4096 bytes match nothing -- is 8192 one-byte steps for a lone lane, 0.75 ms that every other
                 //  lane would wait for; the serial kernel then finds the tile resolved)
-                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes);
-                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes);
+                RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
+                RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
+                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes, d_clist, d_ccnt);
             }
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
@@ -2011,6 +2106,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 }
             }
         }
+        parsed_by_walk = parsed;
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
             RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
@@ -2027,7 +2123,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         rc = sweep(nullptr); if (rc) return rc;
     }
     // ---- E3: the general parse (skipped when the chain walk's own per-tile parse was accepted)
-    rc = dev_buf(c, 11, (size_t)E * 2 + 64, &p); if (rc) return rc;
+    rc = dev_buf(c, 11, (size_t)E * 2 + 64, &p); if (rc) return rc;      // (grow-only: the lists' larger block stays where it is)
     uint16_t *d_exit = (uint16_t *)p;
     const uint32_t n_groups = (uint32_t)ceil_div(n_pt, SUPER);
     void *q; rc = dev_buf(c, 17, (size_t)n_groups * PT * 4 + (size_t)n_groups * 8 + 64, &q); if (rc) return rc;
@@ -2059,7 +2155,8 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     *out_n = total;
     if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- E4
-    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W);
+    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W,
+               (const uint32_t *)(parsed_by_walk ? d_clist : nullptr), (const uint32_t *)(parsed_by_walk ? d_ccnt : nullptr));
     RSN_HIP(hipStreamSynchronize(s));
     return RSN_OK;
 }
