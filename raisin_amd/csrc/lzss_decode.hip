@@ -379,6 +379,147 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
     if (e) atomicOr(err, 1);
 }
 
+// ------------------------------------------------------------------ L1': the front end in one pass over the tokens (r03)
+// k_lzd_count + scan + k_lzd_tiles parse every token twice (0.6 + 0.75 ms per GiB of text) and cost two host round trips.  k_lzd_tiles
+// needs the absolute output offsets for two things only, and both can do without a second parse:
+//   * "the slice starts inside the decoded data" (ptr <= output so far, lzss.go:349): the counting pass knows every token's offset
+//     RELATIVE to its 4 KB block, so it leaves need[b] = max(ptr - relative offset); the stream is valid iff need[b] <= blk_off[b] for every
+//     block -- one compare per block after the scan.  (len <= ptr is local and checked at once.  Until that compare has been read back the
+//     tile kernels run on a stream that may point before its own start: they index LDS tails of TL >= the largest pointer and never memory,
+//     so the worst case is garbage in a buffer whose call returns RSN_ERR_FORMAT.)
+//   * the item that produces the first byte of every output tile: the pass also leaves what each 16-byte span produces (16 bits), so a
+//     tile's first item is found by a binary search over the block offsets, a scan of that block's 256 span outputs and a walk through
+//     ONE span -- k_lzd_tilemap, one wavefront per tile.
+// A span that produces 65535 bytes or more (a foreign stream with huge tokens) raises flags[5]: the host then runs k_lzd_tiles as before.
+__global__ __launch_bounds__(ZB) void k_lzd_count2(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, uint16_t *__restrict__ span_out,
+                                                   unsigned long long *__restrict__ need, uint32_t *__restrict__ maxptr, int *__restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
+    __shared__ uint32_t masks[ZB + 2];
+    __shared__ unsigned long long wsum[ZB / 64], wneed[ZB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    Span r;
+    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, r);
+    unsigned long long mine = 0;
+    int e = 0;
+    if (valid) { span_parse(sw, masks, tid, ZPAD + 16 * tid, valid, r); mine = r.out; if (r.err) e = 1; }
+    span_out[(size_t)blockIdx.x * ZB + tid] = (uint16_t)min(mine, 0xFFFFull);
+    if (mine >= 0xFFFFull) e |= 4;
+    if (__ballot(valid && mask_5c(r.w) != 0) && lane == 0 && __atomic_load_n(&flags[4], __ATOMIC_RELAXED) == 0) atomicOr(&flags[4], 1);
+    unsigned long long incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned long long o = incl - mine;                                    // output offset of the span's first item, relative to the block
+    for (int k = 0; k < wv; k++) o += wsum[k];
+    unsigned long long nd = 0;
+    uint32_t mp = 0;
+    if (valid && !r.err) {
+        unsigned long long before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((uint32_t)k < r.ntok) {
+                const unsigned long long oo = o + (uint32_t)__builtin_popcount(r.lit & ((1u << r.tj[k]) - 1u)) + before;
+                const uint32_t ptr = r.tptr[k], len = r.tlen[k];
+                if (len > ptr) e |= 2;                                   // the slice ends inside out (lzss.go:350)
+                if (ptr > oo) nd = max(nd, (unsigned long long)ptr - oo);   // absolutePointer >= 0 iff the block starts at least this far into the output
+                if (len) mp = max(mp, ptr);
+                before += len;
+            }
+        }
+    }
+    for (int d = 32; d; d >>= 1) { nd = max(nd, (unsigned long long)__shfl_down(nd, d)); mp = max(mp, (uint32_t)__shfl_down(mp, d)); }
+    if (lane == 0) wneed[wv] = nd;
+    if (lane == 0 && mp > __atomic_load_n(maxptr, __ATOMIC_RELAXED)) atomicMax(maxptr, mp);   // same-address atomics serialise: only raise it
+    if (e & 3) atomicOr(&flags[0], e & 3);                                  // 1: malformed token, 2: reference outside the decoded data
+    if (e & 4) atomicOr(&flags[5], 1);
+    __syncthreads();
+    if (tid == 0) {
+        blk_len[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        need[blockIdx.x] = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lzd_check(const unsigned long long *__restrict__ need, const unsigned long long *__restrict__ blk_off, uint32_t n_cb, int *__restrict__ flags) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const bool bad = b < n_cb && need[b] > blk_off[b];
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 2);
+}
+
+// tile_info[t] = {input position, output position} of the item that produces output byte t * DT: one wavefront per tile.
+// Latency is all there is to it (65 536 tiles per GiB, a few dependent steps each), so the steps are few and wide: a 64-ary search of
+// the block offsets, one load of the block's span outputs, one load of the 64 bytes around the span -- the walk through the span's
+// items then reads its bytes out of that register with v_readlane, all lanes in step.
+__global__ __launch_bounds__(256) void k_lzd_tilemap(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off, uint32_t n_cb,
+                                                     const uint16_t *__restrict__ span_out, uint32_t n_tiles, uint2 *__restrict__ tile_info) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const unsigned long long T = (unsigned long long)t * DT;
+    // the last block whose first item starts at or before T (blocks that produce nothing share an offset: the last one wins, and it is
+    // the one with output): [lo, hi) always holds it, 64 probes a step
+    uint32_t lo = 0, hi = n_cb;
+    while (hi - lo > 1) {
+        const uint32_t span = hi - lo, stride = (span + 63) / 64;
+        const uint32_t idx = lo + (uint32_t)lane * stride;                 // lane 0 probes lo itself: always <= T
+        const bool le = idx < hi && blk_off[idx] <= T;
+        const unsigned long long m = __ballot(le);                        // a prefix of the lanes (the offsets ascend)
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(m);
+        const uint32_t nlo = lo + last * stride;
+        hi = min(hi, nlo + stride);
+        lo = nlo;
+    }
+    const uint32_t b = lo;
+    const unsigned long long boff = blk_off[b];
+    const uint32_t rel = (uint32_t)(T - boff);                            // < the block's output (T < the stream's length)
+    // the block's 256 span outputs, four per lane; the span whose items cover `rel`
+    const uint2 pk = *reinterpret_cast<const uint2 *>(span_out + (size_t)b * ZB + 4 * lane);
+    const uint32_t s0 = pk.x & 0xFFFF, s1 = pk.x >> 16, s2 = pk.y & 0xFFFF, s3 = pk.y >> 16, sum = s0 + s1 + s2 + s3;
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    const uint32_t ex = incl - sum;
+    const unsigned long long hm = __ballot(rel >= ex && rel < incl);       // exactly one lane (spans that produce nothing never qualify)
+    if (!hm) { if (lane == 0) tile_info[t] = make_uint2(0u, 0u); return; } // (cannot happen for a consistent count; the resolve kernel then fails its own checks)
+    uint32_t sp = 4 * lane, so = ex;                                       // every lane as if it were the one: span index inside the block, output offset of its first item
+    if (rel >= so + s0) { so += s0; sp++; if (rel >= so + s1) { so += s1; sp++; if (rel >= so + s2) { so += s2; sp++; } } }
+    const int src = __builtin_ctzll(hm);
+    sp = (uint32_t)__builtin_amdgcn_readlane((int)sp, src);
+    so = (uint32_t)__builtin_amdgcn_readlane((int)so, src);
+    // the 64 bytes from 24 before the span (a token that began before it is at most 23 long) to 40 after its start (a token that begins in it ends there)
+    const long long s_beg = (long long)b * ZTILE + 16ll * sp, w0 = s_beg - 24;
+    const long long qa = w0 + lane;
+    const uint32_t wbyte = qa >= 0 && qa < (long long)n ? in[qa] : 0u;
+    auto B = [&](long long q) -> uint32_t {                                // byte q of the stream, q wave-uniform and inside the window (0 beyond the stream)
+        return (uint32_t)__builtin_amdgcn_readlane((int)wbyte, (int)(q - w0));
+    };
+    auto tok = [&](long long j, uint32_t &len, uint32_t &tl) -> bool {    // the token whose '<' is byte j (as parse_tok)
+        long long k = j + 1;
+        unsigned long long v = 0; int nd = 0;
+        while (k < (long long)n && nd < 10 && B(k) >= '0' && B(k) <= '9') { v = v * 10 + (B(k) - '0'); k++; nd++; }
+        if (nd == 0 || k >= (long long)n || B(k) != ',' || v > 0xFFFFFFFFull) return false;
+        k++; v = 0; nd = 0;
+        while (k < (long long)n && nd < 10 && B(k) >= '0' && B(k) <= '9') { v = v * 10 + (B(k) - '0'); k++; nd++; }
+        if (nd == 0 || k >= (long long)n || B(k) != '>' || v > 0xFFFFFFFFull) return false;
+        len = (uint32_t)v; tl = (uint32_t)(k + 1 - j);
+        return true;
+    };
+    long long pos = s_beg;                                                 // first position of the span that is not inside a token begun before it (skip_open_token)
+    for (int back = 1; back < MAXTOK && back <= s_beg; back++) {
+        const uint32_t c = B(s_beg - back);
+        if (c == '>') break;
+        if (c == '<') { uint32_t len, tl; if (tok(s_beg - back, len, tl)) pos = max(pos, s_beg - back + (long long)tl); break; }
+    }
+    const long long lim = min(s_beg + 16, (long long)n);
+    unsigned long long o = boff + so;
+    uint2 res = make_uint2((uint32_t)pos, (uint32_t)o);
+    while (pos < lim) {
+        uint32_t len = 1, adv = 1;
+        if (B(pos) == '<') { if (!tok(pos, len, adv)) break; }
+        if (o + len > T) { res = make_uint2((uint32_t)pos, (uint32_t)o); break; }   // (o <= T here: the items before it end at or before T)
+        o += len; pos += adv;
+    }
+    if (lane == 0) tile_info[t] = res;
+}
+
 struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback;
                      unsigned long long *stats; };   // RSN_LZD_STATS: cycles per phase, summed over blocks
 
@@ -864,14 +1005,22 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     volatile int *hflag = (volatile int *)(h64 + 1);
-    RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));                          // ... [4] the stream holds a 5C byte
-    RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
+    RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));                          // ... [4] the stream holds a 5C byte, [5] a span produces 65535 bytes or more
+    static const bool three_pass = getenv("RSN_LZSS_DEC_3PASS") != nullptr;   // A/B switch: r02's front end (count, scan, then k_lzd_tiles parsing everything again)
+    uint16_t *d_span = nullptr; unsigned long long *d_need = nullptr;
+    if (!three_pass) {
+        rc = dev_buf(c, 27, (size_t)n_cb * ZB * 2 + (size_t)n_cb * 8 + 64, &p); if (rc) return rc;
+        d_need = (unsigned long long *)p; d_span = (uint16_t *)(d_need + n_cb);
+        RSN_LAUNCH("lzss_dec_count", k_lzd_count2, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_span, d_need, (uint32_t *)(d_flag + 2), d_flag);
+    } else RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
     rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
-    if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
+    if (hflag[0] & 1) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
+    if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
     if (h64[0] >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
+    const bool one_pass = !three_pass && hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
     if (!d_out) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens
@@ -893,10 +1042,18 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     uint32_t *d_maxptr = (uint32_t *)(d_flag + 2);
     int *d_fallback = d_flag + 3;
     volatile uint32_t *hmax = (volatile uint32_t *)(hflag + 2);
-    RSN_LAUNCH("lzss_dec_tiles", k_lzd_tiles, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_tinfo, d_maxptr, d_flag);
-    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipStreamSynchronize(s));   // nothing may chase a pointer before every token has been validated
-    if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+    if (one_pass) {
+        // (no round trip here: the tile kernels below cannot leave their LDS arrays whatever the pointers are -- len <= ptr <= DT is known --
+        //  and the verdict of k_lzd_check is read with the flags after them)
+        RSN_LAUNCH("lzss_dec_tiles", k_lzd_check, dim3((uint32_t)ceil_div(n_cb, 256)), dim3(256), 0, s, (const unsigned long long *)d_need, (const unsigned long long *)d_boff, n_cb, d_flag);
+        RSN_LAUNCH("lzss_dec_tiles", k_lzd_tilemap, dim3((uint32_t)ceil_div(n_tiles, 4)), dim3(256), 0, s, d_in, n, (const unsigned long long *)d_boff, n_cb, (const uint16_t *)d_span, n_tiles, d_tinfo);
+    } else {
+        if (!three_pass) RSN_HIP(hipMemsetAsync(d_maxptr, 0, 4, s));      // (k_lzd_tiles raises it again)
+        RSN_LAUNCH("lzss_dec_tiles", k_lzd_tiles, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_tinfo, d_maxptr, d_flag);
+        RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));   // nothing may chase a pointer before every token has been validated
+        if (hflag[0]) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+    }
     static const bool force_jump = getenv("RSN_LZSS_DEC_JUMP") != nullptr;   // A/B switch: whole-stream pointer jumping
     bool tile_path = !force_jump && hmax[0] <= (uint32_t)DT;
     if (tile_path) {
@@ -944,8 +1101,13 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
+        if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");   // k_lzd_check's verdict
         if (hflag[3]) tile_path = false;                                  // a tile's input did not fit (zero-length tokens): redo with the general path
         else if (plain) return RSN_OK;                                    // bytes are in place
+    } else if (one_pass) {                                                // the general path chases pointers through memory: k_lzd_check's verdict first
+        RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
     }
     if (!tile_path) {
         rc = dev_buf(c, 14, (size_t)E * 4 + 64, &p); if (rc) return rc;
