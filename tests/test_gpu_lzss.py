@@ -317,6 +317,42 @@ def test_decode_errors(lz, oracle):
         lz.NewWriterLevel(None, -1)                            # lzss.go:43-45
 
 
+def test_decode_front_end_in_one_pass(lz, oracle, monkeypatch):
+    """The decoder's counting pass also leaves, per 4 KB block, how far into the output the block must start for its pointers to be
+    valid, and per 16-byte span what it produces; the tile kernels then run without a second parse of the tokens (k_lzd_tilemap).
+    Checked here: a pointer before the start of the data deep inside a stream (the compare per block, read back only after the tile
+    kernels have run), at a block edge and inside a tile; spans that produce 65535 bytes and more (the pass hands those streams
+    to the r02 front end); tile boundaries that fall inside literals, inside tokens and right after zero-output spans; and the
+    same bytes from the r02 front end (RSN_LZSS_DEC_3PASS) on everything."""
+    from raisin_amd import RsnError
+    rng = np.random.default_rng(9)
+    lit = rng.integers(97, 123, size=5000, dtype=np.uint8).tobytes()
+    for bad in (lit + b"<6000,10>" + lit, lit[:4090] + b"<4091,7>", lit * 8 + b"<40001,9>" + lit, b"<1,1>" + lit):
+        with pytest.raises(oracle.OracleError):
+            oracle.lzss_decompress(bad)
+        with pytest.raises(RsnError) as ei:
+            lz.Decompress(bad)
+        assert ei.value.code == -3
+    ok = lit + b"<5000,10>" + lit[:4086] + b"<4096,4096>" * 40 + b"<7,7>" * 3000 + lit + b"<16384,16000>" * 9
+    big = rng.integers(97, 123, size=80000, dtype=np.uint8).tobytes()
+    streams = [ok, big + b"<80000,80000>" + b"<160000,70000>x", text(77, 300000) and oracle.lzss_compress(text(77, 300000)),
+               oracle.lzss_compress(lit * 40), (lit * 4)[:16384 - 5] + b"<9,9>" + (lit * 4)[:16384 - 9] + b"<16384,16384>" * 5 + b"q"]
+    want = [oracle.lzss_decompress(c) for c in streams]
+    assert [lz.Decompress(c) for c in streams] == want
+    monkeypatch.setenv("RSN_LZSS_DEC_3PASS", "1")                # (read once per process: effective only if nothing decoded before -- the subprocess below is the real A/B)
+    import subprocess, sys, hashlib
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
+            "import pickle; streams = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "print(' '.join(hashlib.sha256(lz.Decompress(c)).hexdigest() for c in streams))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pickle, tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump(streams, f)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=300, env=dict(os.environ, RSN_LZSS_DEC_3PASS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-len(streams):] == [hashlib.sha256(w).hexdigest() for w in want]
+
+
 def test_decode_paths(lz, oracle):
     """The tile path (back-pointers <= 16384), its fallbacks, and streams only a foreign encoder writes."""
     data = text(41, 70000)
