@@ -529,7 +529,10 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     __shared__ uint32_t masks[DTH + 2];
     __shared__ uint32_t s_part[DTH / 64];
     __shared__ uint32_t s_wlast[DTH / 64];
-    constexpr uint32_t NONE = 0xFFFFu;                                    // "no item starts here" (both type bits set: never a descriptor)
+    // Item marks (phases A and B only): 0 = no item starts here; bit 15 = a RUN of literals starts here, low 15 bits = (staged byte index -
+    // output position) mod 2^15 -- the byte of position y of the run is stage[(y + mark) mod 2^15]; bit 14 = a token, low 14 bits = ptr - 1.
+    // (r02 marked every literal with its own byte: 16 address computations and 16 LDS stores per lane where a span holds one or two runs.)
+    constexpr uint32_t NONE = 0u, M_LIT = 0x8000u, M_TOK = 0x4000u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned long long t_prev = a.stats ? __builtin_amdgcn_s_memtime() : 0;
     auto phase_done = [&](int q) {                                        // RSN_LZD_STATS: cycles of the phase that just ended (thread 0's view)
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         else if (P < a.n) { uint32_t w[4] = {0, 0, 0, 0}; for (int q = 0; q < 16 && P + q < a.n; q++) w[q >> 2] |= (uint32_t)a.in[P + q] << (8 * (q & 3)); x = {w[0], w[1], w[2], w[3]}; }
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
-    for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     phase_done(0);
     const int TL = (int)a.TL;
@@ -582,14 +585,12 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         uint32_t tot = 0;
         for (int w = 0; w < DTH / 64; w++) { if (w < wv) o += (int)s_part[w]; tot += s_part[w]; }
         if (valid && o < tlen) {
+            for (uint32_t st = r.lit & ~(r.lit << 1); st; st &= st - 1) {   // the first literal of every run of literals in the span
+                const int j = __builtin_ctz(st);
+                int x = o + __builtin_popcount(r.lit & ((1u << j) - 1u));
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                if ((r.lit >> j) & 1) {
-                    int x = o + __builtin_popcount(r.lit & ((1u << j) - 1u));
-#pragma unroll
-                    for (int q = 0; q < 4; q++) x += r.tj[q] < (uint32_t)j ? (int)r.tlen[q] : 0;
-                    if (x >= 0 && x < tlen) sd[x] = (uint16_t)((r.w[j >> 2] >> (8 * (j & 3))) & 0xFF);
-                }
+                for (int q = 0; q < 4; q++) x += r.tj[q] < (uint32_t)j ? (int)r.tlen[q] : 0;
+                if (x >= 0 && x < tlen) sd[x] = (uint16_t)(M_LIT | ((uint32_t)(sbyte + j - x) & 0x7FFFu));
             }
             int before = 0;
 #pragma unroll
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
                     const int x0 = o + __builtin_popcount(r.lit & ((1u << r.tj[q]) - 1u)) + before;
                     const uint32_t ptr = r.tptr[q], len = r.tlen[q];
                     const int xs = max(x0, 0);                            // a token that began in the previous tile: its first byte HERE
-                    if (len && x0 + (int)len > 0 && xs < tlen) sd[xs] = (uint16_t)(D_LOC | (ptr - 1u));
+                    if (len && x0 + (int)len > 0 && xs < tlen) sd[xs] = (uint16_t)(M_TOK | (ptr - 1u));
                     before += (int)len;
                 }
             }
@@ -632,18 +633,27 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (cur == NONE) cur = carry;
     }
     uint32_t dsc[16];
-    uint32_t unres = 0;
+    uint32_t unres = 0, litm = 0;
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t val = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
         cur = val != NONE ? val : cur;
         const int x = xb + j;
+        const bool is_lit = (cur & M_LIT) && x < tlen;
         uint32_t d = 0;                                                   // (a position no item covers cannot occur in a validated stream)
-        if ((cur & 0xC000u) == D_LOC) d = token_desc(x, (cur & D_PAY) + 1u);
-        else if (cur != NONE) d = cur;                                    // a literal
-        if (x >= tlen) d = 0;
+        if (is_lit) d = ((uint32_t)x + cur) & 0x7FFFu;                    // for now: the staged index of the literal's byte
+        else if ((cur & M_TOK) && x < tlen) d = token_desc(x, (cur & D_PAY) + 1u);
         dsc[j] = d;
-        unres |= ((d >> 14) == 1u ? 1u : 0u) << j;
+        litm |= (is_lit ? 1u : 0u) << j;
+        unres |= (!is_lit && (d >> 14) == 1u ? 1u : 0u) << j;
+    }
+    if (__ballot(litm != 0)) {   // the literals' bytes out of the stage, all reads issued together (a slot that holds no literal reads byte 0 with everybody else)
+        uint32_t by[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) by[j] = sb[(litm >> j) & 1 ? dsc[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < 16; j++) if ((litm >> j) & 1) dsc[j] = by[j];
     }
     auto write_back = [&]() {
         uint32_t o[8];
