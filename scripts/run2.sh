@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for k in text period; do timeout 300 python scripts/quick_lzss.py $k 1024 2>&1 | grep -A12 "^decode" | grep -E "decode|resolve"; done
+(timeout 600 python -m pytest tests/test_gpu_huffman_decode.py -m gpu -x -q 2>&1 | tail -12) 2>&1

@@ -1,5 +1,6 @@
 """CPU tests: the C-ABI library loads and exports every symbol include/rsn.h declares,
 fails loudly without a device, and its HOST logic (Go-exact tree, header) matches the oracle."""
+import ctypes
 import os
 import random
 import re
@@ -167,6 +168,20 @@ def test_legacy_lz_compress_host_only(built, oracle, samiam, known):
     for d in cases:
         for w in (4096, 8192, 100, 0):
             assert lz.Compress(d, False, w) == oracle.lzss_compress_legacy(d, w)
+
+
+def test_legacy_lz_compress_refuses_what_would_run_for_hours(built):
+    """lz.Compress is the reference's O(n * window) serial loop on the calling thread (O(n^2) for window <= 0) and a cgo
+    call cannot be interrupted: above 64 MiB (1 MiB for unbounded / huge windows) the entry point returns RSN_ERR_LIMIT."""
+    from raisin_amd import _lib
+    L = _lib.lib()
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t(0)
+    big = bytes((1 << 20) + 1)
+    assert L.rsn_lzss_compress_legacy(big, len(big), 0, ctypes.byref(out), ctypes.byref(n)) == -6 and b"legacy" in L.rsn_last_error()
+    assert L.rsn_lzss_compress_legacy(big, len(big), 1 << 20, ctypes.byref(out), ctypes.byref(n)) == -6
+    assert L.rsn_lzss_compress_legacy(big[:1 << 20], 1 << 20, 64, ctypes.byref(out), ctypes.byref(n)) == 0 and n.value > 0
+    L.rsn_free(out)
 
 
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):

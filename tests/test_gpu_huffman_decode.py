@@ -1,4 +1,5 @@
 """GPU parity: librsn Huffman decode (through the C ABI) vs the CPU oracle, bit-exact."""
+import ctypes
 import random
 
 import numpy as np
@@ -138,6 +139,31 @@ def test_errors_where_the_reference_panics(huff, oracle, samiam):
                 huff.Decompress(b)
         else:
             assert huff.Decompress(b) == want
+
+
+def test_size_query_checks_the_stream_and_cannot_overflow(huff):
+    """the size query (d_out NULL) is answered from the header -- after the cheap format checks, so that a malformed stream
+    is refused by the query itself, and with counts that exceed what the payload can hold (a foreign header; a count past 2^63 - 1
+    reads as MaxInt64 like strconv.Atoi, huffman.go:207) answered by the payload's own bound instead of a wrapped sum."""
+    import torch
+    from raisin_amd import _lib
+
+    def query(stream):
+        t = torch.frombuffer(bytearray(stream + b"\0" * 16), dtype=torch.uint8).cuda()
+        got = ctypes.c_size_t(0)
+        rc = _lib.lib().rsn_huffman_decompress_dev(t.data_ptr(), len(stream), None, 0, ctypes.byref(got), None)
+        return rc, got.value
+
+    good = huff.Compress(b"abracadabra" * 1000)
+    rc, need = query(good)
+    assert rc == -7 and 11000 <= need <= 11000 + 32
+    assert query(b"4|a\\\n\x00\x80")[0] == -3                   # single-symbol tree with a payload (reference recurses without end)
+    assert query(b"1|a1|b\\\n\x09\x80")[0] == -3                # pad exceeds the payload
+    assert query(b"1|a1|b")[0] == -3                               # no separator
+    huge = b"99999999999999999999999|a" + b"18446744073709551615|b" + b"\\\n\x00" + bytes(range(100))
+    rc, need = query(huge)
+    assert rc == -7 and need <= 4 * 800 + 32                       # 100 payload bytes: at most 800 symbols of at most 4 bytes
+    assert huff.Decompress(huge) == bytes(b"ab"[(b >> (7 - k)) & 1] for b in range(100) for k in range(8))
 
 
 def test_device_resident_round_trip_256MiB(huff):
