@@ -176,8 +176,26 @@ int main(int argc, char **argv) {
         if (cmd == "compress") {
             if (algorithm.empty()) algorithm = "lzss,huffman";   // reference default "lzss,arithmetic" (cli.go:99); arithmetic is not on this path
             const auto algs = split(algorithm, ',');
+            auto out_name = [&](const std::string &f) { return files.size() == 1 ? (out.empty() ? f + ".rsn" : out) : f + "." + (outext.empty() ? "rsn" : outext); };   // cli.go:108-112
+            if (files.size() > 1 && algs.size() == 1 && algs[0] == "huffman") {
+                // engine.CompressFiles loops over the files, one .rsn each (engine.go:150-154).  Independent inputs of one Huffman layer go
+                // through the batch entry point instead: librsn deals them out over the visible GPUs (file k -> device k mod G) and
+                // overlaps upload, encode and download per device; every output equals what the loop below would have written.
+                std::vector<Bytes> datas;
+                for (auto &f : files) datas.push_back(read_file(f));
+                std::vector<const uint8_t *> ins; std::vector<size_t> lens;
+                for (auto &d : datas) { ins.push_back(d.data()); lens.push_back(d.size()); }
+                std::vector<uint8_t *> outs(files.size(), nullptr); std::vector<size_t> out_lens(files.size(), 0);
+                if (rsn_huffman_compress_batch(files.size(), ins.data(), lens.data(), outs.data(), out_lens.data()) != RSN_OK) throw std::runtime_error(rsn_last_error());
+                for (size_t i = 0; i < files.size(); i++) {
+                    printf("Compressing...\n");
+                    write_file(out_name(files[i]), Bytes(outs[i], outs[i] + out_lens[i]));
+                    rsn_free(outs[i]);
+                    printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", datas[i].size(), out_lens[i], (float)out_lens[i] / (float)datas[i].size() * 100.f);
+                }
+            } else
             for (auto &f : files) {
-                const std::string o = files.size() == 1 ? (out.empty() ? f + ".rsn" : out) : f + "." + (outext.empty() ? "rsn" : outext);   // cli.go:108-112
+                const std::string o = out_name(f);
                 const Bytes data = read_file(f);
                 printf("Compressing...\n");
                 const Bytes c = engine::compress(data, algs);

@@ -54,6 +54,27 @@ def test_cpp_host_cli(tmp_path, oracle, samiam):
     assert "3.5 kB" in out and "Benchmarking lzss,huffman" in out
 
 
+def test_cpp_host_compresses_a_list_of_files_through_the_batch_entry_point(tmp_path, oracle, samiam):
+    """`rsn -compress a,b,c -algorithm=huffman`: engine.CompressFiles' loop over the files (engine.go:150-154, cli.go:102,123-124) goes
+    through rsn_huffman_compress_batch -- the files dealt out over the visible GPUs (here: over three workers sharing one) -- and every
+    .rsn equals the single-file path's; other algorithms and single files keep the loop."""
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    datas = [samiam, samiam[::-1] * 3, bytes(range(128)) * 900, b"z" * 5000, samiam * 40]
+    paths = []
+    for i, d in enumerate(datas):
+        p = tmp_path / ("f%d.txt" % i)
+        p.write_bytes(d)
+        paths.append(str(p))
+    out = subprocess.check_output([exe, "-compress", ",".join(paths), "-algorithm=huffman", "-outext=huf"],
+                                  env=dict(os.environ, RSN_BATCH_WORKERS="3")).decode()
+    assert out.count("Compressing...") == len(datas)
+    for p, d in zip(paths, datas):
+        assert open(p + ".huf", "rb").read() == oracle.huffman_compress(d)
+    subprocess.check_call([exe, "-compress", ",".join(paths[:2]), "-algorithm=lzss,huffman", "-outext=lzh"])   # two layers: the per-file loop
+    assert open(paths[1] + ".lzh", "rb").read() == oracle.huffman_compress(oracle.lzss_compress(datas[1]))
+
+
 def test_benchmark_suite_table(tmp_path, samiam):
     import io
     from raisin_amd import engine
