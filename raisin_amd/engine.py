@@ -87,6 +87,19 @@ def CompressFile(algorithms, path, output):
 
 
 def CompressFiles(algorithms, files, extension):
+    """engine.go:150-154: one .rsn per input.  Several files under one Huffman layer go through rsn_huffman_compress_batch -- the files
+    dealt out over the visible GPUs, upload / encode / download overlapped per device; the outputs are those of the loop."""
+    files = list(files)
+    if len(files) > 1 and list(algorithms) == ["huffman"]:
+        datas = [open(f, "rb").read() for f in files]
+        outs = huffman.CompressBatch(datas)
+        for f, data, out in zip(files, datas, outs):
+            print("Compressing...")
+            open(f + extension, "wb").write(out)
+            print("Original bytes: %d" % len(data))
+            print("Compressed bytes: %d" % len(out))
+            print("Compression ratio: %.2f%%" % (len(out) / len(data) * 100 if data else float("nan")))
+        return
     for f in files:
         CompressFile(algorithms, f, f + extension)
 

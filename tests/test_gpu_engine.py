@@ -73,6 +73,12 @@ def test_cpp_host_compresses_a_list_of_files_through_the_batch_entry_point(tmp_p
         assert open(p + ".huf", "rb").read() == oracle.huffman_compress(d)
     subprocess.check_call([exe, "-compress", ",".join(paths[:2]), "-algorithm=lzss,huffman", "-outext=lzh"])   # two layers: the per-file loop
     assert open(paths[1] + ".lzh", "rb").read() == oracle.huffman_compress(oracle.lzss_compress(datas[1]))
+    from raisin_amd import engine                            # the Python mirror of the same loop
+    engine.CompressFiles(["huffman"], paths, ".pyh")
+    engine.CompressFiles(["lzss"], paths[:2], ".pyl")
+    for p, d in zip(paths, datas):
+        assert open(p + ".pyh", "rb").read() == oracle.huffman_compress(d)
+    assert open(paths[0] + ".pyl", "rb").read() == oracle.lzss_compress(datas[0])
 
 
 def test_benchmark_suite_table(tmp_path, samiam):
