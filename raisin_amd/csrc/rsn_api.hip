@@ -40,9 +40,19 @@ void release_parked(Parked &pk) {              // (HIP calls: only from a live t
 }
 
 // A storm of short-lived caller threads (a Go runtime under load retires and creates OS threads) must not leave an unbounded
-// number of parked scratch arenas in HBM: beyond RSN_MAX_PARKED (default 8) the OLDEST ones are released by the next thread
-// that initialises a context.
-size_t max_parked() { static const size_t v = getenv("RSN_MAX_PARKED") ? (size_t)std::max(0, atoi(getenv("RSN_MAX_PARKED"))) : 8; return v; }
+// number of parked scratch arenas in HBM: beyond RSN_MAX_PARKED the OLDEST ones are released by the next thread that initialises
+// a context.
+// (default: 8 plus three per visible device -- a batch call over G devices retires an uploader, an encoder and a downloader thread per device,
+//  and the next batch wants their rings back)
+size_t max_parked() {
+    static const size_t v = [] {
+        if (getenv("RSN_MAX_PARKED")) return (size_t)std::max(0, atoi(getenv("RSN_MAX_PARKED")));
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 0) cnt = 0;
+        return (size_t)(8 + 3 * cnt);
+    }();
+    return v;
+}
 
 void trim_parked_excess(int restore_device) {
     std::vector<Parked> victims;
