@@ -53,3 +53,25 @@ def test_two_rank_gather_and_timing():
     assert res[0]["chunks"] == [0, 2, 4] and res[1]["chunks"] == [1, 3]
     assert res[0]["sizes"] == [1000, 1777] and res[0]["ok"] is True and res[1]["sizes"] is None
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0
+
+
+@pytest.mark.timeout(300)
+def test_bench_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE): bench.py must become the launcher's parent and forward the
+    child's exit code -- on this GPU-less box the two ranks fail when they reach for cuda:0, which is the point of the check: they were
+    started (two rank tracebacks / a torchrun failure summary), nothing printed the old "started under a launcher" refusal, and the
+    exit code is the child's, not 2.  The self-launch itself must not import torch (it runs before anything may touch a GPU)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--mib", "1",
+                          "--dist-backend", "gloo"], capture_output=True, text=True, env=env, timeout=280)
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode not in (0, 2), (out.returncode, out.stderr[-500:])
+        assert "launcher started" not in out.stderr and "torch.distributed.run" not in out.stdout
+        assert "ChildFailedError" in out.stderr or "exitcode" in out.stderr       # torchrun's summary of the two failed ranks
+    else:
+        assert out.returncode == 0 and out.stdout.count('"n_gpus": 2') == 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def self_launch"):src.index("def main")]
+    assert "import torch" not in body
