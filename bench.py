@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs after the timed region")
     ap.add_argument("--others", default="2b,skewed,3,4,5")
+    ap.add_argument("--profile-only", default="", help="run ONLY these other configs (no headline step, no CPU baselines) and print their entries: "
+                    "what scripts/profile.sh puts under rocprofv3, so that a workload's counters hold that workload's launches and nothing else")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
@@ -370,6 +372,12 @@ def main():
     _lib.check(_lib.lib().rsn_device_set(local_rank))
 
     n = args.mib << 20
+    if args.profile_only:
+        from oracle import oracle as O
+        O.build()
+        names = [x for x in args.profile_only.split(",") if x]
+        print(json.dumps({"profile_only": run_other_configs(torch, device, n, O.host_cores(), False, names)}), flush=True)
+        return
     seed = _shard.chunk_seed(rank, world)
     src = W.uniform_bytes(n, seed, 128, device)
     comp_buf = torch.empty(n + n // 8 + (1 << 20), dtype=torch.uint8, device=device)
