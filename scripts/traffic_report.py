@@ -41,6 +41,9 @@ def main():
     print("%-10s %14s %14s %7s   %14s %14s %7s" % ("workload", "encode traffic", "algorithmic", "ratio", "decode traffic", "algorithmic", "ratio"))
     for label, enc, ae, dec, ad in rows:
         print("%-10s %14.3e %14.3e %7.2f   %14.3e %14.3e %7.2f" % (label, enc, ae, enc / ae, dec, ad, dec / ad))
+    print("\n(FETCH_SIZE is doubled for every kernel -- the gfx950 correction the guide gives for wide coalesced streaming reads, 16 B per lane.  Kernels whose"
+          "\n loads are scattered -- k_chain_serial: one 16-byte group of keys per lane and step -- have no calibration: their true fetch lies between the raw"
+          "\n counter (half the figure below) and the doubled one.)")
     print("\nlargest kernels per workload (fetch + write at the largest launch, GB):")
     for label in ("headline", "skewed", "config3", "config4"):
         p = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, label))
