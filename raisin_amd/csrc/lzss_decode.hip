@@ -520,8 +520,89 @@ __global__ __launch_bounds__(256) void k_lzd_tilemap(const uint8_t *__restrict__
     if (lane == 0) tile_info[t] = res;
 }
 
+// RUN TILES (r03).  A tile that holds nothing but a few tokens -- W-periodic data is four tokens per tile, long runs and repeated blocks
+// look the same -- needs no per-position work at all: its descriptors are a handful of runs "positions x0.. come from positions r0.. of
+// the previous tile's tail", found by resolving the tokens against each other as INTERVALS (one lane, a few dozen steps).  Such a tile
+// is recognised by its input alone -- at most RT_BYTES bytes of tokens for 16 KiB of output -- and resolved by k_lzd_runs, one wavefront
+// per tile: rt_cnt[tile] = number of runs, rt_runs[tile][..] = x0 | r0 << 16 (a run ends where the next begins), no 32 KB of descriptors;
+// k_lzd_resolve returns at once for it, k_lzd_compose and k_lzd_emit expand the runs on the fly.  Config 3: 2 bytes per output byte
+// written and read back -> none.  (The same path INSIDE k_lzd_resolve, taken after its parse, cost text 10 % of that kernel through
+// register allocation alone, whether taken or not.)
+constexpr int RT_ITEMS = 32, RT_RUNS = 64;                                // most tokens of a run tile, most runs after resolving them
+constexpr int RT_BYTES = 448;                                             // most input bytes of a run tile (32 tokens of up to 13 bytes, and room to see a 33rd)
 struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback;
-                     unsigned long long *stats; };   // RSN_LZD_STATS: cycles per phase, summed over blocks
+                     unsigned long long *stats;      // RSN_LZD_STATS: cycles per phase, summed over blocks
+                     uint32_t *rt_cnt, *rt_runs; };  // per tile: 0 = descriptors, else the number of runs; RT_RUNS words per tile
+
+__global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in, size_t n, const uint2 *__restrict__ tile_info, uint32_t n_tiles, uint32_t E, uint32_t TL,
+                                                 uint32_t *__restrict__ rt_cnt, uint32_t *__restrict__ rt_runs) {
+    __shared__ uint8_t s_in[RT_BYTES + MAXTOK + 8];
+    __shared__ uint32_t s_tok[RT_ITEMS + 1];                              // x | (ptr - 1) << 16 in stream order; then the end of the last token
+    __shared__ uint32_t s_runs[RT_RUNS];
+    __shared__ uint32_t s_nr;
+    const int lane = threadIdx.x;
+    const uint32_t k = blockIdx.x, ts = k * DT;
+    const int tlen = (int)min((uint32_t)DT, E - ts);
+    const uint2 info = tile_info[k];
+    const size_t in0 = info.x, in1 = k + 1 < n_tiles ? (size_t)tile_info[k + 1].x : n;   // the tile's items begin in [in0, in1)
+    if (in1 <= in0 || in1 - in0 > (size_t)RT_BYTES) { if (lane == 0) rt_cnt[k] = 0; return; }
+    const uint32_t nb = (uint32_t)(in1 - in0), stage = min((uint32_t)(n - in0), nb + (uint32_t)MAXTOK);
+    for (uint32_t i = lane; i < RT_BYTES + MAXTOK + 8; i += 64) s_in[i] = i < stage ? in[in0 + i] : 0;
+    if (lane == 0) s_nr = 0;
+    __syncthreads();
+    // every '<' among the first nb bytes starts a token (a literal '<' is escaped); the tile is a run tile iff those tokens follow each
+    // other without a byte between them from byte 0 on -- then nothing but tokens produces the tile
+    uint32_t ntok = 0;
+    bool ok = true;
+    int x = (int)((long long)info.y - (long long)ts);                     // output position of the first item, relative to the tile: <= 0
+    if (lane == 0) {
+        uint32_t pos = 0;
+        while (x < tlen && ok) {                                            // (the token that reaches the tile's end may begin at byte nb: it is staged too)
+            if (pos >= stage || s_in[pos] != '<' || ntok >= (uint32_t)RT_ITEMS) { ok = false; break; }
+            const Tok t = parse_tok(s_in, stage, pos);
+            if (!t.ok || t.ptr == 0 || t.ptr > TL || t.len > t.ptr) { ok = false; break; }   // (validated already; a run tile needs ptr <= TL like every tile of the tile path)
+            if (t.len) {                                                    // (a zero-length token produces nothing)
+                const int xs = max(x, 0);
+                if (x + (int)t.len > 0 && xs < tlen) s_tok[ntok++] = (uint32_t)xs | ((t.ptr - 1u) << 16);
+                x += (int)t.len;
+            }
+            pos += t.tl;
+        }
+        ok = ok && ntok >= 1 && (s_tok[0] & 0xFFFFu) == 0 && x >= tlen;   // the tokens cover the tile from its first byte to its last
+        if (ok) {
+            s_tok[ntok] = (uint32_t)tlen;
+            // Every token copies [x0 - ptr, x0 - ptr + len): what lies before the tile is the previous tail (r = TL + position), what lies
+            // inside it is made of runs already resolved -- the tokens before it cover every earlier position -- and is copied piecewise.
+            uint32_t nr = 0;
+            auto push = [&](uint32_t x0, uint32_t r0) {
+                if (nr && r0 == (s_runs[nr - 1] >> 16) + (x0 - (s_runs[nr - 1] & 0xFFFFu))) return;   // continues the run before it
+                if (nr >= (uint32_t)RT_RUNS) { ok = false; return; }
+                s_runs[nr++] = x0 | (r0 << 16);
+            };
+            for (uint32_t it = 0; it < ntok && ok; it++) {
+                const uint32_t x0 = s_tok[it] & 0xFFFFu, ptr = (s_tok[it] >> 16) + 1u, xe = min(s_tok[it + 1] & 0xFFFFu, (uint32_t)tlen);
+                uint32_t out = x0, left = xe - x0;
+                int pos = (int)x0 - (int)ptr;
+                if (pos < 0) { const uint32_t n1 = min(left, (uint32_t)(-pos)); push(out, (uint32_t)((int)TL + pos)); out += n1; pos += (int)n1; left -= n1; }
+                uint32_t q = 0;
+                while (left && ok) {                                       // pos >= 0: inside the tile, covered by the runs so far
+                    while (q + 1 < nr && (s_runs[q + 1] & 0xFFFFu) <= (uint32_t)pos) q++;
+                    const uint32_t rx = s_runs[q] & 0xFFFFu, rend = q + 1 < nr ? (s_runs[q + 1] & 0xFFFFu) : out;   // (the last run ends where this token is writing)
+                    if ((uint32_t)pos < rx || (uint32_t)pos >= rend) { ok = false; break; }
+                    const uint32_t n1 = min(left, rend - (uint32_t)pos);
+                    push(out, (s_runs[q] >> 16) + ((uint32_t)pos - rx));
+                    out += n1; pos += (int)n1; left -= n1;
+                }
+            }
+            if (ok) s_nr = nr;
+        }
+    }
+    __syncthreads();
+    const uint32_t nr = s_nr;
+    if ((uint32_t)lane < nr) rt_runs[(size_t)k * RT_RUNS + lane] = s_runs[lane];
+    if (lane == 0) rt_cnt[k] = nr;
+}
+
 
 __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 waves per SIMD: two blocks per CU
     __shared__ __attribute__((aligned(16))) uint32_t sw[(DT + 128) / 4 + 8];
@@ -539,6 +620,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (a.stats) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&a.stats[q], now - t_prev); t_prev = now; }
     };
     const uint32_t k = blockIdx.x, ts = k * DT;
+    const uint32_t is_run_tile = a.rt_cnt ? a.rt_cnt[k] : 0u;             // (asked for here, looked at after the staging loads have been issued)
     const int tlen = (int)min((uint32_t)DT, a.E - ts);
     const uint2 info = a.tile_info[k];
     const size_t in0 = info.x;
@@ -554,6 +636,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
     for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(0u, 0u, 0u, 0u);
+    if (__builtin_amdgcn_readfirstlane((int)is_run_tile)) return;         // k_lzd_runs has resolved it (block-uniform: a scalar branch)
     __syncthreads();
     phase_done(0);
     const int TL = (int)a.TL;
@@ -695,15 +778,32 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
 }
 
 // C_g = the tail map of the group's last tile expressed in the tail that precedes the group
-__global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t dgrp, uint16_t *__restrict__ comp) {
+// descriptor of position x of a run tile: the last run that begins at or before x (runs[0] begins at 0)
+__device__ __forceinline__ uint32_t run_desc(const uint32_t *runs, uint32_t nr, uint32_t x) {
+    uint32_t lo = 0, hi = nr;                                              // runs[lo].x0 <= x < runs[hi].x0
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((runs[mid] & 0xFFFFu) <= x) lo = mid; else hi = mid; }
+    return D_EXT | (((runs[lo] >> 16) + (x - (runs[lo] & 0xFFFFu))) & D_PAY);
+}
+
+__global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t dgrp, uint16_t *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rt_cnt, const uint32_t *__restrict__ rt_runs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
+    __shared__ uint32_t s_rt[RT_RUNS];
     uint16_t *cur = reinterpret_cast<uint16_t *>(dsm), *nxt = cur + TL;
     const size_t k0 = (size_t)blockIdx.x * dgrp;
-    for (uint32_t j = threadIdx.x; j < TL; j += DTH) cur[j] = desc[k0 * DT + DT - TL + j];
+    auto tail_entry = [&](size_t k, uint32_t nr, uint32_t j) -> uint32_t {   // the tile's descriptor of position DT - TL + j
+        return nr ? run_desc(s_rt, nr, DT - TL + j) : desc[k * DT + DT - TL + j];
+    };
+    uint32_t nr = rt_cnt ? rt_cnt[k0] : 0u;
+    if (threadIdx.x < nr) s_rt[threadIdx.x] = rt_runs[k0 * RT_RUNS + threadIdx.x];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < TL; j += DTH) cur[j] = (uint16_t)tail_entry(k0, nr, j);
     __syncthreads();
     for (uint32_t t = 1; t < dgrp; t++) {
-        const uint16_t *m = desc + (k0 + t) * DT + DT - TL;
-        for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = m[j]; nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
+        nr = rt_cnt ? rt_cnt[k0 + t] : 0u;
+        if (threadIdx.x < nr) s_rt[threadIdx.x] = rt_runs[(k0 + t) * RT_RUNS + threadIdx.x];
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = tail_entry(k0 + t, nr, j); nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
         __syncthreads();
         uint16_t *sw = cur; cur = nxt; nxt = sw;
     }
@@ -767,17 +867,19 @@ __device__ __forceinline__ uint32_t emit_bytes_equal(uint32_t w, uint32_t c) {
 
 // map_ff: the stream holds no 5C at all, so unescaping is the byte map FF -> '<' (lzss.go:391-406, '<' never occurs in the escaped
 // stream): applied to the stored bytes here, `esc` is the caller's output buffer and no unescape pass follows (summ unused).
-__global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t dgrp, uint32_t E,
-                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ, int map_ff) {
+__global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict__ desc, uint32_t TL, uint32_t n_tiles, uint32_t dgrp, uint32_t E,   // (64 registers: two blocks per CU)
+                                                  const uint8_t *__restrict__ gtail, uint8_t *__restrict__ esc, uint8_t *__restrict__ summ, int map_ff,
+                                                  const uint32_t *__restrict__ rt_cnt, const uint32_t *__restrict__ rt_runs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
     __shared__ uint32_t s_last[2][DT / ZTILE];                           // per ZTILE block of the tile: index past its last non-5C byte (by tile parity)
+    __shared__ uint32_t s_rt[2][RT_RUNS];                                 // a run tile's runs (by tile parity)
     uint8_t *prev = dsm, *nxt = dsm + TL;
     const uint32_t g = blockIdx.x;
     if (threadIdx.x < 2 * DT / ZTILE) (&s_last[0][0])[threadIdx.x] = 0;
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = g ? gtail[(size_t)(g - 1) * TL + j] : 0;
     const uint32_t x0 = threadIdx.x * 16;
-    auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {
-        if (k < n_tiles && k * DT + x0 < E) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = p[0]; a1 = p[1]; }
+    auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {                   // (a run tile has no descriptors in memory: nothing is loaded for it)
+        if (k < n_tiles && k * DT + x0 < E && !(rt_cnt && rt_cnt[k])) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = p[0]; a1 = p[1]; }
     };
     uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, e0 = d0, e1 = d1;
     load(g * dgrp, d0, d1);
@@ -787,14 +889,33 @@ __global__ __launch_bounds__(DTH) void k_lzd_emit(const uint16_t *__restrict__ d
         if (k >= n_tiles) break;
         load(k + 1 < (g + 1) * dgrp ? k + 1 : n_tiles, e0, e1);            // next tile's descriptors in flight during this one
         const uint32_t ts = k * DT, len = min((uint32_t)DT, E - ts);
+        const uint32_t nr = rt_cnt ? rt_cnt[k] : 0u;                      // a run tile: its descriptors are nr runs (block-uniform)
+        if (nr) {
+            if (threadIdx.x < nr) s_rt[t & 1][threadIdx.x] = rt_runs[(size_t)k * RT_RUNS + threadIdx.x];
+            __syncthreads();
+        }
         if (x0 < len) {
             const uint32_t w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
             uint32_t o[4] = {0, 0, 0, 0};
+            if (nr) {
+                // the run of the lane's first position by bisection, then forward: r follows the position, a new run takes over at its x0
+                const uint32_t *runs = s_rt[t & 1];
+                uint32_t lo = 0, hi = nr;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((runs[mid] & 0xFFFFu) <= x0) lo = mid; else hi = mid; }
+                uint32_t r = (runs[lo] >> 16) + (x0 - (runs[lo] & 0xFFFFu)), nxt_x = lo + 1 < nr ? (runs[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    if (x0 + (uint32_t)q == nxt_x) { lo++; r = runs[lo] >> 16; nxt_x = lo + 1 < nr ? (runs[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu; }
+                    o[q >> 2] |= (uint32_t)prev[r & D_PAY] << (8 * (q & 3));
+                    r++;
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t v = (w[q >> 1] >> (16 * (q & 1))) & 0xFFFF;
                 const uint32_t b = (v & D_EXT) ? prev[v & D_PAY] : (v & 0xFF);
                 o[q >> 2] |= b << (8 * (q & 3));
+            }
             }
             uint32_t so[4] = {o[0], o[1], o[2], o[3]};                     // what is stored (the tail below keeps the escaped bytes)
             if (map_ff) {
@@ -1074,9 +1195,16 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         rc = dev_buf(c, 22, (size_t)n_groups * TL * 5 + 64, &p); if (rc) return rc;
         uint16_t *d_comp = (uint16_t *)p, *d_comp2 = d_comp + (size_t)n_groups * TL;   // (two map arrays: the scan below ping-pongs)
         uint8_t *d_gtail = (uint8_t *)(d_comp2 + (size_t)n_groups * TL);
-        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr};
+        static const bool no_runs = getenv("RSN_LZSS_DEC_NO_RUNS") != nullptr;   // A/B switch: descriptors for every tile (no run tiles)
+        uint32_t *d_rt_cnt = nullptr, *d_rt_runs = nullptr;
+        if (!no_runs) {
+            rc = dev_buf(c, 23, (size_t)n_tiles * (RT_RUNS + 1) * 4 + 128, &p); if (rc) return rc;
+            d_rt_runs = (uint32_t *)p; d_rt_cnt = d_rt_runs + (size_t)n_tiles * RT_RUNS;
+        }
+        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr, d_rt_cnt, d_rt_runs};
         static const bool lzd_stats = getenv("RSN_LZD_STATS") != nullptr;
-        if (lzd_stats) { void *sp; rc = dev_buf(c, 23, 64, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 64, s)); ra.stats = (unsigned long long *)sp; }
+        if (lzd_stats) { void *sp; rc = dev_buf(c, 25, 64, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 64, s)); ra.stats = (unsigned long long *)sp; }
+        if (d_rt_cnt) RSN_LAUNCH("lzss_dec_runs", k_lzd_runs, dim3(n_tiles), dim3(64), 0, s, d_in, n, (const uint2 *)d_tinfo, n_tiles, E, TL, d_rt_cnt, d_rt_runs);
         RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
         if (lzd_stats) {
             unsigned long long hs[8];
@@ -1091,7 +1219,7 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             attr_tl = (size_t)TL * 4;
         }
         if (n_groups > 1) {
-            RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, dgrp, d_comp);
+            RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, dgrp, d_comp, (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);
             static const bool serial_chain = getenv("RSN_LZSS_DEC_SERIAL_CHAIN") != nullptr;   // A/B switch: one block walks the groups in order
             const uint32_t n_links = n_groups - 1;
             if (serial_chain) RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_links, d_gtail);
@@ -1108,7 +1236,8 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             *out_n = E;
             if (!d_out || E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
         }
-        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0);
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0,
+                   (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");   // k_lzd_check's verdict

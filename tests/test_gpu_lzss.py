@@ -353,6 +353,41 @@ def test_decode_front_end_in_one_pass(lz, oracle, monkeypatch):
     assert out.stdout.split()[-len(streams):] == [hashlib.sha256(w).hexdigest() for w in want]
 
 
+def test_decode_run_tiles(lz, oracle):
+    """Output tiles that hold nothing but a few tokens are resolved as intervals by k_lzd_runs (one wavefront per tile, no descriptors):
+    W-periodic data with tile-aligned and straddling tokens, periods that do not divide the tile, runs of one byte, run tiles next
+    to ordinary ones, tiles with more tokens than a run tile takes (32) or more resolved runs (64), hand-written streams whose tokens
+    copy pieces of several earlier tokens; and the same bytes without the path (RSN_LZSS_DEC_NO_RUNS) in a process of its own."""
+    import hashlib
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    rng = np.random.default_rng(21)
+    blk = rng.integers(97, 123, size=4096, dtype=np.uint8).tobytes()
+    datas = [blk * 40, blk[:1000] * 100, blk[:4095] * 30, blk[:37] * 3000, b"\x00" * 200000, text(5, 40000) + blk * 20 + text(6, 30000) + blk[:777] * 90,
+             (blk[:300] + b"Q") * 400, blk * 3 + blk[:2048] * 31]
+    streams = [oracle.lzss_compress(d) for d in datas]
+    lit = rng.integers(97, 123, size=20000, dtype=np.uint8).tobytes()
+    # hand-written: tokens that copy across earlier tokens' seams, 40 short tokens in one tile, a token of the full tile
+    streams += [lit + b"<4096,4096>" * 3 + b"<6000,4100>" + b"<100,100>" * 200 + b"<16384,16384>" * 4 + b"<3,3>" * 20000,
+                lit + (b"<9,9>" + b"<500,400>") * 300 + b"<16000,16000>" * 3,
+                lit[:16384] + b"<16384,8192>" + b"<8192,8192>" + b"<12288,12288>" + b"<4096,4096>" * 9 + b"x"]
+    want = [oracle.lzss_decompress(c) for c in streams]
+    for d, w in zip(datas, want):
+        assert d == w
+    assert [lz.Decompress(c) for c in streams] == want
+    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
+            "streams = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "print(' '.join(hashlib.sha256(lz.Decompress(c)).hexdigest() for c in streams))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump(streams, f)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=300, env=dict(os.environ, RSN_LZSS_DEC_NO_RUNS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-len(streams):] == [hashlib.sha256(w).hexdigest() for w in want]
+
+
 def test_decode_paths(lz, oracle):
     """The tile path (back-pointers <= 16384), its fallbacks, and streams only a foreign encoder writes."""
     data = text(41, 70000)
