@@ -903,11 +903,19 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
                 uint32_t lo = 0, hi = nr;
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((runs[mid] & 0xFFFFu) <= x0) lo = mid; else hi = mid; }
                 uint32_t r = (runs[lo] >> 16) + (x0 - (runs[lo] & 0xFFFFu)), nxt_x = lo + 1 < nr ? (runs[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu;
+                if (nxt_x >= x0 + 16) {
+                    // all 16 positions in one run (runs are thousands of bytes long): 16 consecutive bytes of the tail, five aligned dwords and a byte shift
+                    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(prev) + (r >> 2);
+                    const uint32_t d0_ = p32[0], d1_ = p32[1], d2_ = p32[2], d3_ = p32[3], d4_ = p32[4];
+                    o[0] = __builtin_amdgcn_alignbyte(d1_, d0_, r); o[1] = __builtin_amdgcn_alignbyte(d2_, d1_, r);   // (v_alignbyte uses r[1:0])
+                    o[2] = __builtin_amdgcn_alignbyte(d3_, d2_, r); o[3] = __builtin_amdgcn_alignbyte(d4_, d3_, r);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    if (x0 + (uint32_t)q == nxt_x) { lo++; r = runs[lo] >> 16; nxt_x = lo + 1 < nr ? (runs[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu; }
-                    o[q >> 2] |= (uint32_t)prev[r & D_PAY] << (8 * (q & 3));
-                    r++;
+                    for (int q = 0; q < 16; q++) {
+                        if (x0 + (uint32_t)q == nxt_x) { lo++; r = runs[lo] >> 16; nxt_x = lo + 1 < nr ? (runs[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu; }
+                        o[q >> 2] |= (uint32_t)prev[r & D_PAY] << (8 * (q & 3));
+                        r++;
+                    }
                 }
             } else {
 #pragma unroll
@@ -1236,8 +1244,8 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             *out_n = E;
             if (!d_out || E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
         }
-        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0,
-                   (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);
+        RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2 + 16, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0,
+                   (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);   // (+16: a run tile reads whole dwords of the tail, up to three bytes past it)
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");   // k_lzd_check's verdict
