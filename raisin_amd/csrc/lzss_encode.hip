@@ -1776,6 +1776,21 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
         return;
     }
     const bool periodic = tchain && tchain[blockIdx.x].walked == 2;     // a W-periodic tile of the chain walk: its keys are arithmetic, not stored
+    if (periodic && ccnt && tchain[blockIdx.x].pad == 1 && enc_len(W, W) < W && PT / W < (uint32_t)LB) {
+        // ... and so are its tokens (k_chain_periodic placed the chain: from `entry` in steps of W): a lane each, no flags, no staging.
+        // (Only when the chain walk's own parse was accepted -- ccnt is passed then: after the general parse the flags decide.)
+        const uint32_t entry = tchain[blockIdx.x].entry, t1 = min(base + (uint32_t)PT, E);
+        if (entry >= base && entry < t1) {
+            const uint32_t x = entry + (uint32_t)tid * W;
+            if (x >= entry && x < t1) {                                    // (x >= entry: no wrap-around)
+                const uint32_t L = min(W, E - x);                          // < W only for the stream's last token
+                uint8_t *o = out + run + (size_t)tid * enc_len(W, W);
+                if (enc_len(W, L) < L) { *o++ = '<'; o = put_dec(o, W); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
+                else for (uint32_t j = 0; j < L; j++) *o++ = fc[x + j];
+            }
+        }
+        return;
+    }
     auto key_at = [&](uint32_t p) { return periodic ? (min(W, E - p) << 16) | W : keys[p]; };
     for (int r = 0; r < PT / RP; r++) {
         const uint32_t rb = base + r * RP;
