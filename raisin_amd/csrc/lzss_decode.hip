@@ -772,7 +772,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (!__syncthreads_or(unres != 0)) break;
     }
     phase_done(3);
-    for (int v = tid; v * 8 < tlen; v += DTH) reinterpret_cast<uint4 *>(a.desc + ts)[v] = reinterpret_cast<const uint4 *>(sd)[v];
+    for (int v = tid; v * 8 < tlen; v += DTH) st16<(RSN_NT_MASK & 32) != 0>(reinterpret_cast<uint4 *>(a.desc + ts) + v, reinterpret_cast<const uint4 *>(sd)[v]);
     phase_done(4);
     if (a.stats && tid == 0) atomicAdd(&a.stats[5], (unsigned long long)rounds);
 }
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = g ? gtail[(size_t)(g - 1) * TL + j] : 0;
     const uint32_t x0 = threadIdx.x * 16;
     auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {                   // (a run tile has no descriptors in memory: nothing is loaded for it)
-        if (k < n_tiles && k * DT + x0 < E && !(rt_cnt && rt_cnt[k])) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = p[0]; a1 = p[1]; }
+        if (k < n_tiles && k * DT + x0 < E && !(rt_cnt && rt_cnt[k])) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = ld16<(RSN_NT_MASK & 64) != 0>(p); a1 = ld16<(RSN_NT_MASK & 64) != 0>(p + 1); }
     };
     uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, e0 = d0, e1 = d1;
     load(g * dgrp, d0, d1);

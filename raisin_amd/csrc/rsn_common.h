@@ -94,6 +94,7 @@ struct ProfScope {
 // Streaming (touched-once) global accesses as `nt` loads / stores.  Which of the headline kernels' streams use them is a
 // build-time A/B mask (Makefile: EXTRA=-DRSN_NT_MASK=<bits>, scripts/ab_nt.sh):
 //   1 k_byte_hist loads   2 k_emit_flat loads   4 k_emit_flat stores   8 k_dec_flat loads   16 k_dec_flat stores
+//   32 k_lzd_resolve's descriptor stores   64 k_lzd_emit's descriptor loads
 // Measured (r03, 1 GiB, step = encode + decode in a loop; gpurun_out/ab_nt*.txt): only bit 1 pays -- k_byte_hist
 // 0.231 -> 0.185 ms (5.8 TB/s) and the step 1.175 -> 1.137 ms.  The three kernels trade the write-back of the previous kernel's
 // dirty lines among themselves (nt stores in k_dec_flat: that kernel +0.05 ms, the histogram after it -0.035; nt loads in the
