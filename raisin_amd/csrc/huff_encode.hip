@@ -163,9 +163,41 @@ __device__ __forceinline__ uint32_t classify16(const uint8_t *__restrict__ in, s
     return mask & valid;
 }
 
+// The same runes from a START MAP (r03): k_rune_hist classifies every position once -- Go's accept ranges, 19 validity tests per lane --
+// and leaves the 16-bit start mask of every 16 positions; the two later passes over the input take the starts from the map.  A start
+// whose next start is L > 1 bytes on is a valid L-byte sequence by construction (only valid sequences consume bytes), one whose next
+// start is the next byte is an ASCII byte or an invalid one (U+FFFD): no tests, a shift and two masks per rune.
+__device__ __forceinline__ uint32_t runes16_from_map(const uint8_t *__restrict__ in, size_t n, size_t P, const uint16_t *__restrict__ smask, uint32_t rune[16]) {
+    uint32_t w[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) w[j] = load_word_clamped(in, n, (long long)P + 4 * j);
+    const uint32_t m = smask[P >> 4];
+    if (((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) rune[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        return m;
+    }
+    const uint32_t m32 = m | (P + 16 < n ? (uint32_t)smask[(P >> 4) + 1] << 16 : 0u);
+    auto B = [&](int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 0xFF; };   // i in [0, 19]
+    const uint32_t left = P < n ? (uint32_t)min((size_t)32, n - P) : 0u;   // bytes of the stream from P on (as far as it matters)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t rest = m32 >> (k + 1);
+        // bytes of the rune that starts at k: up to the next start, or -- no start within reach: the stream's last rune -- to the end of the stream
+        const uint32_t L = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (left > (uint32_t)k ? min(left - (uint32_t)k, 4u) : 1u);
+        const uint32_t b0 = B(k), b1 = B(k + 1), b2 = B(k + 2), b3 = B(k + 3);
+        uint32_t r = b0 < 0x80 ? b0 : kRuneError;                            // one byte: itself, or an invalid byte
+        if (L == 2) r = ((b0 & 0x1F) << 6) | (b1 & 0x3F);
+        else if (L == 3) r = ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F);
+        else if (L >= 4) r = ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
+        rune[k] = r;
+    }
+    return m;
+}
+
 // ---------------------------------------------------------------- K1r: rune histogram
 __global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in, size_t n,
-                                                  unsigned long long *__restrict__ ghist) {
+                                                  unsigned long long *__restrict__ ghist, uint16_t *__restrict__ smask) {
     // runes < 0x800 (ASCII, Latin, Greek, Cyrillic, Hebrew, Arabic ...): dense LDS bins.  The rest: a small
     // open-addressing table per block -- real text has a handful of them (quotes, dashes, currency signs),
     // each hot, and a global atomic per occurrence would serialise on a few L2 lines.  A full table (CJK
@@ -186,6 +218,7 @@ __global__ __launch_bounds__(HB) void k_rune_hist(const uint8_t *__restrict__ in
         if (P >= n) continue;
         uint32_t rune[16];
         const uint32_t m = classify16(in, n, P, rune);
+        if (smask) smask[P >> 4] = (uint16_t)m;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             if (!((m >> k) & 1)) continue;
@@ -227,7 +260,8 @@ __global__ __launch_bounds__(HB) void k_tile_bits(const uint32_t *__restrict__ t
 
 // K2r: rune path -- re-reads the tile, sums len[rune] over rune starts
 __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict__ in, size_t n, const uint8_t *__restrict__ rlen,
-                                                       uint32_t n_tiles, uint32_t tile, unsigned long long *__restrict__ tile_bits) {
+                                                       uint32_t n_tiles, uint32_t tile, unsigned long long *__restrict__ tile_bits,
+                                                       const uint16_t *__restrict__ smask) {   // the start map of k_rune_hist, or null: classify again
     __shared__ unsigned long long part[HB / 64];
     __shared__ uint8_t s_len[2048];                                // code lengths of the dense runes: an LDS read instead of a global gather
     const int tid = threadIdx.x;
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(HB) void k_tile_bits_rune(const uint8_t *__restrict
             const size_t P = (size_t)t * tile + (size_t)(k * HB + tid) * 16;
             if (P >= n) break;
             uint32_t rune[16];
-            const uint32_t m = classify16(in, n, P, rune);
+            const uint32_t m = smask ? runes16_from_map(in, n, P, smask, rune) : classify16(in, n, P, rune);
 #pragma unroll
             for (int j = 0; j < 16; j++) if ((m >> j) & 1) s += rune[j] < 0x800 ? s_len[rune[j]] : rlen[rune[j]];
         }
@@ -362,6 +396,7 @@ struct EmitArgs {
     uint32_t tiles_per_block, n_tiles;
     uint32_t *out_words;
     uint32_t tile;                       // input bytes per tile (TILE or SMALL_TILE)
+    const uint16_t *smask;               // RUNE: the start map of k_rune_hist (16 positions per entry), or null
 };
 
 // Per-lane bit packer into the block's LDS window (big-endian 32-bit words:
@@ -438,7 +473,7 @@ __global__ __launch_bounds__(HB) void k_emit(EmitArgs a) {
         uint32_t smask = 0, w4[4] = {0, 0, 0, 0};
         uint32_t mylen = 0;
         if (MODE == MODE_RUNE) {
-            smask = P < in1 ? classify16(a.in, a.n, P, rune) : 0;
+            smask = P < in1 ? (a.smask ? runes16_from_map(a.in, a.n, P, a.smask, rune) : classify16(a.in, a.n, P, rune)) : 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) if ((smask >> k) & 1) mylen += a.len8[rune[k]];
         } else {
@@ -780,7 +815,7 @@ __global__ void k_rune_table(const RuneCode *__restrict__ list, uint32_t k, unsi
 }
 
 int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint32_t n_tiles, uint32_t tile, uint32_t *d_tile_hist,
-                       std::vector<HuffSym> &syms, bool &ascii) {
+                       std::vector<HuffSym> &syms, bool &ascii, uint16_t **smask_out) {
     void *p;
     int rc = dev_buf(c, 1, 256 * 8, &p); if (rc) return rc;
     unsigned long long *d_gh = (unsigned long long *)p;
@@ -803,7 +838,11 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     unsigned long long *d_rh = (unsigned long long *)p;
     RSN_HIP(hipMemsetAsync(d_rh, 0, (size_t)kMaxRune * 8, s));
     const size_t rounds = ceil_div(n, ROUND);
-    RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh);
+    static const bool no_map = getenv("RSN_HUFF_NO_START_MAP") != nullptr;   // A/B switch: the later passes classify the input again
+    uint16_t *d_smask = nullptr;
+    if (!no_map) { rc = dev_buf(c, 26, (ceil_div(n, 16) + 2) * 2 + 64, &p); if (rc) return rc; d_smask = (uint16_t *)p; }
+    *smask_out = d_smask;
+    RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh, d_smask);
     // the present runes, compacted in rune order (see k_rune_flags)
     const size_t bound = std::min<size_t>(n, kMaxRune);                // distinct runes never exceed the input's bytes
     rc = dev_buf(c, 6, (size_t)kMaxRune * 16 + 16 + bound * sizeof(HuffSym) + 64, &p); if (rc) return rc;
@@ -856,7 +895,8 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
-    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, tile, d_tile_hist, syms, ascii); if (rc) return rc;
+    uint16_t *d_smask = nullptr;                                          // rune path: which positions start a rune (k_rune_hist's classification, kept)
+    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, tile, d_tile_hist, syms, ascii, &d_smask); if (rc) return rc;
     if (!ascii && !no_small_tiles && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
         tile = SMALL_TILE;
         n_tiles = (uint32_t)ceil_div(n, tile);
@@ -963,7 +1003,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     unsigned long long *d_tile_bits = (unsigned long long *)p;
     unsigned long long *d_tile_off = d_tile_bits + n_tiles;
     if (mode == MODE_RUNE) {
-        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, tile, d_tile_bits);
+        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, tile, d_tile_bits, (const uint16_t *)d_smask);
     } else {
         RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, d_tile_hist, d_len8, n_tiles, d_tile_bits);
     }
@@ -973,7 +1013,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const uint32_t tiles_per_block = (uint32_t)std::max<size_t>(1, ceil_div(n_tiles, 2048));
     const uint32_t n_blocks = (uint32_t)ceil_div(n_tiles, tiles_per_block);
     a.in = d_in; a.n = n; a.tile_off = d_tile_off; a.base_bits = base_bits;
-    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out; a.tile = tile;
+    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out; a.tile = tile; a.smask = d_smask;
     RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
                (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + codes.total_bits);
     RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
