@@ -538,7 +538,10 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         if gather_stuck:
-            os._exit(3)                 # a collective is still pending: leave without waiting for it, and say so
+            # a collective is still pending: leave without waiting for it.  The throughput line is out and says so (gather_ms null +
+            # gather_note); the exit code stays 0 -- the gather is extra information, and a failing code could cost the job its line.
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
