@@ -701,6 +701,26 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // the same value, but in a vector register and opaque to the compiler's uniformity analysis: what is computed from it is
 // computed by the vector units (this kernel is bound by the CU's one scalar unit)
 __device__ __forceinline__ uint32_t vec(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+// The same reductions over a ROW of LW = 16 or 32 lanes (k_match_chain with several chains per wavefront): every lane of the row gets the result.
+template <int LW>
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
+    static_assert(LW == 8 || LW == 16 || LW == 32, "half a DPP row, a row, or two");
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR1, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR2, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
+    if constexpr (LW >= 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_MIRROR, 0xF, 0xF, true));
+    if constexpr (LW == 32) v = max(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));   // lane ^ 16
+    return v;
+}
+template <int LW>
+__device__ __forceinline__ uint32_t row_ballot(bool p, int lane) {       // bit k: lane k of the caller's row
+    const unsigned long long b = __ballot(p) >> (lane & (64 - LW));
+    return LW == 32 ? (uint32_t)b : (uint32_t)b & ((1u << (LW & 31)) - 1u);
+}
+template <int LW>
+__device__ __forceinline__ uint32_t row_read(uint32_t v, uint32_t j, int lane) {   // v of lane j of the caller's row (j the same within the row)
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & (uint32_t)(64 - LW)) + j) << 2), (int)v);
+}
 
 // W-periodic tiles (config 3 is nothing else): fc[q] == fc[q - W] for every q the tile's matches can reach, so every position p has the
 // key (min(W, E-p), W) (see k_match).  Found by a pass of its own, straight from memory and without LDS -- inside k_match_chain the same
@@ -733,9 +753,18 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
     if (tid == 0) { tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0}; step[blockIdx.x] = 0; }
 }
 
-template <class C>
-__global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
-    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = C::CS, CH = C::CH, NS = C::NS;
+#ifndef RSN_CHAIN_ROW_CS
+#define RSN_CHAIN_ROW_CS 64                                               // a start every so many positions when a chain has a row of lanes
+#endif
+#ifndef RSN_CHAIN_NARROW
+#define RSN_CHAIN_NARROW 64
+#endif
+#ifndef RSN_CHAIN_HEAVY
+#define RSN_CHAIN_HEAVY 128
+#endif
+template <class C, int LW>
+__global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
+    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : RSN_CHAIN_ROW_CS, CH = C::CH, NS = C::NS;
     constexpr uint32_t OFFM = (1u << C::OFFB) - 1, TAGM = (1u << C::TAGB) - 1;
     __shared__ __attribute__((aligned(16))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream
     __shared__ __attribute__((aligned(16))) uint8_t s_pool[(HNB / 2) * 4 + NS * 2];   // the bucket index; later the two jump arrays of the in-tile parse
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];   // positions somebody has taken, relative to t0 - CH
     __shared__ unsigned long long s_present[256];                         // per byte value: the 2^CSH-position blocks of the stage it occurs in
     __shared__ uint32_t s_part[CTH / 64];
-    __shared__ uint32_t s_heavy, s_next, s_dense;
+    __shared__ uint32_t s_heavy, s_next, s_dense, s_votes;
     __shared__ uint32_t s_nstep, s_stepmin, s_stepmax;                    // commits whose match runs over its whole distance (L = distance >= HLMAX), and the range of those distances
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t E = a.E, W = a.W;
@@ -757,7 +786,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
 #ifdef RSN_CHAIN_STATS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-    uint32_t n_evals = 0, n_rounds = 0, n_ext = 0;
+    uint32_t n_evals = 0, n_rounds = 0, n_ext = 0, n_iter = 0, n_act = 0;
 #endif
     if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
     for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
     for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) s_claim[i] = 0;
     for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
-    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; s_nstep = 0; s_stepmin = 0xFFFFFFFFu; s_stepmax = 0; }
+    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; s_votes = 0; s_nstep = 0; s_stepmin = 0xFFFFFFFFu; s_stepmax = 0; }
     __syncthreads();
 
     // ---- group the staged positions by bigram (as k_match_hash): candidates are [rlo, rhi)
@@ -844,10 +873,11 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
     // advanced less than two positions per visit hands the strip to k_match_hash.
     // (64 visits: at 32, a few text tiles in every ten thousand -- two or three rare words in a row are a few dozen one-byte steps --
     //  gave up, and each such tile costs the stream a second look; noise gives up at 64 as surely as at 32)
-    constexpr uint32_t DENSE_EVALS = 64;
+    constexpr uint32_t DENSE_EVALS = 64, DENSE_VOTE = 8;
     constexpr uint32_t LONG_CAP = 8;                                      // candidates with a common prefix of HLMAX bytes and more that a visit follows through memory
     // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
     //  state machine and spends ~40 scalar instructions per visit on its masks, and scalar issue is this kernel's bound.)
+    if constexpr (LW == 64) {
     bool alive = true;
     uint32_t u_next = 0xFFFFFFFFu, visits = 0, from_kp = 0;               // where the chain in hand goes on; its visits and its start
     while (alive) {
@@ -1039,11 +1069,317 @@ __global__ __launch_bounds__(C::CTH) void k_match_chain(ChainArgs a) {
             }
         }
     }
+    } else {
+        // ---- the same walk with K = 64 / LW chains per wavefront.  This kernel is bound by vector issue (scripts/valu_probe.cpp: a wave64
+        //      integer VALU instruction holds its SIMD for ~4 cycles however many wavefronts share it; the walk's counters come to 3.4), and
+        //      a visit on text examines a dozen candidates (half the visits: eight or fewer): with a wavefront per chain most of those
+        //      instructions work on lanes that hold nothing, and the visit's fixed part -- claim, bucket bounds, the position's bytes, the
+        //      maximum, the store -- is paid per chain.  Here
+        //        1. each chain has a HOME ROW of LW lanes that does its bookkeeping (the rows diverge like threads do; what the wave version
+        //           calls u_* is the same within a row): claim a position, find the bucket, trim it to the window at both ends;
+        //        2. the candidates of all K visits are DEALT over the wavefront in rows of LW entries: row-slot s of round r takes the
+        //           (K r + s)-th row of the concatenated lists, whichever chain it belongs to (its parameters come from LDS), so a visit with
+        //           3 candidates and one with 300 cost 1 + 19 rows = 5 rounds, not 19; a row's maximum goes to its chain by an LDS atomic;
+        //        3. the home rows commit (and take the rare paths: long matches, no bigram match).
+        static_assert(LW == 16 || LW == 8, "a DPP row, or half of one, per chain");
+        constexpr int K = 64 / LW, NWV = CTH / 64;
+        constexpr uint32_t NARROW = RSN_CHAIN_NARROW;                        // a bucket is trimmed while it holds more entries than this
+        constexpr uint32_t HEAVY_ROWS = RSN_CHAIN_HEAVY / LW;                 // a visit with this many rows of candidates takes the whole wavefront
+        __shared__ __attribute__((aligned(16))) uint32_t s_par[NWV][K][8];   // a visit's parameters for the lanes its candidates are dealt to
+        __shared__ uint32_t s_best[NWV][K], s_lcnt[NWV][K], s_lfar[NWV][K];   // its maximum; its long candidates: how many, the farthest
+        __shared__ uint32_t s_llist[NWV][K][LONG_CAP][2];                     // ... and the first LONG_CAP of them (distance | limit << 16, bytes known equal)
+        const int rl = lane & (LW - 1), slot = lane / LW;                     // lane within the row; the row (= the home chain)
+        const bool leader = rl == 0;
+        if (leader) { s_best[wv][slot] = 0; s_lcnt[wv][slot] = 0; s_lfar[wv][slot] = 0; }
+        if (lane < K * 8) (&s_par[wv][0][0])[lane] = 0;
+        bool alive = true, voted = false;
+        uint32_t next = 0xFFFFFFFFu, visits = 0, from_kp = 0;
+        while (__ballot(alive)) {
+            // ---- 1. home rows: a position to evaluate -- where the chain in hand landed, unless that is somebody else's already (that row
+            //      walks the rest) or beyond the tile: then a new start, and the next one if that is taken too
+            uint32_t kp = next;
+            next = 0xFFFFFFFFu;
+            bool mine = false;
+            while (alive && !mine) {
+                if (kp >= kp_end) {
+                    uint32_t kq = 0;
+                    if (leader) kq = atomicAdd(&s_next, 1u);
+                    kq = row_read<LW>(kq, 0, lane);
+                    alive = kq < nitems;
+                    kp = kq == 0 ? kp_first : CH + (kq - 1) * CS;
+                    visits = 0; from_kp = kp;
+                }
+                if (alive) {
+                    uint32_t old = 0;
+                    if (leader) old = atomicOr(&s_claim[kp >> 5], 1u << (kp & 31));
+                    mine = row_ballot<LW>(leader && ((old >> (kp & 31)) & 1), lane) == 0;
+                }
+                if (!mine) kp = 0xFFFFFFFFu;
+            }
+            uint32_t nrows = 0, ipos = 0, irel = 0, capE = 0, b0 = 0, h = 0, tag = 0, lo = 0, hi = 0;
+            unsigned long long pat0 = 0;
+            if (mine) {
+                ipos = (uint32_t)(t0 - CH) + kp; irel = HWMAX + kp; capE = E - ipos;
+                b0 = sb[irel];
+                const uint32_t b1 = sb[irel + 1];
+                h = (b0 << 5) | (b1 & 31u); tag = (b1 >> 5) & TAGM;
+                lo = h ? (uint32_t)ends[h - 1] : 0u; hi = ends[h];
+                const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
+                pat0 = lds_load8(sw, irel + C::OFF0);
+                // the bucket's entries are ordered by block of 2^CSH positions: LW samples per trip trim the entries before the
+                // window's first block and those after the position's own
+                // (while it pays: a trip costs the wavefront about as much as two dealt rows)
+                bool narrowing = hi - lo > NARROW;
+                while (narrowing) {
+                    const uint32_t n = hi - lo, stride = (n + LW - 1) / LW;
+                    const uint32_t idx = min(lo + __umul24((uint32_t)rl, stride), hi - 1);
+                    const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
+                    const uint32_t in = row_ballot<LW>(blk >= blk_lo, lane), after = row_ballot<LW>(blk > blk_i, lane);
+                    const uint32_t first = in ? (uint32_t)__builtin_ctz(in) : (uint32_t)LW;   // samples below `first` lie before the window
+                    const uint32_t skip = max(first, 1u) - 1u;                                 // whole strides known to
+                    const uint32_t nlo = min(lo + __umul24(skip, stride), hi - 1);
+                    const uint32_t nhi = after ? min(lo + __umul24((uint32_t)__builtin_ctz(after), stride), hi - 1) : hi;   // that sample and everything behind it: after i
+                    narrowing = (nlo != lo || nhi != hi) && nhi - nlo > NARROW;
+                    lo = nlo; hi = max(nhi, nlo);
+                }
+                nrows = (hi - lo + LW - 1) / LW;
+            }
+            // ---- 2. the candidates
+            // one candidate per lane: its key L << 16 | distance (0: none).  c_*: the visit it belongs to, `ch` its chain.  A candidate that
+            // agrees with the position for HLMAX bytes and more -- further than the stage reaches -- is put on the chain's list: the home row
+            // follows up to LONG_CAP of them through memory (see the wave version); its key stays as the lower bound it is.
+            auto eval = [&](bool valid, uint32_t e, uint32_t c_irel, uint32_t c_tag, unsigned long long c_pat0, uint32_t c_capE, uint32_t ch, uint32_t &long_dn) -> uint32_t {
+                const uint32_t rel = e & OFFM, dn = c_irel - rel;
+                // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
+                const bool ok = valid && ((dn - 1u) | (((e >> C::OFFB) ^ c_tag) << 20)) < W;
+                uint32_t lim = 0, off = C::OFF0;
+                unsigned long long x = 1;
+                if (ok) {
+                    lim = min(dn, c_capE);                                    // entirely inside the window, and inside the stream
+                    x = lds_load8(sw, rel + off) ^ c_pat0;
+                    uint32_t room = x == 0 ? lim : 0u;
+                    while (off + 8 < room) {                                  // longer than eight bytes: this lane goes on, eight at a time
 #ifdef RSN_CHAIN_STATS
+                        n_ext++;
+#endif
+                        off += 8;
+                        x = lds_load8(sw, rel + off) ^ lds_load8(sw, c_irel + off);
+                        if (x != 0 || off + 8 >= HLMAX) room = 0;             // (the stage reaches HLMAX bytes past a position)
+                    }
+                }
+                const bool fl = x == 0 && off + 8 >= HLMAX;
+                long_dn = fl ? dn : 0u;
+                if (__ballot(fl)) {                                           // (runs and short periods: every candidate of a visit -- one atomic per row, not per lane)
+                    const uint32_t rm = row_ballot<LW>(fl, lane);
+                    if (rm) {
+                        const uint32_t far = row_max_u32<LW>(fl ? dn : 0u), first = (uint32_t)__builtin_ctz(rm);
+                        uint32_t k0 = 0;
+                        if ((uint32_t)rl == first) { k0 = atomicAdd(&s_lcnt[wv][ch], (uint32_t)__builtin_popcount(rm)); atomicMax(&s_lfar[wv][ch], far); }
+                        k0 = row_read<LW>(k0, first, lane);
+                        const uint32_t k = k0 + (uint32_t)__builtin_popcount(rm & ((1u << rl) - 1u));
+                        if (fl && k < LONG_CAP) { s_llist[wv][ch][k][0] = dn | (lim << 16); s_llist[wv][ch][k][1] = off + 8; }
+                    }
+                }
+                const uint32_t nb = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+                uint32_t len = min(off + nb, lim);
+                if (C::OFF0 < 2) len = len < 2 ? 0u : len;                    // the untagged bit of the second byte differed
+                return len ? (len << 16) | dn : 0u;                           // longest, then farthest back (bytes.Index, lzss.go:419)
+            };
+            // 2a. a visit with a bucketful of candidates (few-letter alphabets, runs, the common bigrams of text) takes the whole wavefront,
+            //     round after round, its parameters in scalar registers: dealt row by row each round would fetch them again
+            unsigned long long hm = __ballot(leader && nrows >= HEAVY_ROWS);
+            if (nrows >= HEAVY_ROWS) nrows = 0;
+            else if (mine && leader) {
+                *reinterpret_cast<uint4 *>(&s_par[wv][slot][0]) = uint4{irel, tag, (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
+                *reinterpret_cast<uint4 *>(&s_par[wv][slot][4]) = uint4{lo, hi, capE, 0u};
+            }
+            while (hm) {
+                const int hl = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl), c_tag = (uint32_t)__builtin_amdgcn_readlane((int)tag, hl),
+                               c_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, hl), c_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, hl),
+                               c_capE = (uint32_t)__builtin_amdgcn_readlane((int)capE, hl);
+                const unsigned long long c_pat0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pat0, hl) |
+                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pat0 >> 32), hl) << 32);
+                uint32_t wb = 0, n_long = 0, far = 0;
+                for (uint32_t base = c_lo; base < c_hi; base += 64) {
+#ifdef RSN_CHAIN_STATS
+                    n_rounds += K;
+#endif
+                    const uint32_t idx = base + (uint32_t)lane;
+                    const bool valid = idx < c_hi;
+                    const uint32_t e = s_list[valid ? idx : c_lo];
+                    uint32_t long_dn;
+                    wb = max(wb, eval(valid, e, c_irel, c_tag, c_pat0, c_capE, (uint32_t)hl / LW, long_dn));
+                    // Runs and short periods: thousands of candidates that all agree for HLMAX bytes and more.  Once more of them are known
+                    // than are followed up, only the farthest counts (see 3.), and the entries come farthest first, block by block: when
+                    // this round's last entry lies in a later block than the farthest long candidate, nothing behind it can matter.
+                    const unsigned long long lm = __ballot(long_dn != 0);
+                    if (lm) {
+                        n_long += (uint32_t)__builtin_popcountll(lm);
+                        far = max(far, wave_max_u32(long_dn));
+                        const uint32_t last_blk = ((uint32_t)__builtin_amdgcn_readlane((int)e, 63) & OFFM) >> CSH;   // (lane 63 holds the round's last entry, or re-reads the first: then the loop ends anyway)
+                        if (n_long > LONG_CAP && base + 64 < c_hi && last_blk > ((c_irel - far) >> CSH)) break;
+                    }
+                }
+                wb = wave_max_u32(wb);
+                if (lane == 0) s_best[wv][(uint32_t)hl / LW] = wb;
+            }
+            // 2b. the others, dealt in rows
+            uint32_t pre[K];                                                  // rows of chains 0 .. k together (wave-uniform)
+            pre[0] = (uint32_t)__builtin_amdgcn_readlane((int)nrows, 0);
+#pragma unroll
+            for (int k = 1; k < K; k++) pre[k] = pre[k - 1] + (uint32_t)__builtin_amdgcn_readlane((int)nrows, k * LW);
+            const uint32_t n_all = pre[K - 1];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g0 = 0; g0 < n_all; g0 += K) {
+#ifdef RSN_CHAIN_STATS
+                n_rounds++;
+#endif
+                const uint32_t g = g0 + (uint32_t)slot;
+                uint32_t ch, gbase;                                           // the chain whose row this is: how many of pre[0 .. K-2] are <= g, by bisection
+                if constexpr (K == 4) {
+                    const bool c1 = g >= pre[1];
+                    const uint32_t t = c1 ? pre[2] : pre[0];
+                    const bool c0 = g >= t;
+                    ch = (c1 ? 2u : 0u) + (c0 ? 1u : 0u);
+                    gbase = c0 ? t : (c1 ? pre[1] : 0u);
+                } else {
+                    const bool c2 = g >= pre[3];
+                    const uint32_t t1 = c2 ? pre[5] : pre[1];
+                    const bool c1 = g >= t1;
+                    const uint32_t ta = c1 ? pre[2] : pre[0], tb = c1 ? pre[6] : pre[4], t0q = c2 ? tb : ta;
+                    const bool c0 = g >= t0q;
+                    ch = (c2 ? 4u : 0u) + (c1 ? 2u : 0u) + (c0 ? 1u : 0u);
+                    gbase = c0 ? t0q : (c1 ? t1 : (c2 ? pre[3] : 0u));
+                }
+                const uint4 p0 = *reinterpret_cast<const uint4 *>(&s_par[wv][ch][0]), p1 = *reinterpret_cast<const uint4 *>(&s_par[wv][ch][4]);
+                const uint32_t idx = p1.x + (g - gbase) * LW + (uint32_t)rl;
+                const bool valid = g < n_all && idx < p1.y;
+                uint32_t long_dn;
+                const uint32_t key = eval(valid, s_list[valid ? idx : 0u], p0.x, p0.y, (unsigned long long)p0.z | ((unsigned long long)p0.w << 32), p1.z, ch, long_dn);
+                const uint32_t rbest = row_max_u32<LW>(key);
+                if (leader && rbest) atomicMax(&s_best[wv][ch], rbest);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3. home rows: commit
+            if (mine) {
+                uint32_t best = s_best[wv][slot];
+                const uint32_t lcnt = s_lcnt[wv][slot], long_far = s_lfar[wv][slot];
+                const bool longm = lcnt != 0;
+                if (leader) { s_best[wv][slot] = 0; if (longm) { s_lcnt[wv][slot] = 0; s_lfar[wv][slot] = 0; } }
+                // the first q in [from, lim) with fc[ipos + q] != fc[ipos - d + q], or lim: the row's lanes take eight bytes each per trip
+                auto first_diff = [&](uint32_t d, uint32_t from, uint32_t lim) -> uint32_t {
+                    const uint8_t *pa = a.fc + (size_t)ipos, *pb = pa - d;
+                    uint32_t mm = lim;
+                    for (uint32_t q = from + 8u * (uint32_t)rl; q < lim && mm == lim; q += 8u * LW) {
+                        if (q + 8 <= lim) {
+                            unsigned long long u, v;
+                            __builtin_memcpy(&u, pa + q, 8); __builtin_memcpy(&v, pb + q, 8);
+                            if (u != v) mm = q + ((uint32_t)__builtin_ctzll(u ^ v) >> 3);
+                        } else for (uint32_t k = q; k < lim && mm == lim; k++) if (pa[k] != pb[k]) mm = k;
+                    }
+                    return ~row_max_u32<LW>(~mm);
+                };
+                auto commit = [&](uint32_t key) {
+                    a.keys[ipos] = key;
+                    next = kp + max(1u, key >> 16);                           // lzss.go:139-142: a reference skips size-1 positions
+                    visits++;
+#ifdef RSN_CHAIN_STATS
+                    if (leader) n_evals++;
+#endif
+                };
+                if (best != 0 && !longm) commit(best);                        // the common case first
+                else {
+                    bool giveup_heavy = false, giveup_dense = false;
+                    if (longm) {
+                        if (lcnt <= LONG_CAP) {                               // every long candidate is followed to its end: the maximum is exact
+                            // (farthest first: a candidate at distance d matches d bytes at most, so once the best reaches further than the
+                            //  farthest one left, the rest cannot win -- a 1000-periodic stream follows one candidate over 4000 bytes, not four)
+                            uint32_t done = 0;
+                            for (uint32_t t = 0; t < lcnt; t++) {
+                                uint32_t pick = 0, dj = 0;
+                                for (uint32_t k = 0; k < lcnt; k++) {
+                                    const uint32_t d = s_llist[wv][slot][k][0] & 0xFFFFu;
+                                    if (!((done >> k) & 1u) && d > dj) { dj = d; pick = k; }
+                                }
+                                done |= 1u << pick;
+                                if ((best >> 16) > dj) break;
+                                best = max(best, (first_diff(dj, s_llist[wv][slot][pick][1], s_llist[wv][slot][pick][0] >> 16) << 16) | dj);
+                            }
+                        } else {                                              // (the wave version explains why the farthest long candidate decides)
+                            const uint32_t Lp = min(long_far, capE);
+                            const uint32_t mm = first_diff(long_far, 0, Lp);
+                            if (mm == Lp) best = max(best, (Lp << 16) | long_far);
+                            else {
+                                const uint32_t want = a.fc[(size_t)ipos + mm];
+                                const uint32_t blo = h ? (uint32_t)ends[h - 1] : 0u, bhi = ends[h];
+                                bool other = false;
+                                for (uint32_t idx = blo + rl; idx < bhi; idx += LW) {
+                                    const uint32_t e = s_list[idx], dn = irel - (e & OFFM);
+                                    const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ tag) << 20)) < W;
+                                    if (ok && dn > mm && dn <= ipos && a.fc[(size_t)ipos - dn + mm] == want) other = true;
+                                }
+                                if (row_ballot<LW>(other, lane)) giveup_heavy = true;
+                                else best = max(best, (mm << 16) | long_far);
+                            }
+                        }
+                    }
+                    if (best == 0 && !giveup_heavy) {                         // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
+                        // (with 64 / LW chains per wavefront the block has that many times the walkers: if each walked DENSE_EVALS visits
+                        //  before one gave up, the whole tile would have been evaluated by then.  A walker that looks dense after
+                        //  DENSE_VOTE visits says so once; a quarter of the walkers saying so is the tile's verdict.)
+                        if (!(a.redo & 1u) && bx != 0 && kp - from_kp < 2 * visits) {
+                            if (visits >= DENSE_EVALS) giveup_dense = true;
+                            else if (!voted && visits >= DENSE_VOTE) {
+                                voted = true;
+                                uint32_t v = 0;
+                                if (leader) v = atomicAdd(&s_votes, 1u) + 1u;
+                                giveup_dense = row_read<LW>(v, 0, lane) >= (uint32_t)(CTH / LW / 4);
+                            }
+                        }
+                        if (!giveup_dense) {
+                            const uint32_t ws = max(irel - min(W, irel), zrel);
+                            const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = irel >> CSH;
+                            bool hit = false;
+                            if (fb_lo < fb_hi) {
+                                const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
+                                hit = (s_present[b0] & m) != 0;
+                            }
+                            if (!hit) {                                       // the two ragged ends, byte by byte
+                                const uint32_t e1r = min(fb_lo << CSH, irel), s2 = max(min(fb_hi << CSH, irel), fb_lo < fb_hi ? ws : e1r);
+                                bool f = false;
+                                for (uint32_t q = ws + rl; q < e1r; q += LW) f = f || sb[q] == b0;
+                                for (uint32_t q = s2 + rl; q < irel; q += LW) f = f || sb[q] == b0;
+                                hit = row_ballot<LW>(f, lane) != 0;
+                            }
+                            best = hit ? (1u << 16) : 0u;
+                        }
+                    }
+                    if (longm && !giveup_heavy && (best >> 16) == (best & 0xFFFFu) && leader) {
+                        atomicAdd(&s_nstep, 1u); atomicMin(&s_stepmin, best & 0xFFFFu); atomicMax(&s_stepmax, best & 0xFFFFu);
+                    }
+                    if (giveup_heavy || giveup_dense) {
+                        if (leader) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
+                        alive = false;
+                    } else commit(best);
+                }
+            }
+#ifdef RSN_CHAIN_STATS
+            if (lane == 0) n_iter++;
+#endif
+        }
+    }
+#ifdef RSN_CHAIN_STATS
+    if (a.stats && (lane & (LW - 1)) == 0) {                               // (a row's leader counts for its chain)
+        atomicAdd(&a.stats[0], (unsigned long long)n_rounds); atomicAdd(&a.stats[1], (unsigned long long)n_evals); atomicAdd(&a.stats[2], (unsigned long long)n_ext);
+    }
     if (a.stats && lane == 0) {
         const unsigned long long st2 = __builtin_amdgcn_s_memtime();       // this wavefront is done
-        atomicAdd(&a.stats[0], (unsigned long long)n_rounds); atomicAdd(&a.stats[1], (unsigned long long)n_evals); atomicAdd(&a.stats[2], (unsigned long long)n_ext);
         atomicAdd(&a.stats[4], st1 - st0); atomicAdd(&a.stats[5], st2 - st1); atomicAdd(&a.stats[6], 1ull);
+        atomicAdd(&a.stats[3], (unsigned long long)n_iter); atomicAdd(&a.stats[7], (unsigned long long)n_act);
     }
 #endif
     __syncthreads();
@@ -1963,6 +2299,14 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
     using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
+    // lanes per chain in k_match_chain: 8 or 16 = eight or four chains per wavefront, 64 = a wavefront per chain (RSN_LZSS_CHAIN_LANES, A/B)
+    static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 ? v : 8; }();
+    auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
+        if (chain_lanes == 64) RSN_LAUNCH(name, (k_match_chain<CC, 64>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        else if (chain_lanes == 8) RSN_LAUNCH(name, (k_match_chain<CC, 8>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        else RSN_LAUNCH(name, (k_match_chain<CC, 16>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        return RSN_OK;
+    };
     uint8_t *d_dump = nullptr;
     uint32_t *d_clist = nullptr, *d_ccnt = nullptr;
     bool parsed_by_walk = false;                                      // the chain walk's own per-tile parse was accepted: its lists are valid
@@ -1993,7 +2337,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
         ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start}};
-        RSN_LAUNCH("lzss_sample", k_match_chain<CC>, dim3(SAMPLE_TILES), dim3(CC::CTH), 0, s, hs);
+        rc = launch_chain("lzss_sample", SAMPLE_TILES, hs); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         if ((uint32_t)h64[3] * 4 >= SAMPLE_TILES * 3) chain_mode = false;
@@ -2006,14 +2350,14 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
         ha.stats = (unsigned long long *)stp;
 #endif
-        RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3((uint32_t)ceil_div(E, CC::CT)), dim3(CC::CTH), 0, s, ha);
+        rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
 #ifdef RSN_CHAIN_STATS
         {
             unsigned long long hs[8];
             RSN_HIP(hipMemcpyAsync(hs, stp, 64, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
-            fprintf(stderr, "chain stats: rounds %llu evals %llu (%.3f per position) ext-steps %llu | waves %llu | cycles/wave: setup %.0f walk %.0f | rounds/eval %.2f\n",
-                    hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1]);
+            fprintf(stderr, "chain stats: rounds %llu evals %llu (%.3f per position) ext-steps %llu | waves %llu | cycles/wave: setup %.0f walk %.0f | rounds/eval %.2f | iterations %llu, rows at work %llu\n",
+                    hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1], hs[3], hs[7]);
         }
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
@@ -2101,7 +2445,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
             prev_plain = n_plain;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
-            RSN_LAUNCH("lzss_match_chain", k_match_chain<CC>, dim3(n_list), dim3(CC::CTH), 0, s, ha);
+            rc = launch_chain("lzss_match_chain", n_list, ha); if (rc) return rc;
             rc = resolve(true, use_pred); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
             if (dbg) fprintf(stderr, "lzss chain walk, look %d: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", look, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);

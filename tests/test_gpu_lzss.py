@@ -606,7 +606,9 @@ def test_chain_entry_fixed_by_second_look(lz, oracle):
         assert c == oracle.lzss_compress(data, 300)
         assert lz.Decompress(c) == data
         if _chain_mode() and "RSN_LZSS_NO_FUSED_PARSE" not in __import__("os").environ:
-            assert 2 <= p["lzss_match_chain"][0] <= 4 and "lzss_parse_mark" not in p, sorted(p)
+            # (with a wavefront per chain -- RSN_LZSS_CHAIN_LANES=64 -- every lead needs the second look; with eight chains per
+            #  wavefront and a start every 64 positions some of these joints come out right at once)
+            assert 1 <= p["lzss_match_chain"][0] <= 4 and "lzss_parse_mark" not in p, sorted(p)
 
 
 def test_decode_without_unescape_pass_and_its_capacity_contract(lz, oracle):
