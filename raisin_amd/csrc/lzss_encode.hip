@@ -1085,13 +1085,21 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         constexpr int K = 64 / LW, NWV = CTH / 64;
         constexpr uint32_t NARROW = RSN_CHAIN_NARROW;                        // a bucket is trimmed while it holds more entries than this
         constexpr uint32_t HEAVY_ROWS = RSN_CHAIN_HEAVY / LW;                 // a visit with this many rows of candidates takes the whole wavefront
-        __shared__ __attribute__((aligned(16))) uint32_t s_par[NWV][K][8];   // a visit's parameters for the lanes its candidates are dealt to
-        __shared__ uint32_t s_best[NWV][K], s_lcnt[NWV][K], s_lfar[NWV][K];   // its maximum; its long candidates: how many, the farthest
-        __shared__ uint32_t s_llist[NWV][K][LONG_CAP][2];                     // ... and the first LONG_CAP of them (distance | limit << 16, bytes known equal)
+        // a wavefront's scratch, one record (one base address in a register; the members are offsets in the LDS instructions)
+        struct WaveScratch {
+            uint32_t par[K][8];                                               // a visit's parameters for the lanes its candidates are dealt to
+            uint32_t best[K], lcnt[K], lfar[K];                               // its maximum; its long candidates: how many, the farthest
+            uint32_t nr[K];                                                   // rows of candidates each chain puts up for dealing this time
+            uint32_t llist[K][LONG_CAP][2];                                   // the first LONG_CAP long candidates (distance | limit << 16, bytes known equal)
+            uint16_t rowmap[K * (HEAVY_ROWS < 256 ? HEAVY_ROWS : 256)];       // dealt row -> chain << 8 | row of that chain (a chain with HEAVY_ROWS rows is not dealt)
+        };
+        __shared__ __attribute__((aligned(16))) WaveScratch s_ws[NWV];
+        WaveScratch &ws = s_ws[wv];
+        static_assert(HEAVY_ROWS <= 256 && K <= LW, "a row index fits a byte; the prefix sum runs within a row");
         const int rl = lane & (LW - 1), slot = lane / LW;                     // lane within the row; the row (= the home chain)
         const bool leader = rl == 0;
-        if (leader) { s_best[wv][slot] = 0; s_lcnt[wv][slot] = 0; s_lfar[wv][slot] = 0; }
-        if (lane < K * 8) (&s_par[wv][0][0])[lane] = 0;
+        if (leader) { ws.best[slot] = 0; ws.lcnt[slot] = 0; ws.lfar[slot] = 0; }
+        if (lane < K * 8) (&ws.par[0][0])[lane] = 0;
         bool alive = true, voted = false;
         uint32_t next = 0xFFFFFFFFu, visits = 0, from_kp = 0;
         while (__ballot(alive)) {
@@ -1116,13 +1124,14 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 }
                 if (!mine) kp = 0xFFFFFFFFu;
             }
-            uint32_t nrows = 0, ipos = 0, irel = 0, capE = 0, b0 = 0, h = 0, tag = 0, lo = 0, hi = 0;
+            // (what 3. needs of the position it works out again from kp: fewer registers live across the rounds -- the kernel has 64)
+            uint32_t nrows = 0, irel = 0, capE = 0, tag = 0, lo = 0, hi = 0;
             unsigned long long pat0 = 0;
             if (mine) {
-                ipos = (uint32_t)(t0 - CH) + kp; irel = HWMAX + kp; capE = E - ipos;
-                b0 = sb[irel];
-                const uint32_t b1 = sb[irel + 1];
-                h = (b0 << 5) | (b1 & 31u); tag = (b1 >> 5) & TAGM;
+                irel = HWMAX + kp; capE = E - ((uint32_t)(t0 - CH) + kp);
+                const uint32_t b0 = sb[irel], b1 = sb[irel + 1];
+                const uint32_t h = (b0 << 5) | (b1 & 31u);
+                tag = (b1 >> 5) & TAGM;
                 lo = h ? (uint32_t)ends[h - 1] : 0u; hi = ends[h];
                 const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
                 pat0 = lds_load8(sw, irel + C::OFF0);
@@ -1174,10 +1183,10 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     if (rm) {
                         const uint32_t far = row_max_u32<LW>(fl ? dn : 0u), first = (uint32_t)__builtin_ctz(rm);
                         uint32_t k0 = 0;
-                        if ((uint32_t)rl == first) { k0 = atomicAdd(&s_lcnt[wv][ch], (uint32_t)__builtin_popcount(rm)); atomicMax(&s_lfar[wv][ch], far); }
+                        if ((uint32_t)rl == first) { k0 = atomicAdd(&ws.lcnt[ch], (uint32_t)__builtin_popcount(rm)); atomicMax(&ws.lfar[ch], far); }
                         k0 = row_read<LW>(k0, first, lane);
                         const uint32_t k = k0 + (uint32_t)__builtin_popcount(rm & ((1u << rl) - 1u));
-                        if (fl && k < LONG_CAP) { s_llist[wv][ch][k][0] = dn | (lim << 16); s_llist[wv][ch][k][1] = off + 8; }
+                        if (fl && k < LONG_CAP) { ws.llist[ch][k][0] = dn | (lim << 16); ws.llist[ch][k][1] = off + 8; }
                     }
                 }
                 const uint32_t nb = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
@@ -1190,8 +1199,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             unsigned long long hm = __ballot(leader && nrows >= HEAVY_ROWS);
             if (nrows >= HEAVY_ROWS) nrows = 0;
             else if (mine && leader) {
-                *reinterpret_cast<uint4 *>(&s_par[wv][slot][0]) = uint4{irel, tag, (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
-                *reinterpret_cast<uint4 *>(&s_par[wv][slot][4]) = uint4{lo, hi, capE, 0u};
+                *reinterpret_cast<uint4 *>(&ws.par[slot][0]) = uint4{irel, tag, (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
+                *reinterpret_cast<uint4 *>(&ws.par[slot][4]) = uint4{lo, hi, capE, 0u};
             }
             while (hm) {
                 const int hl = __builtin_ctzll(hm);
@@ -1223,14 +1232,25 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     }
                 }
                 wb = wave_max_u32(wb);
-                if (lane == 0) s_best[wv][(uint32_t)hl / LW] = wb;
+                if (lane == 0) ws.best[(uint32_t)hl / LW] = wb;
             }
-            // 2b. the others, dealt in rows
-            uint32_t pre[K];                                                  // rows of chains 0 .. k together (wave-uniform)
-            pre[0] = (uint32_t)__builtin_amdgcn_readlane((int)nrows, 0);
+            // 2b. the others, dealt in rows.  Which chain a row belongs to comes from a table the home rows fill in: chain c's rows are
+            //     the entries [rows of chains 0 .. c-1 together, + its own).
+            uint32_t pre = 0;                                                 // lane k of every row: rows of chains 0 .. k together
+            if (leader) ws.nr[slot] = nrows;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            pre = ws.nr[rl & (K - 1)];
 #pragma unroll
-            for (int k = 1; k < K; k++) pre[k] = pre[k - 1] + (uint32_t)__builtin_amdgcn_readlane((int)nrows, k * LW);
-            const uint32_t n_all = pre[K - 1];
+            for (int d = 1; d < K; d <<= 1) {                                 // (K <= LW: a prefix sum within the row's first K lanes)
+                const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - d) << 2), (int)pre);
+                if ((rl & (K - 1)) >= d) pre += up;
+            }
+            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, K - 1);
+            {
+                const uint32_t mine0 = row_read<LW>(pre, (uint32_t)slot, lane) - nrows;   // rows of the chains before this one
+                for (uint32_t j = (uint32_t)rl; j < nrows; j += LW) ws.rowmap[mine0 + j] = (uint16_t)(((uint32_t)slot << 8) | j);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t g0 = 0; g0 < n_all; g0 += K) {
@@ -1238,38 +1258,24 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 n_rounds++;
 #endif
                 const uint32_t g = g0 + (uint32_t)slot;
-                uint32_t ch, gbase;                                           // the chain whose row this is: how many of pre[0 .. K-2] are <= g, by bisection
-                if constexpr (K == 4) {
-                    const bool c1 = g >= pre[1];
-                    const uint32_t t = c1 ? pre[2] : pre[0];
-                    const bool c0 = g >= t;
-                    ch = (c1 ? 2u : 0u) + (c0 ? 1u : 0u);
-                    gbase = c0 ? t : (c1 ? pre[1] : 0u);
-                } else {
-                    const bool c2 = g >= pre[3];
-                    const uint32_t t1 = c2 ? pre[5] : pre[1];
-                    const bool c1 = g >= t1;
-                    const uint32_t ta = c1 ? pre[2] : pre[0], tb = c1 ? pre[6] : pre[4], t0q = c2 ? tb : ta;
-                    const bool c0 = g >= t0q;
-                    ch = (c2 ? 4u : 0u) + (c1 ? 2u : 0u) + (c0 ? 1u : 0u);
-                    gbase = c0 ? t0q : (c1 ? t1 : (c2 ? pre[3] : 0u));
-                }
-                const uint4 p0 = *reinterpret_cast<const uint4 *>(&s_par[wv][ch][0]), p1 = *reinterpret_cast<const uint4 *>(&s_par[wv][ch][4]);
-                const uint32_t idx = p1.x + (g - gbase) * LW + (uint32_t)rl;
+                const uint32_t rm = ws.rowmap[g < n_all ? g : 0u], ch = rm >> 8;
+                const uint4 p0 = *reinterpret_cast<const uint4 *>(&ws.par[ch][0]), p1 = *reinterpret_cast<const uint4 *>(&ws.par[ch][4]);
+                const uint32_t idx = p1.x + (rm & 0xFFu) * LW + (uint32_t)rl;
                 const bool valid = g < n_all && idx < p1.y;
                 uint32_t long_dn;
                 const uint32_t key = eval(valid, s_list[valid ? idx : 0u], p0.x, p0.y, (unsigned long long)p0.z | ((unsigned long long)p0.w << 32), p1.z, ch, long_dn);
                 const uint32_t rbest = row_max_u32<LW>(key);
-                if (leader && rbest) atomicMax(&s_best[wv][ch], rbest);
+                if (leader && rbest) atomicMax(&ws.best[ch], rbest);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- 3. home rows: commit
             if (mine) {
-                uint32_t best = s_best[wv][slot];
-                const uint32_t lcnt = s_lcnt[wv][slot], long_far = s_lfar[wv][slot];
+                const uint32_t ipos = (uint32_t)(t0 - CH) + kp, irel = HWMAX + kp, capE = E - ipos;
+                uint32_t best = ws.best[slot];
+                const uint32_t lcnt = ws.lcnt[slot], long_far = ws.lfar[slot];
                 const bool longm = lcnt != 0;
-                if (leader) { s_best[wv][slot] = 0; if (longm) { s_lcnt[wv][slot] = 0; s_lfar[wv][slot] = 0; } }
+                if (leader) { ws.best[slot] = 0; if (longm) { ws.lcnt[slot] = 0; ws.lfar[slot] = 0; } }
                 // the first q in [from, lim) with fc[ipos + q] != fc[ipos - d + q], or lim: the row's lanes take eight bytes each per trip
                 auto first_diff = [&](uint32_t d, uint32_t from, uint32_t lim) -> uint32_t {
                     const uint8_t *pa = a.fc + (size_t)ipos, *pb = pa - d;
@@ -1302,12 +1308,12 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                             for (uint32_t t = 0; t < lcnt; t++) {
                                 uint32_t pick = 0, dj = 0;
                                 for (uint32_t k = 0; k < lcnt; k++) {
-                                    const uint32_t d = s_llist[wv][slot][k][0] & 0xFFFFu;
+                                    const uint32_t d = ws.llist[slot][k][0] & 0xFFFFu;
                                     if (!((done >> k) & 1u) && d > dj) { dj = d; pick = k; }
                                 }
                                 done |= 1u << pick;
                                 if ((best >> 16) > dj) break;
-                                best = max(best, (first_diff(dj, s_llist[wv][slot][pick][1], s_llist[wv][slot][pick][0] >> 16) << 16) | dj);
+                                best = max(best, (first_diff(dj, ws.llist[slot][pick][1], ws.llist[slot][pick][0] >> 16) << 16) | dj);
                             }
                         } else {                                              // (the wave version explains why the farthest long candidate decides)
                             const uint32_t Lp = min(long_far, capE);
@@ -1315,6 +1321,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                             if (mm == Lp) best = max(best, (Lp << 16) | long_far);
                             else {
                                 const uint32_t want = a.fc[(size_t)ipos + mm];
+                                const uint32_t b1 = sb[irel + 1], h = ((uint32_t)sb[irel] << 5) | (b1 & 31u), tag = (b1 >> 5) & TAGM;
                                 const uint32_t blo = h ? (uint32_t)ends[h - 1] : 0u, bhi = ends[h];
                                 bool other = false;
                                 for (uint32_t idx = blo + rl; idx < bhi; idx += LW) {
@@ -1344,6 +1351,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                             const uint32_t ws = max(irel - min(W, irel), zrel);
                             const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = irel >> CSH;
                             bool hit = false;
+                            const uint32_t b0 = sb[irel];
                             if (fb_lo < fb_hi) {
                                 const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
                                 hit = (s_present[b0] & m) != 0;
