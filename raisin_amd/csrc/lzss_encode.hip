@@ -766,7 +766,7 @@ template <class C, int LW>
 __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
     constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : RSN_CHAIN_ROW_CS, CH = C::CH, NS = C::NS;
     constexpr uint32_t OFFM = (1u << C::OFFB) - 1, TAGM = (1u << C::TAGB) - 1;
-    __shared__ __attribute__((aligned(16))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream
+    __shared__ __attribute__((aligned(1024))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream  (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
     __shared__ __attribute__((aligned(16))) uint8_t s_pool[(HNB / 2) * 4 + NS * 2];   // the bucket index; later the two jump arrays of the in-tile parse
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_pool);              // two 16-bit counters per word: counts, then starts, then ends
     uint16_t *s_list = reinterpret_cast<uint16_t *>(s_pool + (HNB / 2) * 4);   // staged offset | tag << OFFB, grouped by bucket
