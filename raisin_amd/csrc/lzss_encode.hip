@@ -431,8 +431,10 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // kernel-argument segment THERE instead of staying live across the chain walk.  The kernel must stay at or below
 // 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
-struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; uint32_t *step; const uint32_t *redo_start; };   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
+struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; uint32_t *step; const uint32_t *redo_start; uint32_t *ckeys, *ckn; };   // ckeys / ckn: the keys of a tile's claimed positions, in position order, and how many (k_chain_serial's input; may be null)   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
 struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
+constexpr uint32_t CK_EXIT = 0xFFFEu, CK_BROKEN = 0xFFFFu;           // a record's "next record" when the chain leaves the tile / lands on a position nobody evaluated
+constexpr uint32_t NO_LIST = 0xFFFFFFFFu;                            // ccnt[tile]: the tile has no compact key list (k_tok_emit reads its flags and keys); ckn[tile]: nor the claimed positions' keys
 __device__ __forceinline__ ChainTail chain_tail() {
     return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
 }
@@ -696,6 +698,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {       // the maxi
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false)); // rows 1 and 3 take in the row before
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false)); // rows 2 and 3 take in lane 31: lane 63 has it all
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// a barrier that orders the block's LDS traffic only: the loads from memory a thread has in flight stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   // lgkmcnt(0); vmcnt and expcnt untouched
+    __builtin_amdgcn_s_barrier();
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // the same value, but in a vector register and opaque to the compiler's uniformity analysis: what is computed from it is
@@ -1391,21 +1398,24 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     }
 #endif
     __syncthreads();
+    // (the thread's index once more, opaque to the compiler: or what the prologue derived from it is kept for the epilogue's loops and,
+    //  the walk needing every register, spilled across it)
+    const int etid = (int)vec((uint32_t)threadIdx.x), elane = etid & 63, ewv = etid >> 6;
     const ChainTail T = chain_tail();
-    if (tid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
-    if (tid == 0 && s_dense && !s_heavy) { T.dense[bx / (MATCH_STRIP / CT)] = 1; if (T.n_dense) atomicAdd(T.n_dense, 1u); }
-    if (s_heavy || s_dense) { if (tid == 0) { T.tchain[bx] = TileChain{0, 0, 0, 0}; T.step[bx] = 0; } return; }
+    if (etid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
+    if (etid == 0 && s_dense && !s_heavy) { T.dense[bx / (MATCH_STRIP / CT)] = 1; if (T.n_dense) atomicAdd(T.n_dense, 1u); }
+    if (s_heavy || s_dense) { if (etid == 0) { T.tchain[bx] = TileChain{0, 0, 0, 0}; T.step[bx] = 0; } return; }
     {   // Every visit of this tile a match over its whole distance, and the same distance d: the stretch repeats with a period that d is
         // the largest multiple of inside the window, every chain in it steps by d and keeps its phase -- the chains of neighbouring tiles
         // never join.  The tile says so (step = d): k_stretch_pred then places the true chain by arithmetic and the next look walks it.
-        if (s_nstep == 0 || s_stepmin != s_stepmax) { if (tid == 0) T.step[bx] = 0; }   // (text: no such visit at all -- nothing to count)
+        if (s_nstep == 0 || s_stepmin != s_stepmax) { if (etid == 0) T.step[bx] = 0; }   // (text: no such visit at all -- nothing to count)
         else {
             uint32_t cl = 0;
-            for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
+            for (int i = etid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
             for (int dd = 32; dd; dd >>= 1) cl += __shfl_down(cl, dd);
-            if (lane == 0) s_part[wv] = cl;
+            if (elane == 0) s_part[ewv] = cl;
             __syncthreads();
-            if (tid == 0) {
+            if (etid == 0) {
                 uint32_t all = 0;
                 for (int k = 0; k < CTH / 64; k++) all += s_part[k];
                 T.step[bx] = s_nstep == all ? s_stepmin : 0u;
@@ -1416,8 +1426,71 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
     {
         uint4 *dst = reinterpret_cast<uint4 *>(T.dump + (size_t)bx * C::DUMP_BYTES);
-        for (int i = tid; i < C::DUMP_BYTES / 16; i += CTH) dst[i] = reinterpret_cast<const uint4 *>(s_claim)[i];
-        if (tid == 0) T.tchain[bx] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
+        for (int i = etid; i < C::DUMP_BYTES / 16; i += CTH) dst[i] = reinterpret_cast<const uint4 *>(s_claim)[i];
+        if (etid == 0) T.tchain[bx] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
+    }
+    // ---- and for k_chain_serial, which follows the chain with one elane per tile: one record per claimed position, side by side in
+    //      position order -- its key, where it is, and WHICH RECORD the chain goes on with (the rank of the landing position among
+    //      the claims: a prefix popcount of the bitmap, here in LDS).  Through the position-indexed key array the elane would fetch
+    //      every line of it, 4 GB per GiB, for a fifth of their contents, and each step would wait for its load; the records it can
+    //      read a window ahead.  (The keys this block has just written come back from the L2.)
+    if (T.ckeys) {
+        constexpr int NWORDS = C::DUMP_BYTES / 4;
+        uint32_t *s_pre = s_cur;                                          // (the bucket index has served)
+        __syncthreads();
+        // (the keys first -- a thread takes every CTH-th position, its loads are all asked for before anything else: one round trip to the
+        //  L2 for the block, under the scan; a tile that turns out to have too many claims has read them for nothing)
+        constexpr int PER = (NWORDS * 32 + CTH - 1) / CTH;
+        const uint32_t *kb = a.keys + (t0 - CH);                              // (wave-uniform: a scalar base, 32-bit offsets)
+        uint32_t kv[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t kp = (uint32_t)etid + (uint32_t)j * CTH;
+            const bool on = kp < (uint32_t)NWORDS * 32u && ((s_claim[kp >> 5] >> (kp & 31)) & 1u);
+            kv[j] = on ? kb[kp] : 0xFFFFFFFFu;                                // (no key has a length of 65535)
+        }
+        {   // claims before every word of the bitmap: the first NWORDS / 64 wavefronts scan 64 words each, then add what lies before them
+            constexpr int NSW = (NWORDS + 63) / 64;
+            const int w = etid;
+            const uint32_t c = w < NWORDS ? (uint32_t)__builtin_popcount(s_claim[w]) : 0u;
+            uint32_t incl = c;
+            if (ewv < NSW) {
+                for (int dd = 1; dd < 64; dd <<= 1) {                         // (bpermute addresses from the opaque lane index: see above)
+                    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((elane - dd) << 2, (int)incl);
+                    if (elane >= dd) incl += y;
+                }
+                if (elane == 63) s_part[ewv] = incl;
+            }
+            lds_barrier();
+            if (ewv < NSW) {
+                uint32_t before = 0;
+                for (int k = 0; k < ewv; k++) before += s_part[k];
+                if (w < NWORDS) s_pre[w] = before + incl - c;
+                if (w == NWORDS - 1) s_pre[NWORDS] = before + incl;
+            }
+        }
+        lds_barrier();
+        const uint32_t total = s_pre[NWORDS];
+        const bool fits = total <= (uint32_t)CT / 2 && (s_claim[kp_first >> 5] >> (kp_first & 31)) & 1u;   // (8 bytes a record in a region of 4 CT)
+        if (fits) {
+            uint2 *ck = reinterpret_cast<uint2 *>(T.ckeys + (size_t)bx * CT);
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const uint32_t kp = (uint32_t)etid + (uint32_t)j * CTH, key = kv[j];
+                if (key != 0xFFFFFFFFu) {
+                    const uint32_t at = s_pre[kp >> 5] + (uint32_t)__builtin_popcount(s_claim[kp >> 5] & ((1u << (kp & 31)) - 1u));
+                    const uint32_t kp2 = kp + max(1u, key >> 16);
+                    uint32_t nr = CK_EXIT;                                // the chain leaves the tile
+                    if (kp2 < kp_end) {
+                        const uint32_t cw = s_claim[kp2 >> 5];
+                        nr = (cw >> (kp2 & 31)) & 1u ? s_pre[kp2 >> 5] + (uint32_t)__builtin_popcount(cw & ((1u << (kp2 & 31)) - 1u)) : CK_BROKEN;
+                    }
+                    ck[at] = uint2{key, (kp << 16) | nr};
+                }
+            }
+        }
+        if (etid == 0)   // the number of records, and the record of the warm-up start
+            T.ckn[bx] = fits ? total | ((s_pre[kp_first >> 5] + (uint32_t)__builtin_popcount(s_claim[kp_first >> 5] & ((1u << (kp_first & 31)) - 1u))) << 16) : NO_LIST;
     }
 }
 
@@ -1432,7 +1505,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
 // CAP = claimed positions the block has room for.  Two instantiations run back to back: CAP = half of all positions
 // (34 KB of LDS, four blocks per CU) resolves every ordinary tile; a tile with more claims than that -- a stretch of
 // one- and two-byte steps -- is left to the second, full-size one (64 KB), which returns at once everywhere else.
-constexpr uint32_t NO_LIST = 0xFFFFFFFFu;                            // ccnt[tile]: the tile has no compact key list (k_tok_emit reads its flags and keys)
 template <class C, int CAP>
 __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ dump, const uint32_t *__restrict__ keys, uint32_t E,
                                                     TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
@@ -1549,13 +1621,81 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
 template <class C>
 __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict__ keys, uint32_t E, uint32_t n_tiles, TileChain *__restrict__ tchain,
                                                      uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
-                                                     uint32_t *__restrict__ clist, uint32_t *__restrict__ ccnt) {
+                                                     uint32_t *clist, uint32_t *__restrict__ ccnt, const uint32_t *__restrict__ ckn) {
     constexpr uint32_t CT = C::CT, CH = C::CH, WORDS = CT / 32;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= n_tiles) return;
-    const TileChain tc = tchain[k];
-    if (tc.walked != 1 || tc.exit != 0) return;                           // periodic / dense / heavy tile, or resolved by an earlier launch
+    const int lane = threadIdx.x;
+    TileChain tc = {0, 0, 0, 0};
+    if (k < n_tiles) tc = tchain[k];
+    bool todo = k < n_tiles && tc.walked == 1 && tc.exit == 0;            // (not: periodic / dense / heavy tile, or resolved by an earlier launch)
     const unsigned long long t0 = (unsigned long long)k * CT, t1 = min(t0 + CT, (unsigned long long)E);
+    // ---- from k_match_chain's records (see its epilogue): record r holds the chain's key there, the position and the next record.
+    // The 64 lanes are on 64 tiles, and a load that one of them waits for stalls them all: so all of them stage a WINDOW of records
+    // in LDS at the same time (one wait per window), then step through their windows until each has left its own.  The chain's own
+    // keys go back into the same region from its start, 4 bytes for every 8 read: the write cursor stays behind the read cursor.
+    const uint32_t cn = (todo && ckn && clist) ? ckn[k] : NO_LIST;
+    bool active = cn != NO_LIST;
+    if (__any(active)) {
+        constexpr uint32_t WIN = 32;
+        __shared__ uint2 s_win[WIN][64];
+        const uint4 *cg = reinterpret_cast<const uint4 *>(clist + (size_t)(k < n_tiles ? k : 0) * CT);   // two records a load; the region holds CT / 2
+        uint32_t *cl = clist + (size_t)(k < n_tiles ? k : 0) * CT;
+        uint32_t *fw = flags + (size_t)(k < n_tiles ? k : 0) * WORDS;
+        uint32_t r = active ? cn >> 16 : 0u, rbase = 0, entry = 0xFFFFFFFFu, exit_kp = 0;
+        uint32_t wi = 0, word = 0, n_on = 0;
+        uint4 pend = {0, 0, 0, 0}, pend2 = {0, 0, 0, 0};
+        unsigned long long bytes = 0;
+        bool ok = true;
+        while (__any(active)) {
+            if (active) {
+                rbase = r & ~1u;
+                uint4 ld[WIN / 2];
+#pragma unroll
+                for (uint32_t j = 0; j < WIN / 2; j++) ld[j] = cg[min(rbase / 2 + j, CT / 4 - 1)];
+#pragma unroll
+                for (uint32_t j = 0; j < WIN / 2; j++) { s_win[2 * j][lane] = uint2{ld[j].x, ld[j].y}; s_win[2 * j + 1][lane] = uint2{ld[j].z, ld[j].w}; }
+            }
+            while (__any(active && r - rbase < WIN)) {
+                if (active && r - rbase < WIN) {
+                    const uint2 e = s_win[r - rbase][lane];
+                    const uint32_t key = e.x, L = key >> 16, kp = e.y >> 16, nr = e.y & 0xFFFFu;
+                    if (kp >= CH) {
+                        if (entry == 0xFFFFFFFFu) entry = kp;
+                        const uint32_t q = kp - CH;
+                        while (wi < (q >> 5)) { fw[wi++] = word; word = 0; }  // (every word of the tile is written exactly once, in order)
+                        word |= 1u << (q & 31);
+                        const uint32_t sl = n_on & 7u;
+                        if (sl == 0) pend.x = key; else if (sl == 1) pend.y = key; else if (sl == 2) pend.z = key; else if (sl == 3) pend.w = key;
+                        else if (sl == 4) pend2.x = key; else if (sl == 5) pend2.y = key; else if (sl == 6) pend2.z = key; else pend2.w = key;
+                        n_on++;
+                        if (sl == 7) { *reinterpret_cast<uint4 *>(cl + n_on - 8) = pend; *reinterpret_cast<uint4 *>(cl + n_on - 4) = pend2; }
+                        const uint32_t el = enc_len(key & 0xFFFFu, L);
+                        bytes += L == 0 ? 1u : (el < L ? el : L);             // lzss.go:143
+                    }
+                    if (nr >= CK_EXIT) { active = false; ok = nr == CK_EXIT; exit_kp = kp + max(1u, L); }
+                    else r = nr;
+                }
+            }
+        }
+        if (cn != NO_LIST) {
+            if (ok) {
+                while (wi < WORDS) { fw[wi++] = word; word = 0; }
+                tile_bytes[k] = bytes;
+                if (n_on & 7u) {
+                    *reinterpret_cast<uint4 *>(cl + (n_on & ~7u)) = pend;
+                    if ((n_on & 7u) > 4) *reinterpret_cast<uint4 *>(cl + (n_on & ~7u) + 4) = pend2;
+                }
+                if (ccnt) ccnt[k] = n_on;
+                if (entry == 0xFFFFFFFFu) entry = exit_kp;                    // (the chain jumps over what is left of the stream: as below, the landing position)
+                tchain[k] = TileChain{(uint32_t)(t0 - CH) + entry, (uint32_t)(t0 - CH) + exit_kp, 1u, 0u};
+                todo = false;
+            } else {                                                      // (cannot happen for a tile that was walked to the end; the keys decide)
+                if (ccnt) ccnt[k] = NO_LIST;
+                clist = nullptr; ccnt = nullptr;                          // the region no longer holds what the list form would read: flags only
+            }
+        }
+    }
+    if (!todo) return;
     unsigned long long p = t0 - CH + tc.pad;                              // the warm-up start (position 0 in tile 0)
     // keys come in aligned groups of four (one 16-byte load); a short step often stays inside the group it has
     uint4 grp = {0, 0, 0, 0};
@@ -2344,7 +2484,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
-        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start}};
+        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
         rc = launch_chain("lzss_sample", SAMPLE_TILES, hs); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -2352,7 +2492,21 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     }
     if (chain_mode) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
-        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start}};
+        // k_chain_serial's compact key lists (k_tok_emit's input where a tile has one): in the memory the general parse would use for its
+        // exits -- the lists are read only if that parse never runs.  RSN_LZSS_NO_LIST: always the flag form (A/B).  Where k_chain_serial
+        // will run, k_match_chain leaves it the claimed positions' keys in the same memory (RSN_LZSS_NO_CKEYS: it reads the key array).
+        static const bool no_list = getenv("RSN_LZSS_NO_LIST") != nullptr, no_ckeys = getenv("RSN_LZSS_NO_CKEYS") != nullptr;
+        static const bool tail_doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr, tail_serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;
+        uint32_t *d_ckn = nullptr;
+        if (!no_list) {
+            void *lp; rc = dev_buf(c, 11, std::max((size_t)E * 2, (size_t)n_pt * PT * 4) + 64, &lp); if (rc) return rc;
+            d_clist = (uint32_t *)lp;
+            rc = dev_buf(c, 27, (size_t)n_pt * 8 + 64, &lp); if (rc) return rc;
+            d_ccnt = (uint32_t *)lp;
+            RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
+            if (!no_ckeys && !tail_doubling && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
+        }
+        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
@@ -2369,16 +2523,6 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         }
 #endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
-        // k_chain_serial's compact key lists (k_tok_emit's input where a tile has one): in the memory the general parse would use for its
-        // exits -- the lists are read only if that parse never runs.  RSN_LZSS_NO_LIST: always the flag form (A/B).
-        static const bool no_list = getenv("RSN_LZSS_NO_LIST") != nullptr;
-        if (!no_list) {
-            void *lp; rc = dev_buf(c, 11, std::max((size_t)E * 2, (size_t)n_pt * PT * 4) + 64, &lp); if (rc) return rc;
-            d_clist = (uint32_t *)lp;
-            rc = dev_buf(c, 27, (size_t)n_pt * 4 + 64, &lp); if (rc) return rc;
-            d_ccnt = (uint32_t *)lp;
-            RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 4, s));
-        }
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
         void *pp; rc = dev_buf(c, 25, (size_t)n_prev * 4 + 64, &pp); if (rc) return rc;
@@ -2402,7 +2546,8 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 //  lane would wait for; the serial kernel then finds the tile resolved)
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
-                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes, d_clist, d_ccnt);
+                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes, d_clist, d_ccnt,
+                           (const uint32_t *)d_ckn);
             }
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
             if (n_prev > 1) RSN_LAUNCH("lzss_chain_prev", k_prev_fix, dim3(n_prev), dim3(1024), 0, s, d_entry, n_pt, (const uint32_t *)d_prev_part);
@@ -2453,6 +2598,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
             prev_plain = n_plain;
             ha.redo = 3; ha.tail.redo_list = d_redo_list;
+            ha.tail.ckeys = nullptr; ha.tail.ckn = nullptr;                   // (a look's tiles are resolved by k_chain_tail, from the key array)
             rc = launch_chain("lzss_match_chain", n_list, ha); if (rc) return rc;
             rc = resolve(true, use_pred); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
