@@ -433,7 +433,10 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
 struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; uint32_t *step; const uint32_t *redo_start; uint32_t *ckeys, *ckn; };   // ckeys / ckn: the keys of a tile's claimed positions, in position order, and how many (k_chain_serial's input; may be null)   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
 struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
-constexpr uint32_t CK_EXIT = 0xFFFEu, CK_BROKEN = 0xFFFFu;           // a record's "next record" when the chain leaves the tile / lands on a position nobody evaluated
+// k_match_chain's record of a claimed position: .x its key, .y = next record (14 bits) | position from t0 - CH (14 bits) << 14
+// (what the position puts into the output -- a token's text or the bytes themselves -- is worked out by the reader: here it would cost
+//  the walk's kernel what it saves the reader)
+constexpr uint32_t CK_EXIT = 0x3FFEu, CK_BROKEN = 0x3FFFu;           // "next record" when the chain leaves the tile / lands on a position nobody evaluated
 constexpr uint32_t NO_LIST = 0xFFFFFFFFu;                            // ccnt[tile]: the tile has no compact key list (k_tok_emit reads its flags and keys); ckn[tile]: nor the claimed positions' keys
 __device__ __forceinline__ ChainTail chain_tail() {
     return *(const ChainTail *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, tail));
@@ -1485,7 +1488,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                         const uint32_t cw = s_claim[kp2 >> 5];
                         nr = (cw >> (kp2 & 31)) & 1u ? s_pre[kp2 >> 5] + (uint32_t)__builtin_popcount(cw & ((1u << (kp2 & 31)) - 1u)) : CK_BROKEN;
                     }
-                    ck[at] = uint2{key, (kp << 16) | nr};
+                    ck[at] = uint2{key, nr | (kp << 14)};
                 }
             }
         }
@@ -1618,16 +1621,23 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
 // The lane also leaves the keys it met inside the tile, in chain order, as a compact list (clist[tile * CT ..], ccnt[tile] entries): what
 // k_tok_emit needs of the 4 bytes per position of the key array is these -- one position in six on text -- and their positions follow
 // from the tile's entry by adding up max(1, L).
+#ifndef RSN_SERIAL_WIN
+#define RSN_SERIAL_WIN 32                                                 // records a lane stages at a time
+#endif
+#ifndef RSN_SERIAL_TILES
+#define RSN_SERIAL_TILES 64                                               // tiles per wavefront (fewer: more wavefronts in flight, emptier)
+#endif
 template <class C>
 __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict__ keys, uint32_t E, uint32_t n_tiles, TileChain *__restrict__ tchain,
                                                      uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
                                                      uint32_t *clist, uint32_t *__restrict__ ccnt, const uint32_t *__restrict__ ckn) {
     constexpr uint32_t CT = C::CT, CH = C::CH, WORDS = CT / 32;
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t k = blockIdx.x * RSN_SERIAL_TILES + threadIdx.x;
     const int lane = threadIdx.x;
     TileChain tc = {0, 0, 0, 0};
-    if (k < n_tiles) tc = tchain[k];
-    bool todo = k < n_tiles && tc.walked == 1 && tc.exit == 0;            // (not: periodic / dense / heavy tile, or resolved by an earlier launch)
+    const bool in_range = k < n_tiles && threadIdx.x < RSN_SERIAL_TILES;
+    if (in_range) tc = tchain[k];
+    bool todo = in_range && tc.walked == 1 && tc.exit == 0;            // (not: periodic / dense / heavy tile, or resolved by an earlier launch)
     const unsigned long long t0 = (unsigned long long)k * CT, t1 = min(t0 + CT, (unsigned long long)E);
     // ---- from k_match_chain's records (see its epilogue): record r holds the chain's key there, the position and the next record.
     // The 64 lanes are on 64 tiles, and a load that one of them waits for stalls them all: so all of them stage a WINDOW of records
@@ -1636,14 +1646,14 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
     const uint32_t cn = (todo && ckn && clist) ? ckn[k] : NO_LIST;
     bool active = cn != NO_LIST;
     if (__any(active)) {
-        constexpr uint32_t WIN = 32;
+        constexpr uint32_t WIN = RSN_SERIAL_WIN;
         __shared__ uint2 s_win[WIN][64];
+        __shared__ uint32_t s_out[8][64];
         const uint4 *cg = reinterpret_cast<const uint4 *>(clist + (size_t)(k < n_tiles ? k : 0) * CT);   // two records a load; the region holds CT / 2
         uint32_t *cl = clist + (size_t)(k < n_tiles ? k : 0) * CT;
         uint32_t *fw = flags + (size_t)(k < n_tiles ? k : 0) * WORDS;
         uint32_t r = active ? cn >> 16 : 0u, rbase = 0, entry = 0xFFFFFFFFu, exit_kp = 0;
         uint32_t wi = 0, word = 0, n_on = 0;
-        uint4 pend = {0, 0, 0, 0}, pend2 = {0, 0, 0, 0};
         unsigned long long bytes = 0;
         bool ok = true;
         while (__any(active)) {
@@ -1658,21 +1668,24 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
             while (__any(active && r - rbase < WIN)) {
                 if (active && r - rbase < WIN) {
                     const uint2 e = s_win[r - rbase][lane];
-                    const uint32_t key = e.x, L = key >> 16, kp = e.y >> 16, nr = e.y & 0xFFFFu;
+                    const uint32_t key = e.x, kp = (e.y >> 14) & 0x3FFFu, nr = e.y & 0x3FFFu;
                     if (kp >= CH) {
                         if (entry == 0xFFFFFFFFu) entry = kp;
                         const uint32_t q = kp - CH;
                         while (wi < (q >> 5)) { fw[wi++] = word; word = 0; }  // (every word of the tile is written exactly once, in order)
                         word |= 1u << (q & 31);
-                        const uint32_t sl = n_on & 7u;
-                        if (sl == 0) pend.x = key; else if (sl == 1) pend.y = key; else if (sl == 2) pend.z = key; else if (sl == 3) pend.w = key;
-                        else if (sl == 4) pend2.x = key; else if (sl == 5) pend2.y = key; else if (sl == 6) pend2.z = key; else pend2.w = key;
+                        // (eight keys at a time, two 16-byte stores -- see below; they wait in LDS: picking one of eight registers by a
+                        //  lane's own count is a tree of branches that every lane walks)
+                        s_out[n_on & 7u][lane] = key;
                         n_on++;
-                        if (sl == 7) { *reinterpret_cast<uint4 *>(cl + n_on - 8) = pend; *reinterpret_cast<uint4 *>(cl + n_on - 4) = pend2; }
-                        const uint32_t el = enc_len(key & 0xFFFFu, L);
+                        if ((n_on & 7u) == 0) {
+                            *reinterpret_cast<uint4 *>(cl + n_on - 8) = uint4{s_out[0][lane], s_out[1][lane], s_out[2][lane], s_out[3][lane]};
+                            *reinterpret_cast<uint4 *>(cl + n_on - 4) = uint4{s_out[4][lane], s_out[5][lane], s_out[6][lane], s_out[7][lane]};
+                        }
+                        const uint32_t L = key >> 16, el = enc_len(key & 0xFFFFu, L);
                         bytes += L == 0 ? 1u : (el < L ? el : L);             // lzss.go:143
                     }
-                    if (nr >= CK_EXIT) { active = false; ok = nr == CK_EXIT; exit_kp = kp + max(1u, L); }
+                    if (nr >= CK_EXIT) { active = false; ok = nr == CK_EXIT; exit_kp = kp + max(1u, key >> 16); }
                     else r = nr;
                 }
             }
@@ -1682,8 +1695,8 @@ __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict_
                 while (wi < WORDS) { fw[wi++] = word; word = 0; }
                 tile_bytes[k] = bytes;
                 if (n_on & 7u) {
-                    *reinterpret_cast<uint4 *>(cl + (n_on & ~7u)) = pend;
-                    if ((n_on & 7u) > 4) *reinterpret_cast<uint4 *>(cl + (n_on & ~7u) + 4) = pend2;
+                    *reinterpret_cast<uint4 *>(cl + (n_on & ~7u)) = uint4{s_out[0][lane], s_out[1][lane], s_out[2][lane], s_out[3][lane]};
+                    if ((n_on & 7u) > 4) *reinterpret_cast<uint4 *>(cl + (n_on & ~7u) + 4) = uint4{s_out[4][lane], s_out[5][lane], s_out[6][lane], s_out[7][lane]};
                 }
                 if (ccnt) ccnt[k] = n_on;
                 if (entry == 0xFFFFFFFFu) entry = exit_kp;                    // (the chain jumps over what is left of the stream: as below, the landing position)
@@ -2546,7 +2559,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
                 //  lane would wait for; the serial kernel then finds the tile resolved)
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(1), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
-                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, 64)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes, d_clist, d_ccnt,
+                RSN_LAUNCH("lzss_chain_tail", k_chain_serial<CC>, dim3((uint32_t)ceil_div(n_pt, RSN_SERIAL_TILES)), dim3(64), 0, s, d_keys, E, n_pt, d_tchain, d_flags, d_tbytes, d_clist, d_ccnt,
                            (const uint32_t *)d_ckn);
             }
             RSN_LAUNCH("lzss_chain_prev", k_prev_walked, dim3(n_prev), dim3(1024), 0, s, d_tchain, n_pt, d_entry, d_prev_part);
