@@ -522,7 +522,10 @@ def test_chain_periodic_stretches_between_text(lz, oracle):
 def test_chain_vs_allpos_switch(oracle):
     """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes, and so does the in-tile parse by
     one lane per tile (RSN_LZSS_TAIL_SERIAL: what streams of 256 MiB and more take; below, a block per tile does
-    it): separate processes, the switches are read once."""
+    it) -- through the records k_match_chain leaves it and, RSN_LZSS_NO_CKEYS, through the key array -- and the chain
+    walk with a wavefront or a row of 16 lanes per chain instead of 8 (RSN_LZSS_CHAIN_LANES): separate processes,
+    the switches are read once.  The input has text, long copies, runs and a short period in it (the walk's long-match
+    paths: candidates followed through memory, the early end of a bucketful visit)."""
     import os
     import subprocess
     import sys
@@ -530,15 +533,18 @@ def test_chain_vs_allpos_switch(oracle):
             "from raisin_amd import lz\n"
             "import hashlib\n"
             "from tests.test_gpu_lzss import text, long_copies\n"
-            "d = text(5, 150000) + long_copies(4, 60000)\n"
+            "d = text(5, 150000) + long_copies(4, 60000) + b'ab' * 9000 + bytes(20000) + text(6, 30000) + b'xyz' * 7000 + text(7, 9000)\n"
             "print(hashlib.sha256(lz.CompressAsync(d)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"RSN_LZSS_ALLPOS": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1"}):
+    envs = ({}, {"RSN_LZSS_ALLPOS": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1", "RSN_LZSS_NO_CKEYS": "1"},
+            {"RSN_LZSS_CHAIN_LANES": "64"}, {"RSN_LZSS_CHAIN_LANES": "16", "RSN_LZSS_TAIL_SERIAL": "1"})
+    for env in envs:
         e = dict(os.environ); e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
     import hashlib
-    d = text(5, 150000) + long_copies(4, 60000)
-    assert outs[0] == outs[1] == outs[2] == hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
+    d = text(5, 150000) + long_copies(4, 60000) + b"ab" * 9000 + bytes(20000) + text(6, 30000) + b"xyz" * 7000 + text(7, 9000)
+    want = hashlib.sha256(oracle.lzss_compress(d)).hexdigest()
+    assert [o == want for o in outs] == [True] * len(envs), list(zip(envs, outs))
 
 
 @pytest.mark.parametrize("shift", [0, 1, 2, 3, 4, 5])
