@@ -110,6 +110,21 @@ __device__ __forceinline__ uint32_t ltgt_masks(const uint32_t w[4]) {
     return lt | (gt << 16);
 }
 
+// ',' mask in the low half, digit mask in the high half (the span's share of what parse_tok_w works out per token: a token's
+// twelve bytes after its '<' are then a shift of two spans' masks)
+__device__ __forceinline__ uint32_t cd_masks(const uint32_t w[4]) {
+    uint32_t cm = 0, dm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t y = w[k] ^ 0x30303030u;                            // digits -> 00..09, ',' -> 1C
+        const uint32_t td = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;        // bit 7 clear iff 00..09
+        const uint32_t yc = y ^ 0x1C1C1C1Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
+        dm |= pack_bit7(~td & 0x80808080u) << (4 * k);
+        cm |= pack_bit7(~tc & 0x80808080u) << (4 * k);
+    }
+    return cm | (dm << 16);
+}
+
 // the token whose '<' is staged byte j; sw = dword view, zero past the data, readable 28 bytes past j
 __device__ __forceinline__ Tok parse_tok_w(const uint32_t *sw, int j) {
     const int q = (j + 1) >> 2; const uint32_t sh = (uint32_t)((j + 1) & 3) * 8;
@@ -177,9 +192,12 @@ struct Span {
     bool err;
 };
 
-// masks[] holds ltgt_masks of every span, two spans of lead-in included: masks[sp + 2] is span sp
-__device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *masks, int sp, int sbyte, int valid, Span &r) {
+// masks[] holds ltgt_masks of every span, two spans of lead-in and one span beyond included: masks[sp + 2] is span sp;
+// cdm[] the same for cd_masks (spans sp and sp + 1 are read)
+__device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *masks, const uint32_t *cdm, int sp, int sbyte, int valid, Span &r) {
     const uint32_t m0 = masks[sp + 2], m1 = masks[sp + 1], m2 = masks[sp];
+    const uint32_t mn = masks[sp + 3], cd0 = cdm[sp + 2], cd1 = cdm[sp + 3];
+    const uint32_t gt32 = (m0 >> 16) | (mn & 0xFFFF0000u), cm32 = (cd0 & 0xFFFFu) | (cd1 << 16), dm32 = (cd0 >> 16) | (cd1 & 0xFFFF0000u);   // this span's bytes and the next one's
     const uint32_t ltw = (m1 << 16) | (m2 & 0xFFFFu), gtw = (m1 & 0xFFFF0000u) | (m2 >> 16);   // the 32 bytes before the span
     const uint32_t cin = (ltw & 0xFFFFFC00u) > (gtw & 0xFFFFFC00u) ? 1u : 0u;                  // last of '<','>' in the 22 bytes before is '<'
     const uint32_t vm = valid >= 16 ? 0xFFFFu : ((1u << valid) - 1u);
@@ -196,7 +214,30 @@ __device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *m
         if (starts) {
             const int j = __builtin_ctz(starts);
             starts &= starts - 1;
-            const Tok t = parse_tok_w(sw, sbyte + j);
+            // What every token the engine writes looks like -- "<d..,d..>" with at most four digits each -- is recognised from the
+            // spans' masks (the twelve bytes after the '<': a shift) and decoded from two 4-byte fields; anything else goes to
+            // parse_tok_w, which classifies the bytes itself and decides.
+            Tok t;
+            {
+                const uint32_t sh = (uint32_t)j + 1u;
+                const uint32_t g12 = (gt32 >> sh) & 0xFFFu, c12 = (cm32 >> sh) & 0xFFFu, d12 = (dm32 >> sh) & 0xFFFu;
+                const uint32_t pc = (uint32_t)__builtin_ctz(c12 | 0x1000u), pg = (uint32_t)__builtin_ctz(g12 | 0x1000u);
+                const uint32_t need = ((1u << pg) - 1u) & ~(1u << pc);
+                if (pc >= 1 && pc <= 4 && pg >= pc + 2 && pg <= pc + 5 && (d12 & need) == need) {
+                    const int b = sbyte + j + 1, q = b >> 2;
+                    const uint32_t d0 = sw[q], d1 = sw[q + 1], d2 = sw[q + 2], d3 = sw[q + 3];
+                    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)b), a1 = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)b),
+                                   a2 = __builtin_amdgcn_alignbyte(d3, d2, (uint32_t)b);   // (v_alignbyte uses b[1:0])
+                    auto dec4 = [](uint32_t x, uint32_t cnt) {            // (as in parse_tok_w)
+                        const uint32_t y = __builtin_bswap32(x & 0x0F0F0F0Fu) >> (8 * (4 - cnt));
+                        const uint32_t u = (y & 0x00FF00FFu) + 10u * ((y >> 8) & 0x00FF00FFu);
+                        return (u & 0xFFFFu) + 100u * (u >> 16);
+                    };
+                    const uint32_t s2 = pc + 1;                           // the second number starts here: byte 2 .. 5 after '<'
+                    const uint32_t f = s2 < 4 ? __builtin_amdgcn_alignbyte(a1, a0, s2) : __builtin_amdgcn_alignbyte(a2, a1, s2);
+                    t.ptr = dec4(a0, pc); t.len = dec4(f, pg - pc - 1); t.tl = pg + 2; t.ok = true;
+                } else t = parse_tok_w(sw, sbyte + j);
+            }
             if (!t.ok) r.err = true;
             else { r.tj[k] = (uint32_t)j; r.tptr[k] = t.ptr; r.tlen[k] = t.len; r.out += t.len; r.ntok = k + 1; }
         }
@@ -207,7 +248,7 @@ __device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *m
 constexpr int ZPAD = 32;                // staged bytes either side of a block (two spans; a token is at most MAXTOK - 1 long)
 
 // stage in[blk0 - ZPAD, blk0 + ZTILE + ZPAD) with 16-byte loads (zero outside the stream) and classify every span
-__device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_t n, size_t blk0, uint32_t *sw, uint32_t *masks, Span &r) {
+__device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_t n, size_t blk0, uint32_t *sw, uint32_t *masks, uint32_t *cdm, Span &r) {
     for (int v = threadIdx.x; v < (ZTILE + 2 * ZPAD) / 16; v += ZB) {
         const long long P = (long long)blk0 - ZPAD + 16ll * v;
         uint4 x = {0, 0, 0, 0};
@@ -223,7 +264,14 @@ __device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_
     const int tid = threadIdx.x;
     load_span(sw, ZPAD + 16 * tid, r.w);
     masks[tid + 2] = ltgt_masks(r.w);
-    if (tid < 2) { uint32_t w[4]; load_span(sw, 16 * tid, w); masks[tid] = ltgt_masks(w); }
+    cdm[tid + 2] = cd_masks(r.w);
+    if (tid < 3) {                                                        // the two spans before the block, and the one after it
+        uint32_t w[4];
+        const int sp = tid < 2 ? tid : ZB + 2;
+        load_span(sw, 16 * sp, w);
+        masks[sp] = ltgt_masks(w);
+        cdm[sp] = cd_masks(w);
+    }
     __syncthreads();
     const long long left = (long long)n - (long long)blk0 - 16ll * tid;   // valid bytes of this lane's span
     return left >= 16 ? 16 : left > 0 ? (int)left : 0;
@@ -231,13 +279,13 @@ __device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_
 
 __global__ __launch_bounds__(ZB) void k_lzd_count(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, int *__restrict__ err) {
     __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
-    __shared__ uint32_t masks[ZB + 2];
+    __shared__ uint32_t masks[ZB + 3], cdm[ZB + 3];
     __shared__ unsigned long long part[ZB / 64];
     Span r;
-    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, r);
+    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, cdm, r);
     unsigned long long mine = 0;
     if (valid) {
-        span_parse(sw, masks, threadIdx.x, ZPAD + 16 * threadIdx.x, valid, r);
+        span_parse(sw, masks, cdm, threadIdx.x, ZPAD + 16 * threadIdx.x, valid, r);
         mine = r.out;
         if (r.err) atomicOr(err, 1);
     }
@@ -329,15 +377,15 @@ static_assert(DT / 16 == DTH && DT <= 16384, "one 16-byte span per lane; 14-bit 
 __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
                                                   uint2 *__restrict__ tile_info, uint32_t *__restrict__ maxptr, int *__restrict__ err) {
     __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
-    __shared__ uint32_t masks[ZB + 2];
+    __shared__ uint32_t masks[ZB + 3], cdm[ZB + 3];
     __shared__ unsigned long long wsum[ZB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t blk0 = (size_t)blockIdx.x * ZTILE;
     Span r;
-    const int valid = stage_block(in, n, blk0, sw, masks, r);
+    const int valid = stage_block(in, n, blk0, sw, masks, cdm, r);
     unsigned long long mine = 0;
     int e = 0;
-    if (valid) { span_parse(sw, masks, tid, ZPAD + 16 * tid, valid, r); mine = r.out; e = r.err; }
+    if (valid) { span_parse(sw, masks, cdm, tid, ZPAD + 16 * tid, valid, r); mine = r.out; e = r.err; }
     unsigned long long incl = mine;
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(incl, d); if (lane >= d) incl += y; }
     if (lane == 63) wsum[wv] = incl;
@@ -394,14 +442,14 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
 __global__ __launch_bounds__(ZB) void k_lzd_count2(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, uint16_t *__restrict__ span_out,
                                                    unsigned long long *__restrict__ need, uint32_t *__restrict__ maxptr, int *__restrict__ flags) {
     __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
-    __shared__ uint32_t masks[ZB + 2];
+    __shared__ uint32_t masks[ZB + 3], cdm[ZB + 3];
     __shared__ unsigned long long wsum[ZB / 64], wneed[ZB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     Span r;
-    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, r);
+    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, cdm, r);
     unsigned long long mine = 0;
     int e = 0;
-    if (valid) { span_parse(sw, masks, tid, ZPAD + 16 * tid, valid, r); mine = r.out; if (r.err) e = 1; }
+    if (valid) { span_parse(sw, masks, cdm, tid, ZPAD + 16 * tid, valid, r); mine = r.out; if (r.err) e = 1; }
     span_out[(size_t)blockIdx.x * ZB + tid] = (uint16_t)min(mine, 0xFFFFull);
     if (mine >= 0xFFFFull) e |= 4;
     if (__ballot(valid && mask_5c(r.w) != 0) && lane == 0 && __atomic_load_n(&flags[4], __ATOMIC_RELAXED) == 0) atomicOr(&flags[4], 1);
@@ -607,7 +655,7 @@ __global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in,
 __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 waves per SIMD: two blocks per CU
     __shared__ __attribute__((aligned(16))) uint32_t sw[(DT + 128) / 4 + 8];
     __shared__ __attribute__((aligned(16))) uint16_t sd[DT];
-    __shared__ uint32_t masks[DTH + 2];
+    __shared__ uint32_t masks[DTH + 3], cdm[DTH + 3];
     __shared__ uint32_t s_part[DTH / 64];
     __shared__ uint32_t s_wlast[DTH / 64];
     // Item marks (phases A and B only): 0 = no item starts here; bit 15 = a RUN of literals starts here, low 15 bits = (staged byte index -
@@ -651,15 +699,21 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         const int sp = base + tid, sbyte = lo + 16 * sp;
         const int valid = hi - sbyte >= 16 ? 16 : hi - sbyte > 0 ? hi - sbyte : 0;
         Span r;
-        uint32_t m = 0, lead = 0;
-        if (valid) { load_span(sw, sbyte, r.w); m = ltgt_masks(r.w); }
-        if (tid < 2 && base) lead = masks[DTH + tid];                     // the last two spans of the previous round
+        uint32_t m = 0, cd = 0, lead = 0, lead_cd = 0;
+        if (valid) { load_span(sw, sbyte, r.w); m = ltgt_masks(r.w); cd = cd_masks(r.w); }
+        if (tid < 2 && base) { lead = masks[DTH + tid]; lead_cd = cdm[DTH + tid]; }   // the last two spans of the previous round
         __syncthreads();
-        masks[tid + 2] = m;
-        if (tid < 2) masks[tid] = lead;
+        masks[tid + 2] = m; cdm[tid + 2] = cd;
+        if (tid < 2) { masks[tid] = lead; cdm[tid] = lead_cd; }
+        if (tid == 2) {                                                   // the span after the round's last (staged: 32 bytes past the range)
+            uint32_t w[4] = {0, 0, 0, 0};
+            const int nb = lo + 16 * (base + DTH);
+            if (nb < hi + 16) load_span(sw, nb, w);
+            masks[DTH + 2] = ltgt_masks(w); cdm[DTH + 2] = cd_masks(w);
+        }
         __syncthreads();
         uint32_t mine = 0;
-        if (valid) { span_parse(sw, masks, tid, sbyte, valid, r); mine = r.out; }
+        if (valid) { span_parse(sw, masks, cdm, tid, sbyte, valid, r); mine = r.out; }
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_part[wv] = incl;
