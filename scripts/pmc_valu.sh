@@ -6,7 +6,7 @@ W=${1:-4}
 OUT=$R/gpurun_out/pmc_valu_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --profile-only $W > $OUT/log.txt 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py $( [ "$W" = headline ] && echo "--steps 3 --warmup 2 --no-cpu --no-others" || echo "--profile-only $W" ) > $OUT/log.txt 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
