@@ -1099,7 +1099,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         struct WaveScratch {
             uint32_t par[K][8];                                               // a visit's parameters for the lanes its candidates are dealt to
             uint32_t best[K], lcnt[K], lfar[K];                               // its maximum; its long candidates: how many, the farthest
-            uint32_t nr[K];                                                   // rows of candidates each chain puts up for dealing this time
             uint32_t llist[K][LONG_CAP][2];                                   // the first LONG_CAP long candidates (distance | limit << 16, bytes known equal)
             uint16_t rowmap[K * (HEAVY_ROWS < 256 ? HEAVY_ROWS : 256)];       // dealt row -> chain << 8 | row of that chain (a chain with HEAVY_ROWS rows is not dealt)
         };
@@ -1246,19 +1245,17 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             }
             // 2b. the others, dealt in rows.  Which chain a row belongs to comes from a table the home rows fill in: chain c's rows are
             //     the entries [rows of chains 0 .. c-1 together, + its own).
-            uint32_t pre = 0;                                                 // lane k of every row: rows of chains 0 .. k together
-            if (leader) ws.nr[slot] = nrows;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            pre = ws.nr[rl & (K - 1)];
-#pragma unroll
-            for (int d = 1; d < K; d <<= 1) {                                 // (K <= LW: a prefix sum within the row's first K lanes)
-                const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - d) << 2), (int)pre);
-                if ((rl & (K - 1)) >= d) pre += up;
-            }
-            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, K - 1);
+            // (rows of the chains up to and including this lane's: a DPP prefix sum over the wavefront of the leaders' counts)
+            uint32_t pre = leader ? nrows : 0u;
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x111, 0xF, 0xF, true);   // row_shr:1 (zero shifted in)
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x112, 0xF, 0xF, true);   // row_shr:2
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xF, true);   // row_shr:4
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xF, true);   // row_shr:8: every lane has its DPP row's sum up to itself
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false);   // DPP rows 1 and 3 take in the row before
+            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false);   // rows 2 and 3 take in lane 31
+            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
             {
-                const uint32_t mine0 = row_read<LW>(pre, (uint32_t)slot, lane) - nrows;   // rows of the chains before this one
+                const uint32_t mine0 = pre - nrows;                               // rows of the chains before this one
                 for (uint32_t j = (uint32_t)rl; j < nrows; j += LW) ws.rowmap[mine0 + j] = (uint16_t)(((uint32_t)slot << 8) | j);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
