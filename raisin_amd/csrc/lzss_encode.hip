@@ -775,7 +775,12 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
 template <class C, int LW>
 __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
     constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : RSN_CHAIN_ROW_CS, CH = C::CH, NS = C::NS;
-    constexpr uint32_t OFFM = (1u << C::OFFB) - 1, TAGM = (1u << C::TAGB) - 1;
+    constexpr uint32_t TAGM = (1u << C::TAGB) - 1;
+    // A list entry is staged offset << TAGB | tag.  The test of a candidate -- its start in [i - W, i) and the same tag -- is then one
+    // subtraction, one rotation and one compare: with Q = (offset of i - 1) << TAGB | tag of i, Q - entry is (distance - 1) << TAGB when
+    // the tags agree and has low bits set when they do not; rotated right by TAGB that is distance - 1, or something above any window.
+    auto cand_q = [](uint32_t irel, uint32_t tag) { return ((irel - 1u) << C::TAGB) | tag; };
+    auto cand_rot = [](uint32_t q, uint32_t e) { const uint32_t d = q - e; return (uint32_t)__builtin_amdgcn_alignbit(d, d, (uint32_t)C::TAGB); };   // < W: a candidate at distance rot + 1
     __shared__ __attribute__((aligned(1024))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream  (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
     __shared__ __attribute__((aligned(16))) uint8_t s_pool[(HNB / 2) * 4 + NS * 2];   // the bucket index; later the two jump arrays of the in-tile parse
     uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_pool);              // two 16-bit counters per word: counts, then starts, then ends
@@ -855,7 +860,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 const uint32_t b1 = sb[rel + 1];
                 const uint32_t h = ((uint32_t)sb[rel] << 5) | (b1 & 31u), sh = 16 * (h & 1);
                 const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
-                s_list[slot] = (uint16_t)(rel | (((b1 >> 5) & TAGM) << C::OFFB));
+                s_list[slot] = (uint16_t)((rel << C::TAGB) | ((b1 >> 5) & TAGM));
             }
             __syncthreads();
         }
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             bool longm = false;                                               // a common prefix reached HLMAX bytes
             uint32_t long_best = 0, long_far = 0, n_long = 0;                 // wave-uniform: the best of the long candidates that were followed up, the farthest of all, how many (LONG_CAP + 1: too many)
             {   // (a position with a single byte left needs no case of its own: the stage is zero behind the stream and L is capped at E - i)
-                const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
+                const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM, v_q = cand_q(u_irel, u_tag);
                 // (bucket bounds and the bisection's arithmetic stay in VECTOR registers although every lane holds the same values:
                 //  the scalar unit is this kernel's bound; only the ballots and the loop branches are scalar)
                 const uint32_t v_lo0 = ends[max(u_h, 1u) - 1];
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 while (__ballot(narrowing)) {                                 // skip the entries before the window, 64-ary
                     const uint32_t n = v_hi - v_lo, stride = (n + 63) >> 6;
                     const uint32_t idx = min(v_lo + (uint32_t)lane * stride, v_hi - 1);
-                    const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
+                    const uint32_t blk = (uint32_t)s_list[idx] >> (C::TAGB + CSH);
                     const unsigned long long in = __ballot(blk >= u_blk_lo);
                     const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
                     const uint32_t skip = max(first, 1u) - 1u;                // whole strides known to lie before the window
@@ -944,9 +949,9 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
 #endif
                     const uint32_t idx = v_base + (uint32_t)lane;
                     const uint32_t e = s_list[idx < v_hi ? idx : v_lo];
-                    const uint32_t rel = e & OFFM, dn = u_irel - rel;
+                    const uint32_t rel = e >> C::TAGB, rot = cand_rot(v_q, e), dn = rot + 1u;
                     // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
-                    const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ u_tag) << 20)) < W;
+                    const bool ok = rot < W;
                     v_base += 64;
                     // the last round if some lane's entry lies after i (the rest of the bucket does then) or no entries remain:
                     // the sign bits of (block of i - block of the entry) and of NOT (next base - end), one vector value, one branch
@@ -1035,8 +1040,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                             const uint32_t want = a.fc[(size_t)u_ipos + mm];
                             bool other = false;
                             for (uint32_t idx = lo + lane; idx < hi; idx += 64) {
-                                const uint32_t e = s_list[idx], dn = u_irel - (e & OFFM);
-                                const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ u_tag) << 20)) < W;
+                                const uint32_t e = s_list[idx], rot = cand_rot(cand_q(u_irel, u_tag), e), dn = rot + 1u;
+                                const bool ok = rot < W;
                                 if (ok && dn > mm && dn <= u_ipos && a.fc[(size_t)u_ipos - dn + mm] == want) other = true;
                             }
                             if (__ballot(other)) giveup_heavy = true;
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 while (narrowing) {
                     const uint32_t n = hi - lo, stride = (n + LW - 1) / LW;
                     const uint32_t idx = min(lo + __umul24((uint32_t)rl, stride), hi - 1);
-                    const uint32_t blk = (s_list[idx] & OFFM) >> CSH;
+                    const uint32_t blk = (uint32_t)s_list[idx] >> (C::TAGB + CSH);
                     const uint32_t in = row_ballot<LW>(blk >= blk_lo, lane), after = row_ballot<LW>(blk > blk_i, lane);
                     const uint32_t first = in ? (uint32_t)__builtin_ctz(in) : (uint32_t)LW;   // samples below `first` lie before the window
                     const uint32_t skip = max(first, 1u) - 1u;                                 // whole strides known to
@@ -1166,10 +1171,10 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             // one candidate per lane: its key L << 16 | distance (0: none).  c_*: the visit it belongs to, `ch` its chain.  A candidate that
             // agrees with the position for HLMAX bytes and more -- further than the stage reaches -- is put on the chain's list: the home row
             // follows up to LONG_CAP of them through memory (see the wave version); its key stays as the lower bound it is.
-            auto eval = [&](bool valid, uint32_t e, uint32_t c_irel, uint32_t c_tag, unsigned long long c_pat0, uint32_t c_capE, uint32_t ch, uint32_t &long_dn) -> uint32_t {
-                const uint32_t rel = e & OFFM, dn = c_irel - rel;
+            auto eval = [&](bool valid, uint32_t e, uint32_t c_irel, uint32_t c_q, unsigned long long c_pat0, uint32_t c_capE, uint32_t ch, uint32_t &long_dn) -> uint32_t {
+                const uint32_t rel = e >> C::TAGB, rot = cand_rot(c_q, e), dn = rot + 1u;
                 // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
-                const bool ok = valid && ((dn - 1u) | (((e >> C::OFFB) ^ c_tag) << 20)) < W;
+                const bool ok = valid && rot < W;
                 uint32_t lim = 0, off = C::OFF0;
                 unsigned long long x = 1;
                 if (ok) {
@@ -1208,13 +1213,13 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             unsigned long long hm = __ballot(leader && nrows >= HEAVY_ROWS);
             if (nrows >= HEAVY_ROWS) nrows = 0;
             else if (mine && leader) {
-                *reinterpret_cast<uint4 *>(&ws.par[slot][0]) = uint4{irel, tag, (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
+                *reinterpret_cast<uint4 *>(&ws.par[slot][0]) = uint4{irel, cand_q(irel, tag), (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
                 *reinterpret_cast<uint4 *>(&ws.par[slot][4]) = uint4{lo, hi, capE, 0u};
             }
             while (hm) {
                 const int hl = __builtin_ctzll(hm);
                 hm &= hm - 1;
-                const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl), c_tag = (uint32_t)__builtin_amdgcn_readlane((int)tag, hl),
+                const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl), c_q = (uint32_t)__builtin_amdgcn_readlane((int)cand_q(irel, tag), hl),
                                c_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, hl), c_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, hl),
                                c_capE = (uint32_t)__builtin_amdgcn_readlane((int)capE, hl);
                 const unsigned long long c_pat0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pat0, hl) |
@@ -1228,7 +1233,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     const bool valid = idx < c_hi;
                     const uint32_t e = s_list[valid ? idx : c_lo];
                     uint32_t long_dn;
-                    wb = max(wb, eval(valid, e, c_irel, c_tag, c_pat0, c_capE, (uint32_t)hl / LW, long_dn));
+                    wb = max(wb, eval(valid, e, c_irel, c_q, c_pat0, c_capE, (uint32_t)hl / LW, long_dn));
                     // Runs and short periods: thousands of candidates that all agree for HLMAX bytes and more.  Once more of them are known
                     // than are followed up, only the farthest counts (see 3.), and the entries come farthest first, block by block: when
                     // this round's last entry lies in a later block than the farthest long candidate, nothing behind it can matter.
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     if (lm) {
                         n_long += (uint32_t)__builtin_popcountll(lm);
                         far = max(far, wave_max_u32(long_dn));
-                        const uint32_t last_blk = ((uint32_t)__builtin_amdgcn_readlane((int)e, 63) & OFFM) >> CSH;   // (lane 63 holds the round's last entry, or re-reads the first: then the loop ends anyway)
+                        const uint32_t last_blk = (uint32_t)__builtin_amdgcn_readlane((int)e, 63) >> (C::TAGB + CSH);   // (lane 63 holds the round's last entry, or re-reads the first: then the loop ends anyway)
                         if (n_long > LONG_CAP && base + 64 < c_hi && last_blk > ((c_irel - far) >> CSH)) break;
                     }
                 }
@@ -1332,8 +1337,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                 const uint32_t blo = h ? (uint32_t)ends[h - 1] : 0u, bhi = ends[h];
                                 bool other = false;
                                 for (uint32_t idx = blo + rl; idx < bhi; idx += LW) {
-                                    const uint32_t e = s_list[idx], dn = irel - (e & OFFM);
-                                    const bool ok = ((dn - 1u) | (((e >> C::OFFB) ^ tag) << 20)) < W;
+                                    const uint32_t e = s_list[idx], rot = cand_rot(cand_q(irel, tag), e), dn = rot + 1u;
+                                    const bool ok = rot < W;
                                     if (ok && dn > mm && dn <= ipos && a.fc[(size_t)ipos - dn + mm] == want) other = true;
                                 }
                                 if (row_ballot<LW>(other, lane)) giveup_heavy = true;
