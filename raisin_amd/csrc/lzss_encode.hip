@@ -84,6 +84,17 @@ __global__ __launch_bounds__(LB) void k_esc_count(const uint8_t *__restrict__ in
 
 // A block's output is contiguous: bytes go to an LDS image shifted so that its 16-byte units line
 // up with global memory, then out with 16-byte stores (per-lane byte stores cost 3x the time).
+// the same, leaving the image zeroed behind it (for writers that OR their bytes in)
+__device__ __forceinline__ void drain_block_zero(uint8_t *s_img, uint32_t al, uint32_t total, uint8_t *dst) {
+    const uint32_t span = al + total;
+    uint8_t *gbase = dst - al;
+    for (uint32_t u = threadIdx.x; u * 16 < span + 16; u += blockDim.x) {   // (one unit past the span: an entry's four words may reach there, as zeros)
+        const uint32_t b0 = u * 16;
+        if (b0 >= al && b0 + 16 <= span) *reinterpret_cast<uint4 *>(gbase + b0) = *reinterpret_cast<const uint4 *>(s_img + b0);
+        else for (uint32_t k = max(b0, al); k < min(b0 + 16, span); k++) gbase[k] = s_img[k];
+        *reinterpret_cast<uint4 *>(s_img + b0) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
 __device__ __forceinline__ void drain_block(const uint8_t *s_img, uint32_t al, uint32_t total, uint8_t *dst) {
     // s_img[al .. al+total) is the output, dst - al is 16-byte aligned
     const uint32_t span = al + total;
@@ -2232,6 +2243,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             else if (p < E) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t k = 0; p + k < E; k++) w[k >> 2] |= (uint32_t)fc[p + k] << (8 * (k & 3)); x = {w[0], w[1], w[2], w[3]}; }
             reinterpret_cast<uint4 *>(l_fc)[v] = x;
         }
+        for (int v = tid; v < (11 * LR + 64) / 16; v += LB) reinterpret_cast<uint4 *>(l_img)[v] = make_uint4(0u, 0u, 0u, 0u);   // the entries are ORed into it
         const uint32_t *cl = clist + (size_t)blockIdx.x * PT;
         uint32_t pos0 = tchain[blockIdx.x].entry - base;            // tile-relative position of the round's first entry
         for (uint32_t r0 = 0; r0 < n_list; r0 += LR) {
@@ -2255,19 +2267,56 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             const uint32_t ex = pre + incl - mine;
             uint8_t *dst = out + run;
             const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
-            uint8_t *o = l_img + al + (ex & 0xFFFF);
+            uint32_t ob = al + (ex & 0xFFFF);                        // where in the image the lane's next entry goes
             uint32_t q = pos0 + (ex >> 16);
+            // One path for every entry, no loops: its (at most 11) bytes -- a token's text put together from arithmetic digits, or
+            // the bytes themselves out of the stage -- are twelve bytes in registers, cut to length, shifted to the byte they start
+            // at and ORed into the zeroed image as four aligned words.  (Digit loops, byte stores and a copy loop per entry had every
+            // lane of a wavefront walk all three paths: this kernel is bound by vector issue.)
+            const uint32_t *fc32 = reinterpret_cast<const uint32_t *>(l_fc);
+            uint32_t *img32 = reinterpret_cast<uint32_t *>(l_img);
 #pragma unroll
             for (int u = 0; u < LE; u++) {
-                if (i0 + u >= n_list) break;
-                const uint32_t L = kk[u] >> 16, off = kk[u] & 0xFFFF;
-                if (L == 0) { *o++ = l_fc[q]; q++; continue; }
-                if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
-                else for (uint32_t j = 0; j < L; j++) *o++ = l_fc[q + j];
-                q += L;
+                const bool live = i0 + u < n_list;
+                const uint32_t L = kk[u] >> 16, off = kk[u] & 0xFFFF, el = enc_len(off, L);
+                const bool tok = L != 0 && el < L;
+                const uint32_t nb = !live ? 0u : (L == 0 ? 1u : (tok ? el : L));   // 0 .. 11
+                const uint32_t qa = q >> 2;
+                const uint32_t r0 = fc32[qa], r1 = fc32[qa + 1], r2 = fc32[qa + 2], r3 = fc32[qa + 3];
+                uint32_t x0 = __builtin_amdgcn_alignbyte(r1, r0, q), x1 = __builtin_amdgcn_alignbyte(r2, r1, q), x2 = __builtin_amdgcn_alignbyte(r3, r2, q);   // (v_alignbyte uses q[1:0])
+                {
+                    auto dec4 = [](uint32_t v, uint32_t &nd) {          // v < 10000: its digits, the first in byte 0, and how many
+                        const uint32_t hi = (v * 5243u) >> 19, lo = v - hi * 100u;               // v / 100 (exact below 43699), v % 100
+                        const uint32_t d3 = (hi * 103u) >> 10, d1 = (lo * 103u) >> 10;           // x / 10 for x < 100
+                        const uint32_t w = (d3 | ((hi - d3 * 10u) << 8) | (d1 << 16) | ((lo - d1 * 10u) << 24)) + 0x30303030u;
+                        nd = 1u + (v > 9u ? 1u : 0u) + (v > 99u ? 1u : 0u) + (v > 999u ? 1u : 0u);
+                        return w >> (8u * (4u - nd));
+                    };
+                    uint32_t nd1, nd2;
+                    const uint32_t ow = dec4(off, nd1), lw = dec4(L, nd2);
+                    const unsigned long long A = 0x3Cull | ((unsigned long long)ow << 8) | (0x2Cull << (8u * (1u + nd1)));   // '<' digits ','
+                    const unsigned long long B = (unsigned long long)lw | (0x3Eull << (8u * nd2));                            // digits '>'
+                    const uint32_t sh = 8u * (2u + nd1);                                                                      // 24 .. 48 bits
+                    const unsigned long long T = A | (B << sh);
+                    if (tok) { x0 = (uint32_t)T; x1 = (uint32_t)(T >> 32); x2 = (uint32_t)(B >> (64u - sh)); }
+                }
+                {   // cut to nb bytes
+                    const unsigned long long M = nb >= 8u ? ~0ull : ((1ull << (8u * nb)) - 1ull);
+                    x0 &= (uint32_t)M; x1 &= (uint32_t)(M >> 32);
+                    x2 &= nb > 8u ? ((1u << (8u * (nb - 8u))) - 1u) : 0u;
+                }
+                const uint32_t b = ob & 3u, k = (4u - b) & 3u;
+                const uint32_t y0 = x0 << (8u * b);
+                const uint32_t y1 = b ? __builtin_amdgcn_alignbyte(x1, x0, k) : x1;
+                const uint32_t y2 = b ? __builtin_amdgcn_alignbyte(x2, x1, k) : x2;
+                const uint32_t y3 = b ? x2 >> (8u * k) : 0u;
+                uint32_t *w = img32 + (ob >> 2);
+                if (nb) { atomicOr(w, y0); atomicOr(w + 1, y1); atomicOr(w + 2, y2); atomicOr(w + 3, y3); }
+                ob += nb;
+                q += live ? max(1u, L) : 0u;
             }
             __syncthreads();
-            drain_block(l_img, al, tot & 0xFFFF, dst);
+            drain_block_zero(l_img, al, tot & 0xFFFF, dst);
             run += tot & 0xFFFF;
             pos0 += tot >> 16;
             __syncthreads();
