@@ -24,6 +24,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#define RSN_API __attribute__((visibility("default")))
+#else
+#define RSN_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -42,16 +49,16 @@ extern "C" {
 /* ---- library / device ------------------------------------------------- */
 /* Select the HIP device used by the calling thread.  A thread that never calls this uses device 0,
  * or what RSN_DEVICE says: a number, or "rr" = new thread contexts take the visible devices in turn. */
-int rsn_device_set(int device);
+RSN_API int rsn_device_set(int device);
 /* Number of visible HIP devices, or a negative error. */
-int rsn_device_count(void);
-const char *rsn_last_error(void); /* thread-local, valid until the next call on this thread */
-const char *rsn_version(void);
+RSN_API int rsn_device_count(void);
+RSN_API const char *rsn_last_error(void); /* thread-local, valid until the next call on this thread */
+RSN_API const char *rsn_version(void);
 /* Releases what the library keeps between calls: the calling thread's device scratch and pinned
  * staging, the contexts parked by threads that have exited, and the recycled result buffers.
  * Safe at any time between calls; the next call re-allocates what it needs. */
-void rsn_trim(void);
-void rsn_free(void *p);           /* releases buffers returned through `out` below (only rsn_free may: they carry a
+RSN_API void rsn_trim(void);
+RSN_API void rsn_free(void *p);           /* releases buffers returned through `out` below (only rsn_free may: they carry a
                                      library header; large ones are recycled, RSN_HOST_POOL=0 disables that) */
 
 /* ---- host-buffer entry points (what the cgo shim binds) ----------------
@@ -59,13 +66,13 @@ void rsn_free(void *p);           /* releases buffers returned through `out` bel
  * is allocated by the library and released with rsn_free().                */
 
 /* replaces huffman.Compress([]byte) []byte            huffman.go:299 */
-int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+RSN_API int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 /* replaces huffman.Decompress([]byte) []byte          huffman.go:327 */
-int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+RSN_API int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 /* replaces lz.CompressAsync([]byte, bool, int) []byte lzss.go:109
  * (the engine path: Writer.Write lzss.go:53-57).  window <= 0 = unbounded
  * search buffer (lzss.go:125).  The progress-bar argument has no equivalent. */
-int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
+RSN_API int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
 /* replaces lz.Compress([]byte, bool, int) []byte      lzss.go:224 -- the older synchronous encoder.
  * FOR SMALL INPUTS ONLY: it is the reference's O(n * window) loop (O(n^2) for window <= 0) on the calling
  * thread; inputs above 64 MiB (above 1 MiB for window <= 0 or > 65536) return RSN_ERR_LIMIT instead of
@@ -73,19 +80,19 @@ int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out
  * Not on the .rsn path (the engine calls CompressAsync) and not accelerated: a host-side
  * restatement for API completeness, quirks included (every-second-byte FindReverse :425-431,
  * offsets computed from the unsliced buffer :249-257, `<=` token threshold :272).  Needs no device. */
-int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
+RSN_API int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n);
 /* replaces lz.Decompress([]byte, bool) []byte         lzss.go:323 */
-int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+RSN_API int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
 
 /* Batch form for independent chunks (one .rsn segment per chunk, as
- * engine.CompressFiles produces one file per input, engine.go:150-154).  The chunks are
- * dealt out over the visible devices -- chunk k -> worker k mod G, worker w on device
- * (calling thread's device + w) mod G, G = rsn_device_count() capped by RSN_BATCH_DEVICES --
- * and on each device chunk k+1's upload, chunk k's encode and chunk k-1's download run at
- * once.  Nothing is exchanged between devices.  Each outs[i] equals what
+ * engine.CompressFiles produces one file per input, engine.go:150-154).  By default the batch
+ * stays on the calling thread's device; with RSN_BATCH_DEVICES=<G>|all the chunks are dealt out
+ * over G visible devices -- chunk k -> worker k mod G, worker w on device (calling thread's
+ * device + w) mod visible.  On each device chunk k+1's upload, chunk k's encode and chunk k-1's
+ * download run at once.  Nothing is exchanged between devices.  Each outs[i] equals what
  * rsn_huffman_compress() returns for ins[i]; on any error every outs[i] is NULL.
  * (RSN_BATCH_WORKERS, RSN_BATCH_LANES, RSN_BATCH_KEEP_MIB: see rsn_api.hip / INTEGRATION.md.) */
-int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
+RSN_API int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
                                uint8_t **outs, size_t *out_lens);
 
 /* ---- device-resident entry points --------------------------------------
@@ -95,9 +102,9 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
  * been synchronised (the calls below synchronise it before returning).
  * d_out must be 16-byte aligned and hold rsn_*_bound() bytes; [d_in, d_in+n)
  * and [d_out, d_out+out_cap) must not overlap (RSN_ERR_ARG).                */
-size_t rsn_huffman_compress_bound(size_t n);
-size_t rsn_lzss_compress_bound(size_t n);
-int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+RSN_API size_t rsn_huffman_compress_bound(size_t n);
+RSN_API size_t rsn_lzss_compress_bound(size_t n);
+RSN_API int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
 /* The decoded size is only known after the header is parsed.  When the buffer is too small -- or
  * d_out is NULL / out_cap 0, the size query -- the call returns RSN_ERR_CAPACITY, sets the error
  * string, and stores in *out_n a capacity that WOULD suffice (the exact size rounded up to 16, plus
@@ -106,9 +113,9 @@ int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out
  * the same contract.  (The Huffman query with d_out NULL is answered from the header's counts alone,
  * without touching the payload: a foreign stream whose payload decodes to more than its header
  * announces reports the larger need on the call that follows.)                                  */
-int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
-int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream);
-int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+RSN_API int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+RSN_API int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream);
+RSN_API int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);
 
 /* ---- measurement --------------------------------------------------------
  * When enabled, every kernel launch of the calling thread is bracketed by HIP
@@ -119,15 +126,15 @@ typedef struct {
     uint64_t launches;
     double total_ms;
 } rsn_prof_entry;
-void rsn_prof_enable(int on);
-void rsn_prof_reset(void);
-int rsn_prof_get(rsn_prof_entry *entries, int cap); /* returns the number of entries */
+RSN_API void rsn_prof_enable(int on);
+RSN_API void rsn_prof_reset(void);
+RSN_API int rsn_prof_get(rsn_prof_entry *entries, int cap); /* returns the number of entries */
 
 /* Introspection used by the parity tests: the code table the encoder builds for
  * `in` (device buffer not needed; runs the histogram on the device, the tree on
  * the host).  Arrays hold `cap` entries in printCodes DFS order (huffman.go:110);
  * returns the symbol count or a negative error. */
-int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs,
+RSN_API int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs,
                           uint64_t *codes, uint8_t *lens, size_t cap);
 
 /* ---- host-side helpers (no device needed) --------------------------------
@@ -139,13 +146,13 @@ int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t
 /* (rune,count) pairs in any order -> codes in printCodes DFS order plus the
  * header this library writes (ascending rune, '\\' never last).  Returns the
  * symbol count, or a negative error.  header may be NULL.                      */
-int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms,
+RSN_API int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms,
                          uint32_t *out_runes, uint64_t *out_codes, uint8_t *out_lens,
                          uint8_t *header, size_t header_cap, size_t *header_len);
 /* decodeTree's scan of a header (bytes before "\\\n").  Returns the number of
  * distinct symbols (ascending rune), or a negative error where the reference
  * would index out of range.                                                   */
-int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap);
+RSN_API int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -426,7 +426,7 @@ int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
 // On a node with several GPUs the chunks are dealt out first: chunk k -> worker k mod G, worker w on device
 // (caller's device + w) mod visible devices, every worker its own pipeline and its own PCIe link; results land in the
 // caller's host arrays, so there is nothing to exchange between devices (no data-path collective).
-//   RSN_BATCH_DEVICES=<d>  use at most d devices (default: all visible)
+//   RSN_BATCH_DEVICES=<d>|all  use up to d devices, starting at the caller's (default 1: the caller's device only)
 //   RSN_BATCH_WORKERS=<w>  number of pipelines (default: one per device used); more workers than devices share
 //                          devices round-robin -- how the split is exercised on a one-GPU box
 //   RSN_BATCH_LANES=1      no pipeline: each worker is a serial loop of rsn_huffman_compress calls (A/B; any other value = pipeline)
@@ -446,11 +446,11 @@ struct BatchPipe {
     void done(size_t &counter) { { std::lock_guard<std::mutex> lk(mu); counter++; } cv.notify_all(); }
 };
 
-int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 
 // The chunks `idx` through one device's pipeline, on the calling thread's context (already initialised on its device).
 // On failure the chunks this worker has produced stay in outs[] for the caller to undo; the message is in c.err.
-int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
     const size_t m = idx.size();
     if (m == 0) return RSN_OK;
     if (env_int("RSN_BATCH_LANES", 3) == 1 || m < 2) {
@@ -548,9 +548,13 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
         for (size_t k = 0; k < n_chunks; k++) { if (outs[k]) rsn_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; }
         return c.fail(rc, "%s", msg);
     };
+    // Other devices are an opt-in: in the one-process-per-GPU model every rank sees every GPU, and a batch that spread
+    // by default would put contexts and ~GiB rings on the other ranks' devices.  RSN_BATCH_DEVICES=<d>|all asks for it.
     int visible = 1;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) visible = 1;
-    const int n_dev = std::max(1, std::min(visible, env_int("RSN_BATCH_DEVICES", visible)));
+    const char *bd = getenv("RSN_BATCH_DEVICES");
+    const int want_dev = !bd || !*bd ? 1 : (!strcmp(bd, "all") ? visible : atoi(bd));
+    const int n_dev = std::max(1, std::min(visible, want_dev));
     const size_t n_workers = std::min<size_t>((size_t)std::max(1, env_int("RSN_BATCH_WORKERS", n_dev)), std::max<size_t>(n_chunks, 1));
     if (n_workers <= 1) {                                        // one device, one pipeline, on the caller's own context
         std::vector<size_t> idx(n_chunks);

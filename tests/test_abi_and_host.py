@@ -30,6 +30,21 @@ def test_every_declared_symbol_is_exported(built):
     assert declared == set(built.SYMBOLS)
 
 
+def test_nothing_but_the_declared_symbols_is_exported(built):
+    """VERDICT r3: the dynamic symbol table is rsn.h's set and nothing else (built with -fvisibility=hidden;
+    a host binary's own `env_int` must not interpose the library's).  The HIP runtime's registration objects
+    (__hip_*) are the one allowed exception."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "rsn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rsn_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "raisin_amd", "librsn.so")], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    extra = {x for x in exported - declared if not x.startswith("__hip_")}
+    assert not extra, sorted(extra)[:20]
+    assert declared <= exported
+
+
 def test_no_cpu_fallback(built):
     """Without a HIP device every codec entry point must fail loudly (never compute on the CPU)."""
     import torch
