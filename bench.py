@@ -64,6 +64,47 @@ def load_traffic(prof_name):
     return best
 
 
+# librsn profiling name -> candidate kernel names in a rocprofv3 trace (the first one the workload's PMC summary holds is used)
+TRACE_CANDIDATES = {
+    "huff_emit": ["k_emit_flat", "k_emit_ascii32", "k_emit<"], "huff_emit_rune": ["k_emit<"], "huff_emit_wide": ["k_emit<"],
+    "huff_byte_hist": ["k_byte_hist"], "huff_rune_hist": ["k_rune_hist"], "huff_tile_bits_rune": ["k_tile_bits_rune"],
+    "huff_dec_flat": ["k_dec_flat"], "huff_dec_emit": ["k_dec_emit"], "huff_dec_sync": ["k_dec_sync"], "huff_dec_fused": ["k_dec_fused"],
+    "lzss_match_chain": ["k_match_chain"], "lzss_match_hash": ["k_match_hash"], "lzss_match": ["k_match2", "k_match"],
+    "lzss_tok_emit": ["k_tok_emit"], "lzss_esc_write": ["k_esc_try", "k_esc_write"], "lzss_tile_periodic": ["k_tile_periodic"],
+    "lzss_chain_tail": ["k_chain_serial", "k_chain_tail"], "lzss_dec_resolve": ["k_lzd_resolve"], "lzss_dec_emit": ["k_lzd_emit"],
+    "lzss_dec_count": ["k_lzd_count2", "k_lzd_count"], "lzss_dec_compose": ["k_lzd_compose"], "lzss_dec_runs": ["k_lzd_runs"],
+    "lzss_dec_lit": ["k_lzd_lit"], "lzss_dec_patch": ["k_lzd_patch"],
+}
+PMC_LABEL = {"2b": "2b", "skewed": "skewed", "3": "config3", "4": "config4", "5": "5", "headline": "headline"}
+
+
+def workload_traffic(workload, prof_name):
+    """HBM bytes (FETCH_SIZE doubled + WRITE_SIZE, the kernel's largest launch) of one kernel in ONE workload's newest committed
+    PMC summary, profiles/<tag>_pmc_<label>.json (scripts/profile.sh <tag> <label>): (bytes, file) or None."""
+    import glob
+    label = PMC_LABEL.get(workload, workload)
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%s.json" % label)), reverse=True):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        for cand in TRACE_CANDIDATES.get(prof_name, ["k_" + prof_name.split("_", 1)[-1]]):
+            hits = [v for k, v in d.items() if k.startswith(cand) and isinstance(v, dict) and v.get("hbm_max")]
+            if hits:
+                return max(h["hbm_max"] for h in hits), os.path.basename(p)
+    return None
+
+
+def roofline_of(workload, prof_name, alg_bytes, ms):
+    """The bench line's roofline object for one kernel of one workload: achieved = ALGORITHMIC bytes / the kernel's average launch
+    duration (HIP events on librsn's stream, this run); traffic = that kernel's PMC bytes in the workload's committed profile."""
+    tr = workload_traffic(workload, prof_name)
+    ach = alg_bytes / ms / 1e6 if ms > 0 else 0.0
+    return {"kernel": prof_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": tr[0] if tr else None,
+            "traffic_source": ("profiles/" + tr[1]) if tr else None, "algorithmic_bytes": int(alg_bytes)}
+
+
 # ---------------------------------------------------------------------------------------------- CPU baselines
 def _timed(fn):
     t0 = time.perf_counter()
@@ -214,9 +255,24 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
         if name in ("3", "4"):
             kalg.update({"lzss_match_chain": n, "lzss_match_hash": n, "lzss_match": n})   # reads the (escaped) stream once
         ent["dominant_kernel"] = {"name": dom, "ms": round(allk[dom], 3)}
-        if dom in kalg and name != "4":
+        if name == "4":                                     # layered: the Huffman layer's kernels work on the LZSS stream (l1 bytes)
+            kalg.update({"huff_byte_hist": l1, "huff_rune_hist": l1, "huff_tile_bits_rune": l1, "huff_emit": l1 + C, "huff_emit_rune": l1 + C,
+                         "huff_dec_sync": C, "huff_dec_emit": C + l1, "huff_dec_flat": C + l1})
+        if name in ("3", "4"):
+            lc = sizes[0]                                   # the LZSS stream
+            kalg.update({"lzss_tok_emit": n + lc, "lzss_esc_write": n, "lzss_tile_periodic": n, "lzss_dec_resolve": lc + n, "lzss_dec_emit": lc + n,
+                         "lzss_dec_count": lc, "lzss_dec_lit": lc + n, "lzss_dec_patch": n})
+        launches = {**{k: v[0] for k, v in prof_e.items()}, **{k: v[0] for k, v in prof_d.items()}}
+        if dom in kalg:
+            # allk holds the kernel's TOTAL ms in the last timed pass; a kernel launched several times in a call (second looks over
+            # a handful of tiles) is priced at the whole call's time for the whole call's algorithmic bytes
             ent["dominant_kernel"]["algorithmic_bytes"] = kalg[dom]
+            ent["dominant_kernel"]["launches"] = launches.get(dom)
             ent["dominant_kernel"]["frac_of_hbm_peak"] = round(kalg[dom] / (allk[dom] / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)
+            ent["roofline"] = roofline_of(name, dom, kalg[dom], allk[dom])
+        else:
+            ent["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                               "traffic": (workload_traffic(name, dom) or [None])[0]}
         # bit-exact against the oracle on a sample (prefix of the same buffer), through the same layers
         smp = {"2b": 32 << 20, "skewed": 32 << 20, "3": 2 << 20, "4": 8 << 20}[name]
         smp = min(smp, n)
@@ -291,6 +347,7 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
                     "encode_frac_of_hbm_peak": round((2 * k * n + C) / (te / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "per_chunk_ms": [round(x / reps * 1e3, 4) for x in per_chunk], "pass_ms": [round(x, 3) for x in passes],
                     "kernels_ms_per_chunk": {kk: round(v[1] / (reps * k), 4) for kk, v in sorted(prof5.items())},
+                    "roofline": roofline_of("headline", "huff_emit", n + C // k, prof5["huff_emit"][1] / prof5["huff_emit"][0]) if "huff_emit" in prof5 else None,
                     "note": "one GPU, chunks one after the other, wall time per call; one allocation for the 8 inputs and one for the 8 outputs, "
                             "two warm-up passes; the sharded form with its gather is the --gpus N run"}
         del srcs, outs, segs, dec, src_all, out_all
@@ -306,6 +363,132 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
     return out
+
+
+def _host_call(fn, buf, *extra):
+    """One host-buffer C-ABI call on a numpy array (pageable memory in, library-owned block out, PCIe both ways): (result, ms)."""
+    import ctypes
+
+    import numpy as np
+    from raisin_amd import _lib
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    got = ctypes.c_size_t(0)
+    t0 = time.perf_counter()
+    _lib.check(fn(buf.ctypes.data_as(ctypes.c_char_p), buf.size, *extra, ctypes.byref(out), ctypes.byref(got)))
+    ms = (time.perf_counter() - t0) * 1e3
+    res = np.ctypeslib.as_array(out, shape=(got.value,)).copy() if got.value else np.empty(0, np.uint8)
+    _lib.lib().rsn_free(out)
+    return res, ms
+
+
+def config1_and_host_api(torch, device, n, with_host_gib):
+    """SURVEY 8(d) config 1 and the host-buffer rates, both PCIe-INCLUSIVE and therefore never `value`:
+      "1": `huffman` on 64 KiB of text (samIAm tiled and cut to 65 536 B; enwik8 is not available) through rsn_huffman_compress /
+           _decompress exactly as the cgo shim calls them, next to the single-thread oracle on the same bytes -- the one size at which
+           the reference's own regime applies, and where a GPU call's fixed cost (launches + two PCIe round trips) is expected to lose;
+      "host_api": ms per call at the bench size for Huffman (2a) and LZSS (config 4's text), host buffer in, host buffer out."""
+    import numpy as np
+    import workloads as W
+    from oracle import oracle as O
+    from raisin_amd import _lib
+    L = _lib.lib()
+    out = {}
+    sam = open(os.path.join(ROOT, "tests", "golden", "samiam.txt"), "rb").read()
+    data = (sam * (65536 // len(sam) + 1))[:65536]
+    arr = np.frombuffer(data, dtype=np.uint8)
+    enc, dec = [], []
+    for _ in range(25):
+        c, te = _host_call(L.rsn_huffman_compress, arr)
+        d, td = _host_call(L.rsn_huffman_decompress, c)
+        enc.append(te)
+        dec.append(td)
+    enc, dec = sorted(enc)[len(enc) // 2], sorted(dec)[len(dec) // 2]
+    oe, od = [], []
+    for _ in range(5):
+        rc, t = _timed(lambda: O.huffman_compress(data))
+        oe.append(t * 1e3)
+        rd, t = _timed(lambda: O.huffman_decompress(rc))
+        od.append(t * 1e3)
+    oe, od = sorted(oe)[2], sorted(od)[2]
+    out["1"] = {"algorithm": "huffman", "bytes": len(data), "api": "host buffers (rsn_huffman_compress / _decompress), PCIe included",
+                "encode_ms": round(enc, 4), "decode_ms": round(dec, 4), "round_trip_MBps": round(len(data) / 1e6 / ((enc + dec) / 1e3), 2),
+                "ratio_pct": round(100.0 * c.size / len(data), 3), "lossless": bool(d.tobytes() == data),
+                "bit_exact_vs_oracle": bool(c.tobytes() == rc), "compressed_bytes": int(c.size),
+                "cpu_baseline": {"value": round(len(data) / 1e6 / ((oe + od) / 1e3), 2), "unit": "MB/s", "cores": 1, "kind": "port",
+                                 "sample": "the whole 64 KiB, single-thread oracle: encode %.3f ms + decode %.3f ms (median of 5)" % (oe, od)},
+                "gpu_faster_than_one_cpu_core": bool(enc + dec < oe + od),
+                "note": "median of 25 calls; a call is ~10 launches and 2-3 host round trips: at this size the fixed cost is the time"}
+    if with_host_gib:
+        ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, second call (pages mapped, arenas grown); never `value`"}
+        src = W.config_input("2a", n, device).cpu().numpy()
+        for rep in range(2):
+            c, te = _host_call(L.rsn_huffman_compress, src)
+            d, td = _host_call(L.rsn_huffman_decompress, c)
+        ha["huffman_2a"] = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src)),
+                            "encode_GBps": round(n / te / 1e6, 2), "decode_GBps": round(n / td / 1e6, 2)}
+        del c, d
+        src = W.config_input("4", n, device).cpu().numpy()
+        for rep in range(2):
+            c, te = _host_call(L.rsn_lzss_compress, src, 4096)
+            d, td = _host_call(L.rsn_lzss_decompress, c)
+        ha["lzss_text"] = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src)),
+                           "encode_GBps": round(n / te / 1e6, 2), "decode_GBps": round(n / td / 1e6, 2)}
+        out["host_api"] = ha
+        L.rsn_trim()
+    return out
+
+
+def config5_dealt(torch, dist, device, n, rank, world, backend, k=8):
+    """BASELINE configs[4] in SURVEY 8(d)'s form: EIGHT independent chunks (seeds 0x5EED0050+i) dealt over the ranks, chunk i -> rank
+    i mod world (raisin_amd/shard.py), every rank encodes its chunks one after the other, time = the slowest rank's; then the finished
+    segments go to rank 0 (all_gather of sizes + grouped send/recv; RCCL over xGMI under nccl), timed on its own.  Total work is
+    fixed as N grows: this object is the STRONG-scaling view next to the line's weak-scaling `value`."""
+    import workloads as W
+    from raisin_amd import huffman
+    from raisin_amd import shard as _shard
+    mine = _shard.chunks_for_rank(k, rank, world)
+    cap = (n + n // 8 + (1 << 20) + 255) & ~255
+    srcs = [W.config_input("5", n, device, chunk=i) for i in mine]
+    outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in mine]
+
+    def fence():
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for j in range(len(mine)):
+        huffman.compress_tensor(srcs[j], out=outs[j])
+    fence()
+    t0 = time.perf_counter()
+    segs = [huffman.compress_tensor(srcs[j], out=outs[j]) for j in range(len(mine))]
+    torch.cuda.synchronize(device)
+    mine_s = time.perf_counter() - t0
+    fence()
+    cpu = torch.device("cpu")
+    t_max = _shard.max_over_ranks(dist, mine_s, device if backend == "nccl" else cpu)
+    dec = torch.empty(n + (1 << 20), dtype=torch.uint8, device=device)
+    ok = all(bool(torch.equal(huffman.decompress_tensor(segs[j], out=dec), srcs[j])) for j in range(len(mine)))
+    ok_all = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if backend == "nccl" else cpu)
+    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    # gather: round j moves every rank's j-th segment (ranks with fewer chunks send an empty one)
+    fence()
+    g0 = time.perf_counter()
+    total = 0
+    rounds = (k + world - 1) // world
+    for j in range(rounds):
+        seg = segs[j] if j < len(segs) else torch.empty(0, dtype=torch.uint8, device=device)
+        if backend != "nccl":
+            seg = seg.cpu()
+        got = _shard.gather_segments(dist, seg, 0)
+        if rank == 0:
+            total += sum(int(x.numel()) for x in got)
+        del got
+    torch.cuda.synchronize(device)
+    gather_ms = (time.perf_counter() - g0) * 1e3
+    return {"chunks": k, "chunks_per_rank": [len(_shard.chunks_for_rank(k, r, world)) for r in range(world)], "bytes": k * n,
+            "encode_ms": round(t_max * 1e3, 3), "encode_MBps": round(k * n / 1e6 / t_max, 1), "scaling": "strong",
+            "gather_ms": round(gather_ms, 3), "gathered_bytes": total, "lossless": bool(int(ok_all.item()) == 1),
+            "note": "8 x %d MiB chunks, chunk i -> rank i mod %d; encode only (what CompressFiles does per file); time = max over ranks" % (n >> 20, world)}
 
 
 def self_launch(n_ranks):
@@ -334,9 +517,11 @@ def main():
     ap.add_argument("--mib", type=int, default=1024, help="buffer size per GPU (default: the 1 GiB of BASELINE.json)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs after the timed region")
-    ap.add_argument("--others", default="2b,skewed,3,4,5")
+    ap.add_argument("--others", default="1,2b,skewed,3,4,5", help="1 = config 1 (64 KiB, host-buffer API) + the host-API rates at the bench size")
+    ap.add_argument("--no-dealt", action="store_true", help="N > 1: skip config 5's eight dealt chunks (the strong-scaling view)")
     ap.add_argument("--profile-only", default="", help="run ONLY these other configs (no headline step, no CPU baselines) and print their entries: "
                     "what scripts/profile.sh puts under rocprofv3, so that a workload's counters hold that workload's launches and nothing else")
+    ap.add_argument("--gather-hang-ok", action="store_true", help="exit 0 even when the segment gather is still pending after 120 s")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (control-flow test: all ranks share GPU 0)")
     args = ap.parse_args()
 
@@ -437,6 +622,14 @@ def main():
 
     gather_ms = None
     gather_stuck = False
+    dealt = None
+    if dist is not None and not args.no_dealt:
+        del dec_buf
+        torch.cuda.empty_cache()
+        try:
+            dealt = config5_dealt(torch, dist, device, n, rank, world, args.dist_backend)
+        except Exception as e:                              # noqa: BLE001 -- extra information: reported, never instead of the line
+            dealt = {"error": "%s: %s" % (type(e).__name__, e)}
     if dist is not None:
         # config 5: compressed segments to rank 0 over RCCL, timed on its own (not part of `value`)
         seg = c.clone() if args.dist_backend == "nccl" else c.cpu()
@@ -491,8 +684,10 @@ def main():
             "metric": "encode+decode MB/s", "value": round(world * K * n / 1e6 / t_max, 1), "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(t_max / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "huffman encode+decode, %d MiB uniform-random bytes 0x00-0x7F per GPU (BASELINE configs[%d]), "
-                                   "splitmix64 seed 0x%X" % (args.mib, 1 if world == 1 else 4, seed),
+            "config": {"workload": ("huffman encode+decode, %d MiB uniform-random bytes 0x00-0x7F (BASELINE configs[1]), splitmix64 seed 0x%X" % (args.mib, seed))
+                       if world == 1 else
+                       ("WEAK scaling: one %d MiB chunk per GPU (BASELINE configs[4]'s chunks, seeds 0x5EED0050+rank), huffman encode+decode of it "
+                        "on every rank, no data-path collective; configs[4]'s fixed eight chunks dealt over the ranks are under config5_dealt" % args.mib),
                        "algorithm": "huffman", "bytes_per_gpu": n, "chunks": world},
             "encode_MBps": round(n / 1e6 / (enc_ms / 1e3), 1), "decode_MBps": round(n / 1e6 / (dec_ms / 1e3), 1),
             "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
@@ -505,6 +700,8 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 3)
+        if dealt is not None:
+            out["config5_dealt"] = dealt
         if dist is not None and gather_ms is None:
             out["gather_ms"] = None
             out["gather_note"] = "segment gather did not complete within 120 s" if gather_stuck else "segment gather failed its size check"
@@ -531,17 +728,25 @@ def main():
             if not args.no_others:
                 names = [x for x in args.others.split(",") if x]
                 try:
-                    out["other_configs"] = run_other_configs(torch, device, n, cores, not args.no_cpu, names)
+                    first = {}
+                    if "1" in names:
+                        names.remove("1")
+                        try:
+                            first = config1_and_host_api(torch, device, n, with_host_gib=True)
+                        except Exception as e:              # noqa: BLE001
+                            first = {"1": {"error": "%s: %s" % (type(e).__name__, e)}}
+                    out["other_configs"] = {**first, **run_other_configs(torch, device, n, cores, not args.no_cpu, names)}
                     out["other_configs_note"] = ALG_NOTE + "; one warm-up pass, then the mean of 2 timed passes per config"
                 except Exception as e:                      # noqa: BLE001
                     out["other_configs_error"] = "%s: %s" % (type(e).__name__, e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         if gather_stuck:
-            # a collective is still pending: leave without waiting for it.  The throughput line is out and says so (gather_ms null +
-            # gather_note); the exit code stays 0 -- the gather is extra information, and a failing code could cost the job its line.
+            # a collective is still pending: leave without waiting for it.  The throughput line is already out (and says so:
+            # gather_ms null + gather_note), so a failing exit code cannot lose it -- and a hung RCCL collective must not read as
+            # success.  --gather-hang-ok restores exit 0 for a driver that insists on it.
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(0 if args.gather_hang_ok else 3)
         dist.destroy_process_group()
 
 

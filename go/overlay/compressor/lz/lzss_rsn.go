@@ -5,10 +5,11 @@
 // librsn (include/rsn.h).  lzss.go also defines Writer, Reader, NewWriter, NewWriterLevel,
 // NewReader, EncodeOpeningSymbols, ... and must stay untagged; integration is two steps
 // (INTEGRATION.md):
-//   1. move the bodies of CompressAsync (lzss.go:109-154, with its workers :156-184), Compress
-//      (:224-316) and Decompress (:323-364) out of lzss.go into a new lzss_purego.go that starts
-//      with `//go:build !rsn`;
-//   2. drop this file next to it.
+//   1. go/overlay/split.py moves CompressAsync (lzss.go:109-154), compressorWorkerAsync (:156-164),
+//      Compress (:224-316) and Decompress (:323-364) with the `sync` import out of lzss.go into a
+//      new lzss_purego.go (`//go:build !rsn`); compressorWorker (:166-184) stays, CompressRecursive
+//      (:203) calls it;
+//   2. and drops this file next to it.
 // Go packages cannot share unexported helpers, so rsnCall is repeated from the huffman overlay.
 // Written without a Go toolchain; tests/abi_shim_test.c replays this call sequence in C.
 package lz

@@ -1,6 +1,8 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# runs on the GPU box (gpurun): from the snapshot's root, or from the current directory when started by hand
+cd "${GRAFT_REPO_ROOT:-$(pwd)}" || exit 1
 mkdir -p gpurun_out
-TAG=${1:-r03b}
+TAG=${1:-r04a}
 (timeout 2400 python -m pytest tests -m gpu -x -q --durations=5 2>&1 | tail -12) > gpurun_out/t_full.log 2>&1
 tail -12 gpurun_out/t_full.log
 (timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo rc=$?)

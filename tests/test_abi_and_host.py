@@ -211,3 +211,64 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     subprocess.run(cmd, check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "host sanitizer run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _reference_checkout(tmp_path):
+    import shutil
+    ref = "/root/reference/compressor"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference is not on this machine (it never ships to the GPU box)")
+    root = tmp_path / "raisin"
+    for pkg in ("lz", "huffman"):
+        shutil.copytree(os.path.join(ref, pkg), root / "compressor" / pkg)
+    for dirpath, _, files in os.walk(root):
+        os.chmod(dirpath, 0o755)
+        for f in files:
+            os.chmod(os.path.join(dirpath, f), 0o644)
+    return root
+
+
+def _split_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rsn_split", os.path.join(ROOT, "go", "overlay", "split.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cgo_recipe_splits_the_reference_packages(tmp_path):
+    """INTEGRATION.md step 1 as a program (VERDICT r3 task 1a): go/overlay/split.py on a copy of the reference's two packages.
+    Under both tags every package-level identifier used is defined once, no import is orphaned (lzss.go's `sync` goes with
+    CompressAsync), compressorWorker stays where CompressRecursive (lzss.go:203) sees it, and no line is lost."""
+    root = _reference_checkout(tmp_path)
+    S = _split_module()
+    assert S.main([str(root), "--dry-run"]) == 0
+    assert S.main([str(root)]) == 0
+    lz = (root / "compressor" / "lz" / "lzss.go").read_text()
+    pure = (root / "compressor" / "lz" / "lzss_purego.go").read_text()
+    assert "func compressorWorker(" in lz and "func CompressRecursive(" in lz and '"sync"' not in lz
+    assert pure.startswith("//go:build !rsn\n// +build !rsn\n") and '"sync"' in pure
+    for f in ("func CompressAsync(", "func compressorWorkerAsync(", "func Compress(", "func Decompress("):
+        assert f in pure and f not in lz
+    assert (root / "compressor" / "lz" / "lzss_rsn.go").read_text().startswith("//go:build rsn\n// +build rsn\n")
+    hp = (root / "compressor" / "huffman" / "huffman_purego.go").read_text()
+    hf = (root / "compressor" / "huffman" / "huffman.go").read_text()
+    assert "func Compress(" in hp and "func Decompress(" in hp and "func Compress(" not in hf and "func NewWriter(" in hf
+    with pytest.raises(SystemExit):              # a second run finds nothing to move and says so
+        S.main([str(root)])
+
+
+def test_cgo_recipe_check_catches_the_r3_defects(tmp_path):
+    """The check is not vacuous: the recipe VERDICT r3 faulted (compressorWorker moved with CompressAsync) is reported, and so is
+    an import left behind."""
+    root = _reference_checkout(tmp_path)
+    S = _split_module()
+    bad = dict(S.PLAN["lz"], move=["CompressAsync", "compressorWorkerAsync", "compressorWorker", "Compress", "Decompress"])
+    problems = S.process(str(root), "lz", bad, os.path.join(ROOT, "go", "overlay"), True)
+    assert any("-tags rsn" in p and "compressorWorker" in p for p in problems), problems
+    src = (root / "compressor" / "lz" / "lzss.go").read_text()
+    kept, moved = S.split_source(src, S.PLAN["lz"]["move"], "lz")
+    kept_with_sync = kept.replace('\t"strconv"\n', '\t"strconv"\n\t"sync"\n', 1)
+    _, _, imps = S.import_block(src)
+    probs = S.check_build({"lzss.go": kept_with_sync, "lzss_purego.go": moved}, set(S.package_level_defs(src)), {i for i, _ in imps}, "lz")
+    assert any("imports sync and does not use it" in p for p in probs), probs

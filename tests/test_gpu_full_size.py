@@ -71,13 +71,16 @@ def test_config2b_huffman_1GiB_uniform_8bit(oracle):
     c2 = huffman.compress_tensor(d)
     d2 = huffman.decompress_tensor(c2)
     assert d2.numel() == d.numel() and torch.equal(d2, d)
-    pre = 32 << 20                                                  # oracle-exact on a 32 MiB prefix: bytes out of both directions
+    # oracle-exact, bytes out of both directions, at 256 MiB (the regimes that make 2b hard -- ~3e5 symbols, codes past
+    # 24 bits, second-level tables, the host heap -- grow with the size; the single-thread oracle does 32 MiB in under a second)
+    pre = 256 << 20
     host = bytes(src[:pre].cpu().numpy())
     got = bytes(huffman.compress_tensor(src[:pre].contiguous()).cpu().numpy())
     ref = oracle.huffman_compress(host)
     assert got == ref
     back = bytes(huffman.decompress_tensor(torch.frombuffer(bytearray(ref), dtype=torch.uint8).cuda()).cpu().numpy())
     assert back == oracle.huffman_decompress(ref)
+    assert max(x[3] for x in oracle.huffman_table(host)) > 24       # the long-code regime is in the sample
     runes = oracle.utf8_runes(host)                                 # Go's `range string(b)`: one rune per valid sequence or invalid byte
     want = int(((runes >= 0x80).astype(np.int64) + (runes >= 0x800) + (runes >= 0x10000) + 1).sum())
     assert len(back) == want > pre                                  # string(rune) written back (huffman.go:138)
@@ -97,7 +100,14 @@ def test_config4_layered_1GiB_text(oracle):
     assert l2.numel() < l1.numel() < GIB
     back1 = huffman.decompress_tensor(l2)
     assert back1.numel() == l1.numel() and torch.equal(back1, l1)   # the inner layer comes back bit for bit
-    del l1
+    # the Huffman layer at FULL size against the oracle, both directions: its input is the ~700 MB LZSS stream --
+    # bytes 0xFF in it are not UTF-8, so this is the rune path at scale, lossless only because `<` never occurs in the text
+    l1_host = bytes(l1.cpu().numpy())
+    cores = oracle.host_cores()
+    ref2 = oracle.huffman_compress_mt(l1_host, cores)
+    assert bytes(l2.cpu().numpy()) == ref2
+    assert oracle.huffman_decompress_mt(ref2, cores) == l1_host
+    del l1, l1_host, ref2
     back = lz.decompress_tensor(back1)
     assert back.numel() == GIB and torch.equal(back, src)           # lossless through both layers
     del back, back1, l2
@@ -246,6 +256,27 @@ def test_bench_two_ranks_control_flow():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["lossless"] is True and j["scaling"] == "weak"
     assert j["config"]["chunks"] == 2 and "gather_ms" in j and j["value"] > 0
+    d5 = j["config5_dealt"]                              # configs[4]'s eight chunks dealt over the two ranks, then gathered
+    assert d5["chunks"] == 8 and d5["chunks_per_rank"] == [4, 4] and d5["lossless"] is True and d5["scaling"] == "strong"
+    assert d5["gathered_bytes"] > 8 * (64 << 20) * 7 // 8 and d5["encode_ms"] > 0
+
+
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 with the DEFAULT backend (nccl = RCCL, one GPU per rank: init_process_group with a device id, the barrier,
+    max-over-ranks on device tensors, gather_segments' all_gather + batch_isend_irecv over xGMI).  Needs two GPUs: skipped on the
+    one-GPU boxes this suite has run on so far, so the first box with two exercises the branch."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL branch needs two")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--mib", "256"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["lossless"] is True and j["value"] > 0
+    assert j["gather_ms"] is not None and j["gather_ms"] > 0
+    assert j["config5_dealt"]["chunks"] == 8 and j["config5_dealt"]["lossless"] is True
 
 
 def test_bench_launches_its_own_ranks():
