@@ -36,7 +36,7 @@ struct Ctx {
     std::vector<hipEvent_t> free_events;
 
     struct Buf { void *p = nullptr; size_t cap = 0; };
-    enum { N_BUFS = 34 };   // 28..33: the batch pipeline's ring
+    enum { N_BUFS = 36 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
 

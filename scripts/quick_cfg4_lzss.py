@@ -10,4 +10,4 @@ _lib.prof_enable(True); _lib.prof_reset()
 t0 = time.perf_counter(); c = lz.compress_tensor(src); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("config 4 lzss layer: %.1f ms -> %d B" % ((t1 - t0) * 1e3, c.numel()))
 for k, (cnt, ms) in sorted(_lib.prof_get().items()):
-    if True: print("  %-22s %3d launches  %.3f ms" % (k, cnt, ms))
+    print("  %-22s %3d launches  %.3f ms" % (k, cnt, ms))

@@ -185,7 +185,8 @@ def test_device_resident_round_trip_256MiB(huff):
 def test_second_level_tables_and_switches(oracle):
     """Codes longer than the first-level table: sub-tables in LDS (byte alphabets), through L2 (rune alphabets with tens of
     thousands of symbols), and the bit-by-bit walk below them (Fibonacci counts: 29-bit codes).  The same streams decode
-    the same with RSN_DEC_NO_LUT2=1 (no second level at all) and RSN_DEC_K=8 (a smaller first level): separate processes,
+    the same with RSN_DEC_NO_LUT2=1 (no second level at all), RSN_DEC_K=8 (a smaller first level), RSN_DEC_KWIDE=0 (first level no
+    wider than the longest code: the r03 rule), RSN_DEC_FUSED=1 (the one-pass decoder with its look-back) and RSN_NO_MULTI=1: separate processes,
     the switches are read once."""
     import hashlib
     import os
@@ -198,16 +199,16 @@ def test_second_level_tables_and_switches(oracle):
             "from oracle import oracle\n"
             "from test_gpu_huffman_encode import fib_skewed, rnd_bytes\n"
             "import workloads as W\n"
-            "for d in (fib_skewed(30), bytes(W.skewed_bytes(3 << 20).numpy()), rnd_bytes(11, 3 << 20)):\n"
+            "for d in (fib_skewed(30), bytes(W.skewed_bytes(3 << 20).numpy()), rnd_bytes(11, 3 << 20), bytes(W.config_input('4', 3 << 20).numpy()), b'ab' * 70000 + b'c'):\n"
             "    c = oracle.huffman_compress(d)\n"
             "    print(hashlib.sha256(huffman.Decompress(c)).hexdigest(), hashlib.sha256(oracle.huffman_decompress(c)).hexdigest())\n"
             ) % (root, os.path.join(root, "tests"))
     outs = []
-    for env in ({}, {"RSN_DEC_NO_LUT2": "1"}, {"RSN_DEC_K": "8"}):
+    for env in ({}, {"RSN_DEC_NO_LUT2": "1"}, {"RSN_DEC_K": "8"}, {"RSN_DEC_KWIDE": "0"}, {"RSN_DEC_FUSED": "1"}, {"RSN_NO_MULTI": "1"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l.split() for l in r.stdout.strip().splitlines()]
-        assert len(lines) == 3 and all(a == b for a, b in lines), (env, lines)
+        assert len(lines) == 5 and all(a == b for a, b in lines), (env, lines)
         outs.append(lines)
-    assert outs[0] == outs[1] == outs[2]
+    assert all(o == outs[0] for o in outs)
