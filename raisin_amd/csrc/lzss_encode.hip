@@ -153,10 +153,25 @@ __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in
 // The optimistic form: most inputs hold no byte that needs an escape (5C, FF) at all, and then the escaped stream is the input with
 // '<' mapped to FF (lzss.go:373-377), every byte in its place.  One pass writes exactly that and raises a flag if it met a 5C or FF;
 // only then do the counting pass, the scan and k_esc_write run (the flagged attempt cost one copy).
-__global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ fc, unsigned long long *__restrict__ flag) {
+// (r04) The same pass also answers k_tile_periodic's question for the common window -- does every byte equal the byte Wp before it? -- from
+// the bytes it has in registers and a second load Wp earlier that the neighbouring block has just brought into the L2: one flag per block;
+// k_tiles_from_blocks turns them into the tiles' records.  (Config 3: k_tile_periodic read tile + window again from memory, 0.60 ms per
+// GiB; comparing the INPUT is the same as comparing the escaped stream while nothing needs an escape: '<' -> FF is injective on such input.)
+__global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ fc, unsigned long long *__restrict__ flag,
+                                                uint32_t Wp, uint8_t *__restrict__ same_blk) {
     const size_t P = (size_t)blockIdx.x * ESC_TILE + threadIdx.x * 16;
     uint32_t w[4]; int cnt;
     load16(in, n, P, w, &cnt);                                             // (bytes beyond n read as zero: neither special nor '<')
+    bool same = true;
+    if (Wp) {                                                              // (a multiple of 16: the earlier bytes are one aligned load too)
+        if (P < Wp) same = cnt == 0;
+        else if (cnt) {
+            uint32_t v[4]; int c2;
+            load16(in, n, P - Wp, v, &c2);
+            if (cnt == 16) same = ((w[0] ^ v[0]) | (w[1] ^ v[1]) | (w[2] ^ v[2]) | (w[3] ^ v[3])) == 0;
+            else for (int k = 0; k < cnt; k++) same = same && ((w[k >> 2] ^ v[k >> 2]) >> (8 * (k & 3)) & 0xFF) == 0;
+        }
+    }
     uint32_t special = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); w[j] |= bytes_equal(w[j], 0x3Cu); }
@@ -164,8 +179,14 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
     uint8_t *d = fc + P;
     if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
     else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    if (Wp) {
+        const int all = __syncthreads_and(same);
+        if (threadIdx.x == 0) same_blk[blockIdx.x] = (uint8_t)all;
+    }
 }
 
+// k_tile_periodic's records from k_esc_try's block flags: a tile is W-periodic iff every block that overlaps [t0, t0 + tile + W - 1) repeats
+// the bytes W before it (block granularity: a stretch that ends inside the last block is walked like any other tile)
 // ------------------------------------------------------------------ E2: match search
 struct MatchArgs {
     const uint8_t *fc; uint32_t E; uint32_t W; uint32_t DW;   // DW = diagonals per wave
@@ -741,6 +762,19 @@ __device__ __forceinline__ uint32_t row_ballot(bool p, int lane) {       // bit 
 template <int LW>
 __device__ __forceinline__ uint32_t row_read(uint32_t v, uint32_t j, int lane) {   // v of lane j of the caller's row (j the same within the row)
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & (uint32_t)(64 - LW)) + j) << 2), (int)v);
+}
+
+__global__ void k_tiles_from_blocks(const uint8_t *__restrict__ same_blk, uint32_t E, uint32_t W, uint32_t tile, uint32_t n_tiles, TileChain *__restrict__ tchain, uint32_t *__restrict__ step) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const unsigned long long t0 = (unsigned long long)t * tile;
+    bool ok = t0 >= W;
+    if (ok) {
+        const unsigned long long q_end = min(t0 + tile + W - 1, (unsigned long long)E);
+        for (unsigned long long b = t0 / ESC_TILE; b * ESC_TILE < q_end; b++) ok = ok && same_blk[b];
+    }
+    tchain[t] = TileChain{0, 0, ok ? 2u : 0u, 0};
+    step[t] = 0;
 }
 
 // W-periodic tiles (config 3 is nothing else): fc[q] == fc[q - W] for every q the tile's matches can reach, so every position p has the
@@ -2434,11 +2468,16 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     unsigned long long *h64 = (unsigned long long *)hp;
     static const bool no_try = getenv("RSN_LZSS_ESC_TWO_PASS") != nullptr;   // A/B switch: always count, scan, write
     bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
+    // (the window, should nothing need an escape -- then E = n; a multiple of 16 for k_esc_try's periodicity flags, see there)
+    const uint32_t Wp = window > 0 && (uint64_t)window <= HWMAX && (uint64_t)window < n && window % 16 == 0 ? (uint32_t)window : 0u;
+    static const bool no_fused_periodic = getenv("RSN_LZSS_NO_FUSED_PERIODIC") != nullptr;   // A/B switch: k_tile_periodic reads the stream itself
+    uint8_t *d_same = nullptr;
     if (!no_try) {
         rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
+        if (Wp && !no_fused_periodic) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
         RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
         RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1);
+        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same);
         RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         copied = h64[0] == 0;
@@ -2539,7 +2578,9 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
     // (From 8192 tiles = 64 MiB: the sample is a launch that waits for one tile plus a host sync, 0.12 ms -- 15 % of an 8 MiB call,
     //  to save a stream of noise that size 0.13 ms.  RSN_LZSS_SAMPLE_MIN_TILES moves the threshold: the tests use it.)
-    if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain, d_step);
+    if (chain_mode && copied && d_same && W == Wp)
+        RSN_LAUNCH("lzss_tile_periodic", k_tiles_from_blocks, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, (const uint8_t *)d_same, E, W, (uint32_t)PT, n_pt, d_tchain, d_step);
+    else if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain, d_step);
     constexpr uint32_t SAMPLE_TILES = 64;
     static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
     const char *smin_env = getenv("RSN_LZSS_SAMPLE_MIN_TILES");
