@@ -95,6 +95,14 @@ RSN_API int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size
 RSN_API int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
                                uint8_t **outs, size_t *out_lens);
 
+/* ONE stream from `shards` slices of ONE input (intra-file sharding): per-slice histograms are summed, one tree and one
+ * header are built, every slice is encoded at its exact bit offset (the format has a single front pad, huffman.go:245-255) by a
+ * worker of its own, and the pieces are stitched on the way down.  The result is byte for byte rsn_huffman_compress(in, n).
+ * shards <= 0: RSN_HUFF_SHARDS, else one per device used.  Worker w runs on device (calling thread's + w mod D) mod visible,
+ * D = RSN_BATCH_DEVICES (default 1: the workers share the caller's device).  rsn_huffman_compress itself takes this path
+ * when RSN_HUFF_SHARDS > 1 is set in the environment.                                                                    */
+RSN_API int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_t **out, size_t *out_n);
+
 /* ---- device-resident entry points --------------------------------------
  * d_in / d_out are HIP device pointers on the calling thread's device; stream
  * is a hipStream_t (NULL = the thread's own stream).  The call returns after

@@ -28,7 +28,7 @@ _lib = None
 SYMBOLS = [
     "rsn_device_set", "rsn_device_count", "rsn_last_error", "rsn_version", "rsn_free", "rsn_trim",
     "rsn_huffman_compress", "rsn_huffman_decompress", "rsn_lzss_compress", "rsn_lzss_decompress", "rsn_lzss_compress_legacy",
-    "rsn_huffman_compress_batch",
+    "rsn_huffman_compress_batch", "rsn_huffman_compress_sharded",
     "rsn_huffman_compress_bound", "rsn_lzss_compress_bound",
     "rsn_huffman_compress_dev", "rsn_huffman_decompress_dev", "rsn_lzss_compress_dev", "rsn_lzss_decompress_dev",
     "rsn_prof_enable", "rsn_prof_reset", "rsn_prof_get", "rsn_huffman_table",
@@ -85,6 +85,7 @@ def lib():
     L.rsn_huffman_plan.restype = ctypes.c_int64
     L.rsn_huffman_parse_header.argtypes = [ctypes.c_char_p, sz, vp, vp, sz]
     L.rsn_huffman_parse_header.restype = ctypes.c_int64
+    L.rsn_huffman_compress_sharded.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(u8p), szp]
     L.rsn_huffman_compress_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), szp, ctypes.POINTER(u8p), szp]
     _lib = L
     return L

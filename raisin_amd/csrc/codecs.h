@@ -15,6 +15,12 @@ size_t lzss_compress_bound(size_t n);
 // is the capacity that would have sufficed.
 int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n,
                     HuffTree *tree_out, HuffCodes *codes_out);
+// the same in two halves, for one stream out of several slices of the input (rsn_huffman_compress_sharded, rsn_api.hip)
+struct HuffSlice { uint32_t tile = 0, n_tiles = 0; uint32_t *d_tile_hist = nullptr; uint16_t *d_smask = nullptr; bool ascii = true; std::vector<HuffSym> syms; };
+int huff_slice_hist(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, HuffSlice &sl);
+int huff_slice_emit(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, const HuffSlice &sl, const HuffTree &tree, const HuffCodes &codes, bool flat,
+                    const std::string &hdr, unsigned long long base_bits, unsigned long long slice_bits, uint8_t *d_out);
+bool huff_flat_code(const HuffTree &tree, const HuffCodes &codes);
 int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);

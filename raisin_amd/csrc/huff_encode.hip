@@ -21,8 +21,7 @@
 #include <chrono>
 #include <cstddef>
 
-#include "huff_host.h"
-#include "rsn_common.h"
+#include "codecs.h"
 
 namespace rsn {
 
@@ -877,65 +876,42 @@ size_t huff_compress_bound(size_t n) {
     return n * 21 / 8 + syms * 26 + 96;
 }
 
-// Encodes d_in[0..n) into d_out.  On RSN_ERR_CAPACITY *out_n holds the needed capacity.
-int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n,
-                    HuffTree *tree_out, HuffCodes *codes_out) {
-    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
-    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
+// The encoder in two halves, so that one stream can be produced from several SLICES of the input (rsn_huffman_compress_sharded: one
+// slice per worker / device).  huff_slice_hist: the slice's symbol counts (and what the emit pass wants kept: tile histograms, the
+// rune-start map).  huff_slice_emit: the slice's code bits at a given bit position of d_out, from the tree and codes of the WHOLE
+// input.  huff_encode_dev is the two in a row for a single slice.
+int huff_slice_hist(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, HuffSlice &sl) {
     static const bool no_small_tiles = getenv("RSN_HUFF_NO_SMALL_TILES") != nullptr;   // A/B switch
-    uint32_t tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
-    uint32_t n_tiles = (uint32_t)ceil_div(n, tile);
+    sl.tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
+    sl.n_tiles = (uint32_t)ceil_div(n, sl.tile);
     void *p;
-    int rc = dev_buf(c, 0, (size_t)n_tiles * 128 * 4, &p); if (rc) return rc;
-    uint32_t *d_tile_hist = (uint32_t *)p;
-
-    std::vector<HuffSym> syms;
-    bool ascii;
-    static const bool host_timing = getenv("RSN_HOST_TIMING") != nullptr;   // prints where the host side of a call spends its time
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto t0 = now();
-    uint16_t *d_smask = nullptr;                                          // rune path: which positions start a rune (k_rune_hist's classification, kept)
-    rc = hist_ascii_or_rune(c, s, d_in, n, n_tiles, tile, d_tile_hist, syms, ascii, &d_smask); if (rc) return rc;
-    if (!ascii && !no_small_tiles && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
-        tile = SMALL_TILE;
-        n_tiles = (uint32_t)ceil_div(n, tile);
+    int rc = dev_buf(c, 0, (size_t)sl.n_tiles * 128 * 4, &p); if (rc) return rc;
+    sl.d_tile_hist = (uint32_t *)p;
+    sl.d_smask = nullptr;                                                 // rune path: which positions start a rune (k_rune_hist's classification, kept)
+    rc = hist_ascii_or_rune(c, s, d_in, n, sl.n_tiles, sl.tile, sl.d_tile_hist, sl.syms, sl.ascii, &sl.d_smask); if (rc) return rc;
+    if (!sl.ascii && !no_small_tiles && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
+        sl.tile = SMALL_TILE;
+        sl.n_tiles = (uint32_t)ceil_div(n, sl.tile);
     }
-    const auto t1 = now();
+    return RSN_OK;
+}
 
-    std::string hdr;
-    emit_header(syms, hdr);   // syms is ascending by rune here
-    const auto t2 = now();
-    HuffTree tree; HuffCodes codes; std::string msg;
-    if (!build_tree(syms, tree, msg)) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
-    const auto t3 = now();
-    if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
-    const auto t4 = now();
-    if (host_timing) fprintf(stderr, "huffman encode host: histogram (kernels + D2H + compaction) %.2f ms, header %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n",
-                             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), syms.size());
-    if (tree_out) *tree_out = tree;
-    if (codes_out) *codes_out = codes;
-    if (!d_out) return RSN_OK;   // table introspection only
-
-    const unsigned pad = (unsigned)((8 - codes.total_bits % 8) % 8);            // huffman.go:245-249
-    hdr.append("\\\n");
-    hdr.push_back((char)pad);
+// hdr: the bytes in front of the payload that THIS slice writes (header || "\\\n" || pad byte for the first slice, nothing for the
+// others); base_bits: where the slice's first code bit goes, counted from d_out; slice_bits: how many it writes; flat: every code of the
+// (all-ASCII) alphabet has the same length.  Synchronises the stream.
+int huff_slice_emit(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, const HuffSlice &sl, const HuffTree &tree, const HuffCodes &codes, bool flat,
+                    const std::string &hdr, unsigned long long base_bits, unsigned long long slice_bits, uint8_t *d_out) {
+    void *p; int rc;
     const size_t H = hdr.size();
-    const size_t total = H + (size_t)((codes.total_bits + pad) / 8);
-    *out_n = total;
-    const size_t need = round_up(total, 16) + 32;
-    if (need > out_cap) { *out_n = need; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", need, out_cap); }
-
-    const unsigned long long base_bits = 8ull * H + pad;
-    if (codes.total_bits == 0) {   // one distinct symbol: code "" (huffman.go:110-116), no payload bytes
-        RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+    const uint32_t tile = sl.tile, n_tiles = sl.n_tiles;
+    if (slice_bits == 0) {   // one distinct symbol: code "" (huffman.go:110-116), no payload bytes
+        if (H) RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
         RSN_HIP(hipStreamSynchronize(s));
         return RSN_OK;
     }
 
     // ---- flat code: offsets are arithmetic (decided before any table is uploaded: this path needs none)
-    static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
-    if (ascii && codes.min_len == codes.max_len && codes.max_len <= 7 && !no_flat_emit) {
+    if (flat) {
         const unsigned L = codes.max_len;
         FlatEmitArgs fa{};
         fa.in = d_in; fa.n = n; fa.base_bits = base_bits; fa.out_words = (uint32_t *)d_out; fa.hdr_len = (uint32_t)H;
@@ -963,8 +939,8 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         return RSN_OK;
     }
 
-    // ---- code tables
-    const int mode = !ascii ? MODE_RUNE : (codes.max_len <= (unsigned)TAB_LEN_SHIFT ? MODE_ASCII : MODE_ASCII_WIDE);
+    // ---- code tables.  (An all-ASCII slice of an input that has runes elsewhere still takes the byte-indexed tables: its own bytes' codes.)
+    const int mode = !sl.ascii ? MODE_RUNE : (codes.max_len <= (unsigned)TAB_LEN_SHIFT ? MODE_ASCII : MODE_ASCII_WIDE);
     EmitArgs a{};
     uint8_t *d_len8 = nullptr;
     if (mode == MODE_RUNE) {
@@ -986,6 +962,7 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         memset(ht, 0, sizeof *ht);
         for (uint32_t i = 0; i < tree.n_leaves; i++) {
             const uint32_t r = tree.rune[i];
+            if (r >= 256) continue;                                // (a rune of another slice)
             ht->c64[r] = codes.code[i]; ht->l8[r] = codes.len[i];
             if (codes.max_len <= (unsigned)TAB_LEN_SHIFT) ht->t32[r] = ((uint32_t)codes.len[i] << TAB_LEN_SHIFT) | (uint32_t)codes.code[i];
         }
@@ -997,15 +974,14 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
     a.len8 = d_len8;
 
-
     // ---- tile bit offsets
     rc = dev_buf(c, 4, ((size_t)n_tiles * 2 + 2) * 8, &p); if (rc) return rc;
     unsigned long long *d_tile_bits = (unsigned long long *)p;
     unsigned long long *d_tile_off = d_tile_bits + n_tiles;
     if (mode == MODE_RUNE) {
-        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, tile, d_tile_bits, (const uint16_t *)d_smask);
+        RSN_LAUNCH("huff_tile_bits_rune", k_tile_bits_rune, dim3(std::min<uint32_t>(n_tiles, 4096)), dim3(HB), 0, s, d_in, n, d_len8, n_tiles, tile, d_tile_bits, (const uint16_t *)sl.d_smask);
     } else {
-        RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, d_tile_hist, d_len8, n_tiles, d_tile_bits);
+        RSN_LAUNCH("huff_tile_bits", k_tile_bits, dim3((uint32_t)ceil_div(n_tiles, HB / 64)), dim3(HB), 0, s, sl.d_tile_hist, d_len8, n_tiles, d_tile_bits);
     }
     rc = scan_u64(c, s, "huff_scan", d_tile_bits, d_tile_off, n_tiles, d_tile_off + n_tiles); if (rc) return rc;
 
@@ -1013,10 +989,10 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const uint32_t tiles_per_block = (uint32_t)std::max<size_t>(1, ceil_div(n_tiles, 2048));
     const uint32_t n_blocks = (uint32_t)ceil_div(n_tiles, tiles_per_block);
     a.in = d_in; a.n = n; a.tile_off = d_tile_off; a.base_bits = base_bits;
-    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out; a.tile = tile; a.smask = d_smask;
+    a.tiles_per_block = tiles_per_block; a.n_tiles = n_tiles; a.out_words = (uint32_t *)d_out; a.tile = tile; a.smask = sl.d_smask;
     RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
-               (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + codes.total_bits);
-    RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
+               (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + slice_bits);
+    if (H) RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
     static const bool emit16 = getenv("RSN_EMIT16") != nullptr;   // A/B switch: the 16-symbols-per-lane generic kernel
     static const int emit_spl = [] { const char *e = getenv("RSN_EMIT_SPL"); return e ? atoi(e) : 32; }();
     if (mode == MODE_ASCII && !emit16 && emit_spl == 64) RSN_LAUNCH("huff_emit", k_emit_ascii32<64>, dim3(n_blocks), dim3(HB), 0, s, a);
@@ -1027,6 +1003,51 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     else RSN_LAUNCH("huff_emit_rune", k_emit<MODE_RUNE>, dim3(n_blocks), dim3(HB), 0, s, a);
     RSN_HIP(hipStreamSynchronize(s));   // hdr (host memory) must outlive the copy
     return RSN_OK;
+}
+
+bool huff_flat_code(const HuffTree &tree, const HuffCodes &codes) {
+    static const bool no_flat_emit = getenv("RSN_NO_FLAT") != nullptr;
+    if (no_flat_emit || codes.min_len != codes.max_len || codes.max_len > 7 || codes.max_len == 0) return false;
+    for (uint32_t i = 0; i < tree.n_leaves; i++) if (tree.rune[i] >= 0x80) return false;
+    return true;
+}
+
+// Encodes d_in[0..n) into d_out.  On RSN_ERR_CAPACITY *out_n holds the needed capacity.
+int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n,
+                    HuffTree *tree_out, HuffCodes *codes_out) {
+    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
+    static const bool host_timing = getenv("RSN_HOST_TIMING") != nullptr;   // prints where the host side of a call spends its time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    HuffSlice sl;
+    int rc = huff_slice_hist(c, s, d_in, n, sl); if (rc) return rc;
+    const auto t1 = now();
+
+    std::string hdr;
+    emit_header(sl.syms, hdr);   // syms is ascending by rune here
+    const auto t2 = now();
+    HuffTree tree; HuffCodes codes; std::string msg;
+    if (!build_tree(sl.syms, tree, msg)) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
+    const auto t3 = now();
+    if (!assign_codes(tree, codes, msg)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
+    const auto t4 = now();
+    if (host_timing) fprintf(stderr, "huffman encode host: histogram (kernels + D2H + compaction) %.2f ms, header %.2f ms, tree %.2f ms, codes %.2f ms, %u symbols\n",
+                             ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), tree.n_leaves);
+    if (tree_out) *tree_out = tree;
+    if (codes_out) *codes_out = codes;
+    if (!d_out) return RSN_OK;   // table introspection only
+
+    const unsigned pad = (unsigned)((8 - codes.total_bits % 8) % 8);            // huffman.go:245-249
+    hdr.append("\\\n");
+    hdr.push_back((char)pad);
+    const size_t H = hdr.size();
+    const size_t total = H + (size_t)((codes.total_bits + pad) / 8);
+    *out_n = total;
+    const size_t need = round_up(total, 16) + 32;
+    if (need > out_cap) { *out_n = need; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", need, out_cap); }
+    return huff_slice_emit(c, s, d_in, n, sl, tree, codes, sl.ascii && huff_flat_code(tree, codes), hdr, 8ull * H + pad, codes.total_bits, d_out);
 }
 
 }  // namespace rsn

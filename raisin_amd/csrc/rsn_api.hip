@@ -11,10 +11,15 @@
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 
 namespace rsn {
+
+namespace {
+int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+}  // namespace
 
 Ctx &ctx() {
     static thread_local Ctx c;
@@ -367,13 +372,20 @@ int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_
     return lzss_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
 }
 
-int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
-    if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+static int huffman_compress_single(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     // typical outputs are < n; the exact need is reported back on RSN_ERR_CAPACITY
     return host_call(in, n, out, out_n, n + n / 8 + (1 << 16),
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return huff_encode_dev(c, s, di, n, dout, cap, got, nullptr, nullptr);
                      });
+}
+
+int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    // RSN_HUFF_SHARDS=<G> > 1: one stream out of G slices, a worker (and, with RSN_BATCH_DEVICES, a device) each -- same bytes
+    static const int env_shards = env_int("RSN_HUFF_SHARDS", 0);
+    if (env_shards > 1 && n >= ((size_t)1 << 16)) return rsn_huffman_compress_sharded(in, n, env_shards, out, out_n);
+    return huffman_compress_single(in, n, out, out_n);
 }
 
 int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
@@ -445,8 +457,6 @@ struct BatchPipe {
     bool wait(const size_t &counter, size_t want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return rc != RSN_OK || counter >= want; }); return rc == RSN_OK; }
     void done(size_t &counter) { { std::lock_guard<std::mutex> lk(mu); counter++; } cv.notify_all(); }
 };
-
-static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 
 // The chunks `idx` through one device's pipeline, on the calling thread's context (already initialised on its device).
 // On failure the chunks this worker has produced stay in outs[] for the caller to undo; the message is in c.err.
@@ -583,6 +593,161 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
     for (auto &t : workers) t.join();
     (void)hipSetDevice(c.device);
     for (size_t w = 0; w < n_workers; w++) if (rcs[w] != RSN_OK) return undo(rcs[w], msgs[w].c_str());
+    return RSN_OK;
+}
+
+// ---- one Huffman stream from G slices of ONE input ("intra-file sharding"): the slices' symbol counts are summed on the
+// host, ONE tree and ONE header are built (so the result is byte for byte what rsn_huffman_compress returns), every slice's bit total
+// is its counts times the code lengths, and slice w writes its code bits at bit offset base + sum of the totals before it: the single
+// front pad of the format (huffman.go:245-255) makes the slices meet at BIT positions, so each worker encodes into a buffer of its own
+// at the right bit phase and the bytes two neighbours share are ORed together on the way down.  Worker w runs on device
+// (caller's + w mod D) mod visible, D from RSN_BATCH_DEVICES (default 1: the workers share the caller's device, which is how the
+// split is exercised on a one-GPU box); on a node with several GPUs each slice has its own PCIe link, histogram and emit.
+// Cuts fall on rune starts (a UTF-8 sequence is never split: huffman.go:309 decodes the whole string).
+namespace {
+bool is_rune_start(const uint8_t *in, size_t n, size_t q) {
+    if ((in[q] & 0xC0) != 0x80) return true;                              // not a continuation byte: always begins a rune (valid or U+FFFD)
+    for (size_t k = 1; k <= 3 && k <= q; k++) {
+        if ((in[q - k] & 0xC0) == 0x80) continue;
+        int sz = 1;
+        (void)go_decode_rune(in + (q - k), n - (q - k), &sz);             // the nearest byte before q that can begin a sequence: does it reach q?
+        return (size_t)sz <= k;
+    }
+    return true;                                                          // three continuation bytes before it: no sequence is that long
+}
+struct ShardSync {
+    std::mutex mu; std::condition_variable cv;
+    size_t arrived = 0, generation = 0, parties;
+    int rc = RSN_OK; std::string msg;
+    explicit ShardSync(size_t p) : parties(p) {}
+    void fail(int code, const char *m) { std::lock_guard<std::mutex> lk(mu); if (rc == RSN_OK) { rc = code; msg = m; } cv.notify_all(); }
+    // all parties meet; `last` runs on the last one to arrive, before the others go on.  false: somebody failed
+    bool meet(const std::function<void()> &last) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (rc != RSN_OK) return false;
+        const size_t gen = generation;
+        if (++arrived == parties) { lk.unlock(); last(); lk.lock(); arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen || rc != RSN_OK; });
+        return rc == RSN_OK;
+    }
+};
+}  // namespace
+
+int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_t **out, size_t *out_n) {
+    Ctx &c = ctx();
+    if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
+    *out = nullptr; *out_n = 0;
+    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    int rc0 = ctx_init(c); if (rc0) return rc0;
+    int G = shards > 0 ? shards : env_int("RSN_HUFF_SHARDS", 0);
+    int visible = 1;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) visible = 1;
+    const char *bd = getenv("RSN_BATCH_DEVICES");
+    const int n_dev = std::max(1, std::min(visible, !bd || !*bd ? 1 : (!strcmp(bd, "all") ? visible : atoi(bd))));
+    if (G <= 0) G = n_dev;
+    G = (int)std::min<size_t>((size_t)std::min(G, 256), std::max<size_t>(1, n / 64));   // (a slice of a few bytes is all overhead)
+    std::vector<size_t> cut{0};
+    for (int w = 1; w < G; w++) {
+        size_t p = (size_t)((unsigned __int128)n * (unsigned)w / (unsigned)G);
+        while (p > cut.back() && !is_rune_start(in, n, p)) p--;
+        if (p > cut.back()) cut.push_back(p);
+    }
+    cut.push_back(n);
+    const size_t S = cut.size() - 1;                                      // slices
+    if (S == 1) return huffman_compress_single(in, n, out, out_n);
+
+    struct Slice { HuffSlice hs; unsigned long long bits = 0, start = 0; uint8_t edge[2] = {0, 0}; size_t first = 0, last = 0; bool has = false; };
+    std::vector<Slice> sl(S);
+    HuffTree tree; HuffCodes codes; std::string hdr;
+    bool flat = false;
+    uint8_t *res = nullptr; size_t total = 0;
+    ShardSync sync(S);
+    const int base_dev = c.device;
+
+    auto plan = [&] {                                                     // runs once, on the last worker to finish its histogram
+        std::vector<HuffSym> all;
+        bool ascii = true;
+        for (auto &x : sl) { all.insert(all.end(), x.hs.syms.begin(), x.hs.syms.end()); ascii = ascii && x.hs.ascii; }
+        std::sort(all.begin(), all.end(), [](const HuffSym &a, const HuffSym &b) { return a.rune < b.rune; });
+        std::vector<HuffSym> syms;
+        for (const HuffSym &y : all) { if (!syms.empty() && syms.back().rune == y.rune) syms.back().freq += y.freq; else syms.push_back(y); }
+        emit_header(syms, hdr);
+        std::vector<HuffSym> by_rune = syms;
+        std::string msg;
+        if (!build_tree(syms, tree, msg)) { sync.fail(RSN_ERR_EMPTY, msg.c_str()); return; }
+        if (!assign_codes(tree, codes, msg)) { sync.fail(RSN_ERR_LIMIT, msg.c_str()); return; }
+        std::vector<std::pair<uint32_t, uint8_t>> len_of(tree.n_leaves);  // rune -> code length, ascending rune
+        for (uint32_t i = 0; i < tree.n_leaves; i++) len_of[i] = {tree.rune[i], codes.len[i]};
+        std::sort(len_of.begin(), len_of.end());
+        unsigned long long sum = 0;
+        for (auto &x : sl) {
+            x.bits = 0;
+            for (const HuffSym &y : x.hs.syms) {
+                const auto it = std::lower_bound(len_of.begin(), len_of.end(), std::make_pair(y.rune, (uint8_t)0));
+                x.bits += y.freq * it->second;
+            }
+            sum += x.bits;
+        }
+        if (sum != codes.total_bits) { sync.fail(RSN_ERR_DEVICE, "huffman: the slices' bit totals do not add up (internal error)"); return; }
+        const unsigned pad = (unsigned)((8 - codes.total_bits % 8) % 8);      // huffman.go:245-249
+        hdr.append("\\\n");
+        hdr.push_back((char)pad);
+        unsigned long long at = 8ull * hdr.size() + pad;
+        for (auto &x : sl) { x.start = at; at += x.bits; }
+        total = hdr.size() + (size_t)((codes.total_bits + pad) / 8);
+        flat = ascii && huff_flat_code(tree, codes);
+        res = (uint8_t *)result_alloc(total);
+        if (!res) sync.fail(RSN_ERR_NOMEM, "allocating the result block failed");
+    };
+
+    auto worker = [&](size_t w) {
+        const int dev = (base_dev + (int)(w % (size_t)n_dev)) % visible;
+        if (rsn_device_set(dev) != RSN_OK) { sync.fail(RSN_ERR_DEVICE, rsn_last_error()); return; }
+        Ctx &cw = ctx(); hipStream_t s = cw.own_stream;
+        auto bail = [&](int rc) { sync.fail(rc, cw.err.c_str()); };
+        const size_t n_w = cut[w + 1] - cut[w];
+        void *d_in = nullptr, *d_out = nullptr;
+        int rc = dev_buf(cw, 20, round_up(n_w, 16) + 64, &d_in); if (rc) return bail(rc);
+        hipError_t e = hipMemsetAsync((uint8_t *)d_in + (n_w & ~(size_t)15), 0, 64, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_in, in + cut[w], n_w, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { sync.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); return; }
+        rc = huff_slice_hist(cw, s, (const uint8_t *)d_in, n_w, sl[w].hs); if (rc) return bail(rc);
+        if (!sync.meet(plan)) return;
+        Slice &x = sl[w];
+        // the slice's buffer begins at a 16-byte boundary of the stream at or before its first bit (the kernels want that alignment)
+        const size_t origin = w == 0 ? 0 : (size_t)(x.start / 8) & ~(size_t)15;
+        const unsigned long long base = x.start - 8ull * origin;
+        const size_t local = (size_t)((base + x.bits + 7) / 8);
+        rc = dev_buf(cw, 21, round_up(local, 16) + 64, &d_out); if (rc) return bail(rc);
+        rc = huff_slice_emit(cw, s, (const uint8_t *)d_in, n_w, x.hs, tree, codes, flat, w == 0 ? hdr : std::string(), base, x.bits, (uint8_t *)d_out);
+        if (rc) return bail(rc);
+        // down: the bytes that are this slice's alone straight into the result, its first and last payload byte (which a neighbour
+        // may share) into `edge`, to be ORed in when everybody is done
+        size_t lo = w == 0 ? 0 : (size_t)(x.start / 8), hi = x.bits ? (size_t)((x.start + x.bits - 1) / 8) : (w == 0 ? hdr.size() - 1 : lo);   // inclusive
+        if (x.bits == 0 && w != 0) return;                                  // (writes nothing)
+        x.has = x.bits != 0;
+        x.first = (size_t)(x.start / 8); x.last = hi;
+        const uint8_t *dl = (const uint8_t *)d_out - origin;                // dl[k] = byte k of the stream
+        e = hipSuccess;
+        if (x.has) {
+            e = hipMemcpyAsync(&x.edge[0], dl + x.first, 1, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&x.edge[1], dl + x.last, 1, hipMemcpyDeviceToHost, s);
+            if (w == 0 && x.first > 0 && e == hipSuccess) e = hipMemcpyAsync(res, dl, x.first, hipMemcpyDeviceToHost, s);   // the header
+            if (x.last > x.first + 1 && e == hipSuccess) e = hipMemcpyAsync(res + x.first + 1, dl + x.first + 1, x.last - x.first - 1, hipMemcpyDeviceToHost, s);
+        } else e = hipMemcpyAsync(res, dl, hi + 1 - lo, hipMemcpyDeviceToHost, s);   // one distinct symbol: the header is the stream
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) sync.fail(RSN_ERR_DEVICE, hipGetErrorString(e));
+    };
+
+    std::vector<std::thread> threads;
+    for (size_t w = 1; w < S; w++) threads.emplace_back(worker, w);
+    worker(0);                                                            // the caller is worker 0, on its own context
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(c.device);
+    if (sync.rc != RSN_OK) { if (res) result_free(res); return c.fail(sync.rc, "%s", sync.msg.c_str()); }
+    for (auto &x : sl) if (x.has) { res[x.first] = 0; res[x.last] = 0; }
+    for (auto &x : sl) if (x.has) { res[x.first] |= x.edge[0]; if (x.last != x.first) res[x.last] |= x.edge[1]; }
+    *out = res; *out_n = total;
     return RSN_OK;
 }
 

@@ -14,6 +14,12 @@ def Decompress(fileContents):
     return _lib.call_host(_lib.lib().rsn_huffman_decompress, fileContents)
 
 
+def CompressSharded(fileContents, shards=0):
+    """ONE stream from `shards` slices of one input (rsn_huffman_compress_sharded): per-slice histograms summed, one tree, every slice
+    encoded at its bit offset by a worker of its own (a device of its own with RSN_BATCH_DEVICES).  Equals Compress(fileContents)."""
+    return _lib.call_host(_lib.lib().rsn_huffman_compress_sharded, fileContents, int(shards))
+
+
 def CompressBatch(chunks):
     """One complete .rsn segment per chunk, as engine.CompressFiles writes one file per input (engine.go:150-154):
     rsn_huffman_compress_batch deals the chunks out over the visible GPUs (chunk k -> device k mod G) and pipelines
