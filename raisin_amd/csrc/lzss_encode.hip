@@ -468,6 +468,13 @@ struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; ui
 // k_match_chain's record of a claimed position: .x its key, .y = next record (14 bits) | position from t0 - CH (14 bits) << 14
 // (what the position puts into the output -- a token's text or the bytes themselves -- is worked out by the reader: here it would cost
 //  the walk's kernel what it saves the reader)
+// SECTIONS (r04).  A stream too long for one pass (positions are 32 bits) is encoded section by section.  A section's stream begins
+// HALO_TILES tiles before the position the true chain enters it -- the exit of the section before -- so that every position of the
+// section sees its whole window; those tiles are never walked (ChainArgs::redo bit 2), their records say "the chain steps from tile
+// to tile" (k_halo_init), the first tile behind them starts its chain AT its first position instead of a warm-up zone before it,
+// and the general parse starts there too (k_parse_chain).  HALO_TILES is a group of the general parse: it enters a group through
+// its first tile.
+constexpr uint32_t HALO_TILES = 64;
 constexpr uint32_t CK_EXIT = 0x3FFEu, CK_BROKEN = 0x3FFFu;           // "next record" when the chain leaves the tile / lands on a position nobody evaluated
 constexpr uint32_t NO_LIST = 0xFFFFFFFFu;                            // ccnt[tile]: the tile has no compact key list (k_tok_emit reads its flags and keys); ckn[tile]: nor the claimed positions' keys
 __device__ __forceinline__ ChainTail chain_tail() {
@@ -848,6 +855,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     uint32_t n_evals = 0, n_rounds = 0, n_ext = 0, n_iter = 0, n_act = 0;
 #endif
+    if ((a.redo & 4u) && bx < HALO_TILES) return;                         // a section's halo: candidates for the tiles behind it, no chain of its own
     if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
     for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
         const long long P = r0 + 16ll * v;
@@ -920,6 +928,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0);
     const uint32_t kp_end = CH + npos;                                    // a chain stops when it leaves the tile
     uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));                       // the warm-up start (CH in tile 0: the true start)
+    if ((a.redo & 4u) && bx == HALO_TILES) kp_first = CH;                  // the first tile of a section: the true chain enters at its first position
     if (list_entry >> 31) kp_first = chain_tail().redo_start[blockIdx.x] - (uint32_t)(t0 - CH);   // the true entry as k_chain_verify worked it out: the tile before's exit, or a whole-distance stretch's arithmetic
     // (a tile of a whole-distance stretch walked from its predicted entry: the chain is two or three visits long, and the other 64
     //  starts would each verify a 4 KiB match for nothing -- should the prediction be wrong, the one chain walks the tile alone)
@@ -1947,6 +1956,16 @@ __global__ void k_stretch_pred(const TileChain *__restrict__ tc, const uint32_t 
 
 // Accepts the per-tile chains of k_match_chain as THE chain iff they join up: tile 0 enters at position 0 and every
 // tile's exit is the next tile's entry (the last tile's exit is at or beyond the end of the stream).
+// the records of a section's halo tiles: resolved, nothing flagged, nothing emitted, the chain handed from tile to tile
+template <class C>
+__global__ __launch_bounds__(256) void k_halo_init(TileChain *__restrict__ tchain, uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
+                                                   uint8_t *__restrict__ dump, uint32_t *__restrict__ step, uint32_t tile) {
+    const uint32_t k = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < tile / 32; i += 256) flags[(size_t)k * (tile / 32) + i] = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)C::DUMP_BYTES / 4; i += 256) reinterpret_cast<uint32_t *>(dump + (size_t)k * C::DUMP_BYTES)[i] = 0;
+    if (threadIdx.x == 0) { tchain[k] = TileChain{k * tile, (k + 1) * tile, 1u, 0u}; tile_bytes[k] = 0; step[k] = 0; }
+}
+
 __global__ void k_sample_tiles(uint32_t *__restrict__ list, uint32_t n, uint32_t n_tiles) {   // n tiles spread evenly over the stream (not tile 0: it has no window)
     if (threadIdx.x < n) list[threadIdx.x] = (uint32_t)(((unsigned long long)threadIdx.x * n_tiles + n_tiles / 2) / n);
 }
@@ -2051,6 +2070,7 @@ __global__ __launch_bounds__(LB) void k_parse_exit(const uint32_t *__restrict__ 
 //   k_parse_fill    per group, walk its SUPER tiles from the now-known entry
 constexpr int SUPER = 64;
 static_assert(MAX_WINDOW <= PT, "the chain must enter every group through its first tile");
+static_assert(HALO_TILES == SUPER, "a section's chain starts at a group's first position");
 
 __device__ __forceinline__ unsigned long long chain_step(const uint16_t *__restrict__ exit_rel, unsigned long long pos, uint32_t t) {
     // pos is a global position inside tile t (or beyond it): returns the first chain position >= end of tile t
@@ -2068,13 +2088,15 @@ __global__ __launch_bounds__(LB) void k_parse_super(const uint16_t *__restrict__
     }
 }
 
-__global__ void k_parse_chain(const uint32_t *__restrict__ super_exit, uint32_t n_groups, uint32_t n_tiles, unsigned long long *__restrict__ group_entry) {
+__global__ void k_parse_chain(const uint32_t *__restrict__ super_exit, uint32_t n_groups, uint32_t n_tiles, unsigned long long *__restrict__ group_entry,
+                              unsigned long long start) {           // start: 0, or the first position behind a section's halo (a group's first)
     if (threadIdx.x || blockIdx.x) return;
-    unsigned long long pos = 0;
+    unsigned long long pos = start;
     for (uint32_t g = 0; g < n_groups; g++) {
         group_entry[g] = pos;                                       // global position where the chain enters (or jumps over) group g
         const unsigned long long lo = (unsigned long long)g * SUPER * PT;
         const unsigned long long hi = (unsigned long long)min((g + 1) * SUPER, n_tiles) * PT;
+        if (pos >= hi) continue;                                    // a halo group: the chain begins behind it
         // a match is at most W <= PT long, so the chain always lands inside the group's FIRST tile
         pos = hi + super_exit[(size_t)g * PT + (pos - lo)];
     }
@@ -2454,55 +2476,20 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
 // ======================================================================= host side
 size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
 
-int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n) {
-    *out_n = 0;
-    if (n == 0) return RSN_OK;                                        // CompressAsync(empty) == empty
-    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "lzss: device buffers must be 16-byte aligned");
-    if (n >= (1ull << 31)) return c.fail(RSN_ERR_LIMIT, "lzss: input of %zu bytes exceeds the 2 GiB per-call limit", n);
+// One pass over one escaped stream of E < 2^31 positions: match search, greedy chain, token emit.  halo: the stream is a SECTION of a
+// longer one -- its first HALO_TILES tiles are window only and the chain enters at the first position behind them; stop_tile (0: none):
+// the section ends in front of that tile -- *out_n is then the bytes of the items that begin before it, *exit_pos where the chain first
+// lands in or behind it (the next section's entry).  d_same / Wp: k_esc_try's periodicity flags for this very stream, or null.
+static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint32_t W, const uint8_t *d_same, uint32_t Wp, bool copied,
+                              bool halo, uint32_t stop_tile, uint8_t *d_out, size_t out_cap, size_t *out_n, uint32_t *exit_pos) {
     void *p; int rc;
-    // ---- E1
-    const uint32_t n_eb = (uint32_t)ceil_div(n, ESC_TILE);
-    rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
-    unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
-    static const bool no_try = getenv("RSN_LZSS_ESC_TWO_PASS") != nullptr;   // A/B switch: always count, scan, write
-    bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
-    // (the window, should nothing need an escape -- then E = n; a multiple of 16 for k_esc_try's periodicity flags, see there)
-    const uint32_t Wp = window > 0 && (uint64_t)window <= HWMAX && (uint64_t)window < n && window % 16 == 0 ? (uint32_t)window : 0u;
-    static const bool no_fused_periodic = getenv("RSN_LZSS_NO_FUSED_PERIODIC") != nullptr;   // A/B switch: k_tile_periodic reads the stream itself
-    uint8_t *d_same = nullptr;
-    if (!no_try) {
-        rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
-        if (Wp && !no_fused_periodic) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
-        RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
-        RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same);
-        RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
-        RSN_HIP(hipStreamSynchronize(s));
-        copied = h64[0] == 0;
-        h64[0] = 0;
+    const uint32_t halo_bit = halo ? 4u : 0u;
+    if (W > MAX_WINDOW) {
+        if (halo || stop_tile) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %u", MAX_WINDOW);
+        return lzss_encode_big(c, s, d_fc, E, W, d_out, out_cap, out_n);   // lzss_big.hip: exact at any window, not fast
     }
-    if (!copied) {
-        RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
-        rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
-        RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
-        RSN_HIP(hipStreamSynchronize(s));
-    }
-    const size_t E64 = n + (size_t)h64[0];
-    if (E64 >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: escaped stream too large for one call");
-    const uint32_t E = (uint32_t)E64;
-    uint32_t W;
-    if (window <= 0) W = E;                                           // unbounded search buffer (lzss.go:125)
-    else W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);       // a window longer than the stream never binds
-    if (W == 0) W = 1;
-    rc = dev_buf(c, 9, (size_t)E + 64, &p); if (rc) return rc;
-    uint8_t *d_fc = (uint8_t *)p;
-    if (!copied) {
-        RSN_HIP(hipMemsetAsync(d_fc + E, 0, 64, s));                  // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
-    }
-    if (W > MAX_WINDOW) return lzss_encode_big(c, s, d_fc, E, W, d_out, out_cap, out_n);   // lzss_big.hip: exact at any window, not fast
     // ---- E2 + E3.  Chain mode (default, W <= 4096): keys only where greedy chains land, everything else
     //      KEY_UNKNOWN; if the parse finds the true chain on an unknown position, those strips are
     //      searched at every position and the parse runs again (never more rounds than strips).
@@ -2514,6 +2501,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     static const bool brute = getenv("RSN_LZSS_BRUTE") != nullptr || getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: sweep every strip
     static const bool allpos = getenv("RSN_LZSS_ALLPOS") != nullptr;                                            // A/B switch: bucket search at every position
     const bool hashed = W <= HWMAX && !brute;
+    if ((halo || stop_tile) && !hashed) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %d", HWMAX);
     bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
     auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 (or k_match) on every strip, or on the flagged ones
         MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, only};
@@ -2578,9 +2566,10 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // sample of 64 tiles first; if three quarters of them give up, the whole stream goes to the bucket search at every position.
     // (From 8192 tiles = 64 MiB: the sample is a launch that waits for one tile plus a host sync, 0.12 ms -- 15 % of an 8 MiB call,
     //  to save a stream of noise that size 0.13 ms.  RSN_LZSS_SAMPLE_MIN_TILES moves the threshold: the tests use it.)
-    if (chain_mode && copied && d_same && W == Wp)
+    if (chain_mode && copied && d_same && W == Wp && !halo)
         RSN_LAUNCH("lzss_tile_periodic", k_tiles_from_blocks, dim3((uint32_t)ceil_div(n_pt, 256)), dim3(256), 0, s, (const uint8_t *)d_same, E, W, (uint32_t)PT, n_pt, d_tchain, d_step);
     else if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain, d_step);
+    if (chain_mode && halo) RSN_LAUNCH("lzss_tile_periodic", k_halo_init<CC>, dim3(std::min(HALO_TILES, n_pt)), dim3(256), 0, s, d_tchain, d_flags, d_tbytes, d_dump, d_step, (uint32_t)PT);
     constexpr uint32_t SAMPLE_TILES = 64;
     static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
     const char *smin_env = getenv("RSN_LZSS_SAMPLE_MIN_TILES");
@@ -2589,7 +2578,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
-        ChainArgs hs{d_fc, E, W, d_keys, 2, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
+        ChainArgs hs{d_fc, E, W, d_keys, 2u | halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
         rc = launch_chain("lzss_sample", SAMPLE_TILES, hs); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -2611,7 +2600,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
             if (!no_ckeys && !tail_doubling && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
         }
-        ChainArgs ha{d_fc, E, W, d_keys, 0, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
+        ChainArgs ha{d_fc, E, W, d_keys, halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
@@ -2702,7 +2691,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
             const uint32_t n_plain = n_list - std::min(n_list, n_arith);         // entries that are not placed by arithmetic: tiles that gave up, joints to mend
             if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
             prev_plain = n_plain;
-            ha.redo = 3; ha.tail.redo_list = d_redo_list;
+            ha.redo = 3u | halo_bit; ha.tail.redo_list = d_redo_list;
             ha.tail.ckeys = nullptr; ha.tail.ckn = nullptr;                   // (a look's tiles are resolved by k_chain_tail, from the key array)
             rc = launch_chain("lzss_match_chain", n_list, ha); if (rc) return rc;
             rc = resolve(true, use_pred); if (rc) return rc;
@@ -2754,7 +2743,7 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         RSN_HIP(hipMemsetAsync(d_ttot + 1, 0, 8, s));
         RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);
         RSN_LAUNCH("lzss_parse_super", k_parse_super, dim3(n_groups), dim3(LB), 0, s, d_exit, n_pt, E, d_super);
-        RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry);
+        RSN_LAUNCH("lzss_parse_chain", k_parse_chain, dim3(1), dim3(64), 0, s, d_super, n_groups, n_pt, d_gentry, (unsigned long long)(halo ? (unsigned long long)HALO_TILES * PT : 0ull));
         RSN_LAUNCH("lzss_parse_fill", k_parse_fill, dim3((uint32_t)ceil_div(n_groups, 64)), dim3(64), 0, s, d_exit, d_gentry, n_groups, n_pt, d_entry);
         RSN_LAUNCH("lzss_parse_mark", k_parse_mark, dim3(n_pt), dim3(LB), mark_sh, s, d_fc, d_keys, E, W, d_entry, d_flags, d_tbytes, d_redo, d_ttot + 1);
         rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
@@ -2769,13 +2758,124 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
         rc = sweep(d_heavy); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(d_redo, 0, (size_t)n_strips * 4, s));
     }
-    const size_t total = (size_t)h64[0];
+    size_t total = (size_t)h64[0];
+    if (stop_tile && stop_tile < n_pt) {
+        // the section ends in front of stop_tile: what the items before it emit, and where the chain goes on
+        RSN_HIP(hipMemcpyAsync(h64, d_toff + stop_tile, 8, hipMemcpyDeviceToHost, s));
+        if (parsed_by_walk) RSN_HIP(hipMemcpyAsync(h64 + 1, &d_tchain[stop_tile].entry, 4, hipMemcpyDeviceToHost, s));
+        else RSN_HIP(hipMemcpyAsync(h64 + 1, d_entry + stop_tile, 4, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        total = (size_t)h64[0];
+        const uint32_t ent = (uint32_t)h64[1];
+        if (ent == NO_ENTRY) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: the chain jumped over a section's last tile");
+        *exit_pos = parsed_by_walk ? ent : stop_tile * (uint32_t)PT + ent;
+    } else if (exit_pos) *exit_pos = E;
     *out_n = total;
     if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- E4
-    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W,
+    RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(stop_tile && stop_tile < n_pt ? stop_tile : n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W,
                (const uint32_t *)(parsed_by_walk ? d_clist : nullptr), (const uint32_t *)(parsed_by_walk ? d_ccnt : nullptr));
     RSN_HIP(hipStreamSynchronize(s));
+    return RSN_OK;
+}
+
+static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
+
+int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    *out_n = 0;
+    if (n == 0) return RSN_OK;                                        // CompressAsync(empty) == empty
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "lzss: device buffers must be 16-byte aligned");
+    // ~12 bytes of scratch per position of a pass (keys 4, compact lists 4, chain records, the escaped stream, a section's copy) + the
+    // escaped stream itself: small calls pass straight through, large ones are admitted one device-full at a time (rsn_api.hip)
+    const size_t need = n < ((size_t)32 << 20) ? 0 : 13 * std::min(n, (size_t)3 << 29) + 2 * n;
+    if (need) (void)scratch_admit(c, need);
+    const int rc = lzss_encode_admitted(c, s, d_in, n, window, d_out, out_cap, out_n);
+    // (the encoder's scratch: slots 8..19, 22..27, 35, 36 -- not 20 / 21, the host-buffer entry points' staging, still in use by the caller)
+    if (need) scratch_release(c, need, (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35));
+    return rc;
+}
+
+static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    void *p; int rc;
+    // ---- E1
+    const uint32_t n_eb = (uint32_t)ceil_div(n, ESC_TILE);
+    rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
+    unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
+    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    unsigned long long *h64 = (unsigned long long *)hp;
+    static const bool no_try = getenv("RSN_LZSS_ESC_TWO_PASS") != nullptr;   // A/B switch: always count, scan, write
+    bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
+    // (the window, should nothing need an escape -- then E = n; a multiple of 16 for k_esc_try's periodicity flags, see there)
+    const uint32_t Wp = window > 0 && (uint64_t)window <= HWMAX && (uint64_t)window < n && window % 16 == 0 ? (uint32_t)window : 0u;
+    static const bool no_fused_periodic = getenv("RSN_LZSS_NO_FUSED_PERIODIC") != nullptr;   // A/B switch: k_tile_periodic reads the stream itself
+    uint8_t *d_same = nullptr;
+    if (!no_try) {
+        rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
+        if (Wp && !no_fused_periodic) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
+        RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
+        RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
+        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same);
+        RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        copied = h64[0] == 0;
+        h64[0] = 0;
+    }
+    if (!copied) {
+        RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
+        rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(h64, d_etot, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+    }
+    const size_t E64 = n + (size_t)h64[0];
+    rc = dev_buf(c, 9, E64 + 64, &p); if (rc) return rc;
+    uint8_t *d_fc = (uint8_t *)p;
+    if (!copied) {
+        RSN_HIP(hipMemsetAsync(d_fc + E64, 0, 64, s));                // readable padding behind the stream
+        RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+    }
+    // One pass takes a stream of up to SEC_MAX positions (32-bit positions, and ~10 bytes of scratch per position); a longer one goes
+    // section by section (RSN_LZSS_SECTION_MIB: a smaller section, for the tests).
+    static const size_t sec_env = [] { const char *e = getenv("RSN_LZSS_SECTION_MIB"); return e && atoi(e) > 0 ? (size_t)atoi(e) << 20 : (size_t)0; }();
+    constexpr size_t SEC_MAX = ((size_t)1 << 31) - ((size_t)1 << 24);
+    const size_t halo_len = (size_t)HALO_TILES * PT;
+    if (E64 <= SEC_MAX && (sec_env == 0 || E64 <= sec_env + halo_len)) {
+        const uint32_t E = (uint32_t)E64;
+        uint32_t W;
+        if (window <= 0) W = E;                                       // unbounded search buffer (lzss.go:125)
+        else W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);   // a window longer than the stream never binds
+        if (W == 0) W = 1;
+        return lzss_encode_stream(c, s, d_fc, E, W, d_same, Wp, copied, false, 0, d_out, out_cap, out_n, nullptr);
+    }
+    // ---- sections: [entry, entry + sec) each, entry = where the chain left the section before (lzss.go:134-151 is one serial walk: the
+    //      only thing a section needs from its predecessors is that position and the W bytes in front of it)
+    if (window <= 0 || (uint64_t)window > HWMAX) return c.fail(RSN_ERR_LIMIT, "lzss: %zu escaped bytes need sections, which take windows up to %d (asked: %lld)", E64, HWMAX, (long long)window);
+    const uint32_t W = (uint32_t)window;
+    const size_t sec = (sec_env ? std::min(sec_env, (size_t)1 << 30) : (size_t)1 << 30) / PT * PT;   // positions per section: whole tiles
+    size_t entry = 0, written = 0;
+    void *sp = nullptr;
+    while (entry < E64) {
+        const bool halo = entry >= halo_len;                          // (the first section begins at the stream's beginning: no halo)
+        const size_t a0 = halo ? entry - halo_len : 0;
+        const bool last = E64 - entry <= sec + sec / 4;               // (a short remainder rides with the section before it)
+        const size_t b0 = last ? E64 : entry + sec + W;               // W bytes of look-ahead: a match that begins in the section may end there
+        const uint32_t Es = (uint32_t)(b0 - a0);
+        const uint32_t stop_tile = last ? 0u : (uint32_t)((entry - a0 + sec) / PT);
+        // an aligned copy of its own with zeroed padding behind it, like a whole stream's (the kernels load 16 bytes at a time from the
+        // base, and what lies behind the last position must not look like data): 1 GiB device to device, 0.4 ms of a 30 ms section
+        rc = dev_buf(c, 36, (size_t)Es + 64, &sp); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(sp, d_fc + a0, Es, hipMemcpyDeviceToDevice, s));
+        RSN_HIP(hipMemsetAsync((uint8_t *)sp + Es, 0, 64, s));
+        const uint8_t *fc_s = (const uint8_t *)sp;
+        size_t got = 0; uint32_t exit_local = 0;
+        rc = lzss_encode_stream(c, s, fc_s, Es, std::min(W, Es), nullptr, 0, copied, halo, stop_tile, d_out + written, out_cap > written ? out_cap - written : 0, &got, &exit_local);
+        if (rc == RSN_ERR_CAPACITY) { *out_n = lzss_compress_bound(n); return rc; }
+        if (rc) return rc;
+        written += got;
+        if (last) break;
+        if ((size_t)exit_local < entry - a0 + sec || exit_local > Es) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: a section's chain left it at %u", exit_local);
+        entry = a0 + exit_local;
+    }
+    *out_n = written;
     return RSN_OK;
 }
 

@@ -19,6 +19,7 @@ namespace rsn {
 
 namespace {
 int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+std::atomic<size_t> g_arena_bytes[64];                                   // device scratch held by all contexts of the process, per device
 }  // namespace
 
 Ctx &ctx() {
@@ -38,7 +39,7 @@ std::vector<Parked> *g_parked = nullptr;      // heap-allocated and never destro
 
 void release_parked(Parked &pk) {              // (HIP calls: only from a live thread, never from a thread-exit destructor)
     if (hipSetDevice(pk.device) != hipSuccess) return;
-    for (auto &b : pk.bufs) if (b.p) (void)hipFree(b.p);
+    for (auto &b : pk.bufs) if (b.p) { (void)hipFree(b.p); g_arena_bytes[pk.device & 63] -= b.cap; }
     if (pk.pinned) (void)hipHostFree(pk.pinned);
     for (auto e : pk.events) (void)hipEventDestroy(e);
     if (pk.stream) (void)hipStreamDestroy(pk.stream);
@@ -129,14 +130,75 @@ int ctx_init(Ctx &c) {
     return RSN_OK;
 }
 
+// ---- admission of calls that need gigabytes of scratch (LZSS encode: ~12 bytes per position).  Every calling thread has an arena of
+// its own, so 64 goroutines compressing 1 GiB files at once would ask for 64 x 12 GiB: instead of hipErrorOutOfMemory for most of
+// them, a call states its need up front and WAITS while the needs of the calls in flight on its device add up to more than the
+// device holds (RSN_SCRATCH_GIB, default 85 % of the device's memory); a call that finishes while others wait, or while the arenas
+// on the device have grown past half of that, gives its large buffers back instead of keeping them for its thread's next call.
+namespace {
+struct ScratchGate { std::mutex mu; std::condition_variable cv; size_t cap = 0, in_flight = 0; int calls = 0, waiting = 0; unsigned long long queued = 0; };
+ScratchGate g_gate[64];
+}  // namespace
+
+size_t scratch_admit(Ctx &c, size_t need) {
+    ScratchGate &g = g_gate[c.device & 63];
+    std::unique_lock<std::mutex> lk(g.mu);
+    if (g.cap == 0) {
+        const char *e = getenv("RSN_SCRATCH_GIB");
+        size_t fr = 0, tot = 0;
+        if (e && atof(e) > 0) g.cap = (size_t)(atof(e) * (double)((size_t)1 << 30));
+        else if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) g.cap = tot / 100 * 85;
+        else g.cap = (size_t)64 << 30;
+    }
+    if (g.calls > 0 && g.in_flight + need > g.cap) {                     // (a lone call always runs: its own allocation failing is the answer then)
+        static const bool dbg = getenv("RSN_SCRATCH_DEBUG") != nullptr;
+        g.waiting++; g.queued++;
+        if (dbg) fprintf(stderr, "librsn: a call that needs %.2f GiB of scratch waits: %d in flight need %.2f of %.2f GiB\n", need / 1073741824.0, g.calls, g.in_flight / 1073741824.0, g.cap / 1073741824.0);
+        g.cv.wait(lk, [&] { return g.calls == 0 || g.in_flight + need <= g.cap; });
+        g.waiting--;
+    }
+    g.calls++; g.in_flight += need;
+    return need;
+}
+
+void scratch_release(Ctx &c, size_t need, unsigned long long slots) {
+    ScratchGate &g = g_gate[c.device & 63];
+    bool give_back;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.calls--; g.in_flight -= need;
+        give_back = g.waiting > 0 || g_arena_bytes[c.device & 63].load() > g.cap / 2;
+    }
+    if (give_back && hipSetDevice(c.device) == hipSuccess) {
+        for (int k = 0; k < Ctx::N_BUFS; k++) {
+            if (!((slots >> k) & 1ull)) continue;
+            Ctx::Buf &b = c.bufs[k];
+            if (b.p && b.cap >= ((size_t)64 << 20)) { (void)hipFree(b.p); g_arena_bytes[c.device & 63] -= b.cap; b.p = nullptr; b.cap = 0; }
+        }
+    }
+    g.cv.notify_all();
+}
+
+void scratch_forget(Ctx &c, size_t bytes) { g_arena_bytes[c.device & 63] -= bytes; }
+unsigned long long scratch_queued(int device) { ScratchGate &g = g_gate[device & 63]; std::lock_guard<std::mutex> lk(g.mu); return g.queued; }
+
 int dev_buf(Ctx &c, int slot, size_t bytes, void **out) {
     Ctx::Buf &b = c.bufs[slot];
     if (bytes > b.cap) {
-        if (b.p) { RSN_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        if (b.p) { RSN_HIP(hipFree(b.p)); g_arena_bytes[c.device & 63] -= b.cap; b.p = nullptr; b.cap = 0; }
         const size_t want = round_up(bytes + bytes / 8, 4096);
         hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {                                            // what exited threads left parked on the device goes first, then once more
+            (void)hipGetLastError();
+            std::vector<Parked> victims;
+            { std::lock_guard<std::mutex> lk(g_park_mu); if (g_parked) victims.swap(*g_parked); }
+            for (auto &pk : victims) release_parked(pk);
+            (void)hipSetDevice(c.device);
+            e = hipMalloc(&b.p, want);
+        }
         if (e != hipSuccess) { b.p = nullptr; return c.fail(RSN_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
         b.cap = want;
+        g_arena_bytes[c.device & 63] += want;
     }
     *out = b.p;
     return RSN_OK;
@@ -290,7 +352,7 @@ int rsn_device_set(int device) {
     if (c.inited && c.device != device) {
         // drop per-device resources; they are re-created lazily on the new device
         (void)hipSetDevice(c.device);
-        for (auto &b : c.bufs) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        for (auto &b : c.bufs) { if (b.p) { (void)hipFree(b.p); g_arena_bytes[c.device & 63] -= b.cap; } b.p = nullptr; b.cap = 0; }
         if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
         c.own_stream = nullptr;
         prof_collect(c);
@@ -317,7 +379,7 @@ void rsn_trim(void) {
     Ctx &c = ctx();
     if (c.inited && hipSetDevice(c.device) == hipSuccess) {
         (void)hipStreamSynchronize(c.own_stream);
-        for (auto &b : c.bufs) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        for (auto &b : c.bufs) { if (b.p) { (void)hipFree(b.p); g_arena_bytes[c.device & 63] -= b.cap; } b.p = nullptr; b.cap = 0; }
         if (c.pinned) (void)hipHostFree(c.pinned);
         c.pinned = nullptr; c.pinned_cap = 0;
     }
@@ -539,7 +601,7 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
     downloader.join();
     for (int r = 0; r < BatchPipe::RING; r++) if (P.d_tmp[r]) (void)hipFree(P.d_tmp[r]);
     if ((in_cap + out_cap) * BatchPipe::RING > ((size_t)std::max(0, env_int("RSN_BATCH_KEEP_MIB", 1024)) << 20))
-        for (int k = 28; k < 28 + 2 * BatchPipe::RING; k++) { if (c.bufs[k].p) (void)hipFree(c.bufs[k].p); c.bufs[k].p = nullptr; c.bufs[k].cap = 0; }
+        for (int k = 28; k < 28 + 2 * BatchPipe::RING; k++) { if (c.bufs[k].p) { (void)hipFree(c.bufs[k].p); scratch_forget(c, c.bufs[k].cap); } c.bufs[k].p = nullptr; c.bufs[k].cap = 0; }
     if (P.rc != RSN_OK) return c.fail(P.rc, "%s", P.msg.c_str());
     return RSN_OK;
 }

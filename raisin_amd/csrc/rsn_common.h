@@ -36,7 +36,7 @@ struct Ctx {
     std::vector<hipEvent_t> free_events;
 
     struct Buf { void *p = nullptr; size_t cap = 0; };
-    enum { N_BUFS = 36 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words
+    enum { N_BUFS = 38 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words; 35: k_esc_try's block flags; 36: an LZSS section's stream
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
 
@@ -54,6 +54,11 @@ Ctx &ctx();
 int ctx_init(Ctx &c);                       // lazy: picks device, creates stream
 int dev_buf(Ctx &c, int slot, size_t bytes, void **out);   // grow-only scratch
 int pinned_buf(Ctx &c, size_t bytes, void **out);
+// admission of calls with gigabytes of scratch (rsn_api.hip): waits while the device's calls in flight need more than it holds
+size_t scratch_admit(Ctx &c, size_t need);
+void scratch_release(Ctx &c, size_t need, unsigned long long slots);         // ... and gives those slots' large buffers back when others wait (bit k = slot k)
+void scratch_forget(Ctx &c, size_t bytes);
+unsigned long long scratch_queued(int device);                               // calls that have had to wait so far (tests)
 void prof_collect(Ctx &c);
 
 #define RSN_HIP(call)                                                                              \

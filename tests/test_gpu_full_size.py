@@ -313,3 +313,23 @@ def test_beyond_4GiB_offsets():
     c = huffman.compress_tensor(src)
     d = huffman.decompress_tensor(c)
     assert d.numel() == n and torch.equal(d, src)
+
+
+def test_lzss_beyond_2GiB_in_sections(oracle):
+    """the reference has no bound on its input (lzss.go:109); one pass here has 32-bit positions, so 2.5 GiB of config
+    4's text goes through three sections (1 GiB each, 512 KiB of halo, the chain's exit handed from one to the next) -- and the bytes
+    are the oracle's CompressAsync output (segment induction, oracle.lzss_check).  The decoder's own limit (a 4 GiB escaped stream)
+    is not touched: the stream decodes back to the input."""
+    import torch
+    import workloads as W
+    from raisin_amd import lz
+    n = 5 * GIB // 2
+    src = W.config_input("4", n, "cuda")
+    got = lz.compress_tensor(src)
+    assert got.numel() < n
+    host = bytes(src.cpu().numpy())
+    gb = bytes(got.cpu().numpy())
+    _oracle_says_identical(oracle, host, gb, "config 4 text, 2.5 GiB in sections")
+    del host, gb
+    back = lz.decompress_tensor(got)
+    assert back.numel() == n and torch.equal(back, src)

@@ -634,3 +634,70 @@ def test_decode_without_unescape_pass_and_its_capacity_contract(lz, oracle):
         exact = torch.empty(len(data) + 16 - len(data) % 16, dtype=torch.uint8, device="cuda")[: len(data)]
         got = _lib.call_dev(_lib.lib().rsn_lzss_decompress_dev, src.data_ptr(), src.numel(), exact.data_ptr(), len(data), None)
         assert got == len(data) and bytes(exact.cpu().numpy()) == data
+
+
+def test_sections_give_the_same_stream(oracle):
+    """A stream of 2 GiB and more is encoded section by section (lzss_encode_dev: 32-bit positions): each section's stream begins 64
+    tiles before the position the chain enters it -- the exit of the section before -- and ends a window behind its last tile.
+    RSN_LZSS_SECTION_MIB=4 forces 4 MiB sections on inputs of 20-30 MiB (in a process of its own: the switch is read once): the bytes
+    are those of the single pass and the oracle's (text; sections of noise with escapes, periodic data and runs; a 37-byte period)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "import workloads as W\nfrom raisin_amd import lz\n"
+            "from oracle import oracle as O\n"
+            "g = torch.Generator().manual_seed(3)\n"
+            "text = W.config_input('4', 30 << 20)\n"
+            "parts = []\n"
+            "for k in range(24):\n"
+            "    kind = k %% 4\n"
+            "    if kind == 0: parts.append(W.config_input('4', 40 << 20)[(k + 3) << 20:(k + 4) << 20])\n"
+            "    elif kind == 1: parts.append(torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, generator=g))\n"
+            "    elif kind == 2: parts.append(W.config_input('3', 1 << 20))\n"
+            "    else: parts.append(torch.randint(97, 101, ((1 << 20) // 37 + 1,), dtype=torch.uint8, generator=g).repeat_interleave(37)[:1 << 20])\n"
+            "mixed = torch.cat(parts)\n"
+            "per = torch.randint(32, 127, (37,), dtype=torch.uint8, generator=g).repeat((20 << 20) // 37)\n"
+            "for name, t in (('text', text), ('mixed', mixed), ('period37', per)):\n"
+            "    host = bytes(t.numpy())\n"
+            "    out = bytes(lz.compress_tensor(t.cuda()).cpu().numpy())\n"
+            "    ok, bad = O.lzss_check(host, out)\n"
+            "    print(name, hashlib.sha256(out).hexdigest(), len(out), ok, bad)\n" % root)
+    res = []
+    for env in ({}, {"RSN_LZSS_SECTION_MIB": "4"}, {"RSN_LZSS_SECTION_MIB": "7", "RSN_LZSS_NO_FUSED_PARSE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l.split() for l in r.stdout.strip().splitlines()]
+        assert len(lines) == 3 and all(l[3] == "True" for l in lines), (env, lines)
+        res.append([l[:3] for l in lines])
+    assert res[0] == res[1] == res[2]
+
+
+def test_a_storm_of_large_calls_queues_instead_of_failing(oracle):
+    """every calling thread has a scratch arena of its own and a 1 GiB LZSS encode wants ~12 GiB of it; concurrent large
+    calls are admitted while their needs fit the device (RSN_SCRATCH_GIB: here 1.5 GiB, so that 64 MiB calls -- ~1 GiB each -- run one
+    at a time) and the rest wait; a call that finishes while others wait hands its buffers back.  Six threads, all results the
+    single-threaded bytes; the log shows that calls did wait."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, threading; sys.path.insert(0, %r)\n"
+            "import workloads as W\nfrom raisin_amd import lz\n"
+            "datas = [bytes(W.config_input('4', (64 << 20) + k * 4099).numpy()) for k in range(3)]\n"
+            "want = [hashlib.sha256(lz.CompressAsync(d)).hexdigest() for d in datas]\n"
+            "got = [None] * 6\n"
+            "def run(i):\n"
+            "    got[i] = hashlib.sha256(lz.CompressAsync(datas[i %% 3])).hexdigest()\n"
+            "ts = [threading.Thread(target=run, args=(i,)) for i in range(6)]\n"
+            "[t.start() for t in ts]; [t.join() for t in ts]\n"
+            "print('OK' if got == want + want else 'MISMATCH', got, want)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RSN_SCRATCH_GIB="1.5", RSN_SCRATCH_DEBUG="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().startswith("OK"), r.stdout[-2000:]
+    assert "waits" in r.stderr, r.stderr[-2000:]
