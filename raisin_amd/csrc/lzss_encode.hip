@@ -854,6 +854,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
 #ifdef RSN_CHAIN_STATS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     uint32_t n_evals = 0, n_rounds = 0, n_ext = 0, n_iter = 0, n_act = 0;
+    uint32_t n_dealt = 0, n_heavy = 0, n_heavy_visits = 0, n_ok = 0, n_before = 0, n_after = 0, n_trips = 0;   // wave rounds dealt / heavy chunks / heavy visits / candidates that pass the window+tag test / bucket entries before and after trimming / narrowing trips
 #endif
     if ((a.redo & 4u) && bx < HALO_TILES) return;                         // a section's halo: candidates for the tiles behind it, no chain of its own
     if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
@@ -1203,6 +1204,15 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 lo = h ? (uint32_t)ends[h - 1] : 0u; hi = ends[h];
                 const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
                 pat0 = lds_load8(sw, irel + C::OFF0);
+#ifdef RSN_CHAIN_STATS
+                if (leader) n_before += hi - lo;
+#endif
+                // (r04, measured and dropped: the window's slice of the bucket by INTERPOLATION -- entries are ordered by block and text spreads
+                //  a bigram evenly over the stage, so four guesses at each end, checked exactly by the block of the entry in front of / at the
+                //  guess, trim any bucket of more than two rows for one LDS read.  It works -- 85.5 entries per visit become 36.0 instead of
+                //  40.2 -- and changes nothing: 28.17 against 28.16 ms.  RSN_CHAIN_STATS says why: of the 36 entries dealt per visit 27.7 ARE
+                //  candidates (in the window, same tag), the trips below already do four fifths of the trimming, and half of all candidate
+                //  rounds belong to the 12 % of visits with a bucketful -- the commonest bigrams of a Zipf text -- which no trimming shortens.)
                 // the bucket's entries are ordered by block of 2^CSH positions: LW samples per trip trim the entries before the
                 // window's first block and those after the position's own
                 // (while it pays: a trip costs the wavefront about as much as two dealt rows)
@@ -1218,8 +1228,14 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     const uint32_t nhi = after ? min(lo + __umul24((uint32_t)__builtin_ctz(after), stride), hi - 1) : hi;   // that sample and everything behind it: after i
                     narrowing = (nlo != lo || nhi != hi) && nhi - nlo > NARROW;
                     lo = nlo; hi = max(nhi, nlo);
+#ifdef RSN_CHAIN_STATS
+                    if (leader) n_trips++;
+#endif
                 }
                 nrows = (hi - lo + LW - 1) / LW;
+#ifdef RSN_CHAIN_STATS
+                if (leader) n_after += hi - lo;
+#endif
             }
             // ---- 2. the candidates
             // one candidate per lane: its key L << 16 | distance (0: none).  c_*: the visit it belongs to, `ch` its chain.  A candidate that
@@ -1229,6 +1245,9 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 const uint32_t rel = e >> C::TAGB, rot = cand_rot(c_q, e), dn = rot + 1u;
                 // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
                 const bool ok = valid && rot < W;
+#ifdef RSN_CHAIN_STATS
+                n_ok += ok ? 1u : 0u;
+#endif
                 uint32_t lim = 0, off = C::OFF0;
                 unsigned long long x = 1;
                 if (ok) {
@@ -1273,6 +1292,9 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             while (hm) {
                 const int hl = __builtin_ctzll(hm);
                 hm &= hm - 1;
+#ifdef RSN_CHAIN_STATS
+                n_heavy_visits++;
+#endif
                 const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl), c_q = (uint32_t)__builtin_amdgcn_readlane((int)cand_q(irel, tag), hl),
                                c_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, hl), c_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, hl),
                                c_capE = (uint32_t)__builtin_amdgcn_readlane((int)capE, hl);
@@ -1281,7 +1303,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 uint32_t wb = 0, n_long = 0, far = 0;
                 for (uint32_t base = c_lo; base < c_hi; base += 64) {
 #ifdef RSN_CHAIN_STATS
-                    n_rounds += K;
+                    n_rounds += K; n_heavy++;
 #endif
                     const uint32_t idx = base + (uint32_t)lane;
                     const bool valid = idx < c_hi;
@@ -1321,7 +1343,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             __builtin_amdgcn_wave_barrier();
             for (uint32_t g0 = 0; g0 < n_all; g0 += K) {
 #ifdef RSN_CHAIN_STATS
-                n_rounds++;
+                n_rounds++; n_dealt++;
 #endif
                 const uint32_t g = g0 + (uint32_t)slot;
                 const uint32_t rm = ws.rowmap[g < n_all ? g : 0u], ch = rm >> 8;
@@ -1454,6 +1476,13 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         const unsigned long long st2 = __builtin_amdgcn_s_memtime();       // this wavefront is done
         atomicAdd(&a.stats[4], st1 - st0); atomicAdd(&a.stats[5], st2 - st1); atomicAdd(&a.stats[6], 1ull);
         atomicAdd(&a.stats[3], (unsigned long long)n_iter); atomicAdd(&a.stats[7], (unsigned long long)n_act);
+        atomicAdd(&a.stats[8], (unsigned long long)n_dealt); atomicAdd(&a.stats[9], (unsigned long long)n_heavy); atomicAdd(&a.stats[10], (unsigned long long)n_heavy_visits);
+    }
+    if (a.stats) {
+        unsigned long long okc = n_ok;
+        for (int d = 32; d; d >>= 1) okc += __shfl_down(okc, d);
+        if (lane == 0) atomicAdd(&a.stats[11], okc);
+        if ((lane & (LW - 1)) == 0) { atomicAdd(&a.stats[12], (unsigned long long)n_before); atomicAdd(&a.stats[13], (unsigned long long)n_after); atomicAdd(&a.stats[14], (unsigned long long)n_trips); }
     }
 #endif
     __syncthreads();
@@ -2602,16 +2631,19 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         }
         ChainArgs ha{d_fc, E, W, d_keys, halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
 #ifdef RSN_CHAIN_STATS
-        void *stp; rc = dev_buf(c, 23, 64, &stp); if (rc) return rc;
-        RSN_HIP(hipMemsetAsync(stp, 0, 64, s));
+        void *stp; rc = dev_buf(c, 23, 128, &stp); if (rc) return rc;
+        RSN_HIP(hipMemsetAsync(stp, 0, 128, s));
         ha.stats = (unsigned long long *)stp;
 #endif
         rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
 #ifdef RSN_CHAIN_STATS
         {
-            unsigned long long hs[8];
-            RSN_HIP(hipMemcpyAsync(hs, stp, 64, hipMemcpyDeviceToHost, s));
+            unsigned long long hs[16];
+            RSN_HIP(hipMemcpyAsync(hs, stp, 128, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
+            fprintf(stderr, "chain stats+: per visit: dealt wave-rounds %.3f, heavy chunks %.3f (heavy visits %.4f), candidates passing window+tag %.2f, bucket entries %.1f -> %.1f after trimming (%.3f trips); per iteration: visits %.2f, dealt rounds %.2f, heavy chunks %.2f\n",
+                    (double)hs[8] / hs[1], (double)hs[9] / hs[1], (double)hs[10] / hs[1], (double)hs[11] / hs[1], (double)hs[12] / hs[1], (double)hs[13] / hs[1], (double)hs[14] / hs[1],
+                    (double)hs[1] / hs[3], (double)hs[8] / hs[3], (double)hs[9] / hs[3]);
             fprintf(stderr, "chain stats: rounds %llu evals %llu (%.3f per position) ext-steps %llu | waves %llu | cycles/wave: setup %.0f walk %.0f | rounds/eval %.2f | iterations %llu, rows at work %llu\n",
                     hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1], hs[3], hs[7]);
         }
