@@ -753,10 +753,10 @@ __device__ __forceinline__ uint32_t vec(uint32_t x) { asm volatile("" : "+v"(x))
 // The same reductions over a ROW of LW = 16 or 32 lanes (k_match_chain with several chains per wavefront): every lane of the row gets the result.
 template <int LW>
 __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
-    static_assert(LW == 8 || LW == 16 || LW == 32, "half a DPP row, a row, or two");
+    static_assert(LW == 4 || LW == 8 || LW == 16 || LW == 32, "a quad, half a DPP row, a row, or two");
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR1, 0xF, 0xF, true));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_QUAD_XOR2, 0xF, 0xF, true));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
+    if constexpr (LW >= 8) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
     if constexpr (LW >= 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RSN_DPP_ROW_MIRROR, 0xF, 0xF, true));
     if constexpr (LW == 32) v = max(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));   // lane ^ 16
     return v;
@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
 #endif
 template <class C, int LW>
 __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
-    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : RSN_CHAIN_ROW_CS, CH = C::CH, NS = C::NS;
+    // (a start every 64 positions for 128 walkers; a quad per chain is 256 walkers: a start every 32)
+    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : (LW == 4 ? RSN_CHAIN_ROW_CS / 2 : RSN_CHAIN_ROW_CS), CH = C::CH, NS = C::NS;
     constexpr uint32_t TAGM = (1u << C::TAGB) - 1;
     // A list entry is staged offset << TAGB | tag.  The test of a candidate -- its start in [i - W, i) and the same tag -- is then one
     // subtraction, one rotation and one compare: with Q = (offset of i - 1) << TAGB | tag of i, Q - entry is (distance - 1) << TAGB when
@@ -1151,24 +1152,25 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         //           (K r + s)-th row of the concatenated lists, whichever chain it belongs to (its parameters come from LDS), so a visit with
         //           3 candidates and one with 300 cost 1 + 19 rows = 5 rounds, not 19; a row's maximum goes to its chain by an LDS atomic;
         //        3. the home rows commit (and take the rare paths: long matches, no bigram match).
-        static_assert(LW == 16 || LW == 8, "a DPP row, or half of one, per chain");
+        static_assert(LW == 16 || LW == 8 || LW == 4, "a DPP row, half of one, or a quad per chain");
         constexpr int K = 64 / LW, NWV = CTH / 64;
         constexpr uint32_t NARROW = RSN_CHAIN_NARROW;                        // a bucket is trimmed while it holds more entries than this
-        constexpr uint32_t HEAVY_ROWS = RSN_CHAIN_HEAVY / LW;                 // a visit with this many rows of candidates takes the whole wavefront
+        constexpr uint32_t HEAVY_ROWS = RSN_CHAIN_HEAVY / LW < 16 ? RSN_CHAIN_HEAVY / LW : 16;   // a visit with this many rows of candidates takes the whole wavefront (a row index is four bits of the row map)
+        constexpr uint32_t LCAP = K > 8 ? 4 : LONG_CAP;                       // long candidates listed per chain (sixteen chains: the lists' LDS)
         // a wavefront's scratch, one record (one base address in a register; the members are offsets in the LDS instructions)
         struct WaveScratch {
             uint32_t par[K][8];                                               // a visit's parameters for the lanes its candidates are dealt to
             uint32_t best[K], lcnt[K], lfar[K];                               // its maximum; its long candidates: how many, the farthest
-            uint32_t llist[K][LONG_CAP][2];                                   // the first LONG_CAP long candidates (distance | limit << 16, bytes known equal)
-            uint16_t rowmap[K * (HEAVY_ROWS < 256 ? HEAVY_ROWS : 256)];       // dealt row -> chain << 8 | row of that chain (a chain with HEAVY_ROWS rows is not dealt)
+            uint32_t llist[K][LCAP][2];                                       // the first LCAP long candidates (distance | limit << 16, bytes known equal)
+            uint8_t rowmap[K * HEAVY_ROWS];                                   // dealt row -> chain << 4 | row of that chain (a chain with HEAVY_ROWS rows is not dealt)
         };
         __shared__ __attribute__((aligned(16))) WaveScratch s_ws[NWV];
         WaveScratch &ws = s_ws[wv];
-        static_assert(HEAVY_ROWS <= 256 && K <= LW, "a row index fits a byte; the prefix sum runs within a row");
+        static_assert(HEAVY_ROWS <= 16 && K <= 16, "chain and row share a byte of the row map");
         const int rl = lane & (LW - 1), slot = lane / LW;                     // lane within the row; the row (= the home chain)
         const bool leader = rl == 0;
         if (leader) { ws.best[slot] = 0; ws.lcnt[slot] = 0; ws.lfar[slot] = 0; }
-        if (lane < K * 8) (&ws.par[0][0])[lane] = 0;
+        for (int i = lane; i < K * 8; i += 64) (&ws.par[0][0])[i] = 0;
         bool alive = true, voted = false;
         uint32_t next = 0xFFFFFFFFu, visits = 0, from_kp = 0;
         while (__ballot(alive)) {
@@ -1273,7 +1275,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                         if ((uint32_t)rl == first) { k0 = atomicAdd(&ws.lcnt[ch], (uint32_t)__builtin_popcount(rm)); atomicMax(&ws.lfar[ch], far); }
                         k0 = row_read<LW>(k0, first, lane);
                         const uint32_t k = k0 + (uint32_t)__builtin_popcount(rm & ((1u << rl) - 1u));
-                        if (fl && k < LONG_CAP) { ws.llist[ch][k][0] = dn | (lim << 16); ws.llist[ch][k][1] = off + 8; }
+                        if (fl && k < LCAP) { ws.llist[ch][k][0] = dn | (lim << 16); ws.llist[ch][k][1] = off + 8; }
                     }
                 }
                 const uint32_t nb = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
@@ -1318,7 +1320,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                         n_long += (uint32_t)__builtin_popcountll(lm);
                         far = max(far, wave_max_u32(long_dn));
                         const uint32_t last_blk = (uint32_t)__builtin_amdgcn_readlane((int)e, 63) >> (C::TAGB + CSH);   // (lane 63 holds the round's last entry, or re-reads the first: then the loop ends anyway)
-                        if (n_long > LONG_CAP && base + 64 < c_hi && last_blk > ((c_irel - far) >> CSH)) break;
+                        if (n_long > LCAP && base + 64 < c_hi && last_blk > ((c_irel - far) >> CSH)) break;
                     }
                 }
                 wb = wave_max_u32(wb);
@@ -1337,7 +1339,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
             {
                 const uint32_t mine0 = pre - nrows;                               // rows of the chains before this one
-                for (uint32_t j = (uint32_t)rl; j < nrows; j += LW) ws.rowmap[mine0 + j] = (uint16_t)(((uint32_t)slot << 8) | j);
+                for (uint32_t j = (uint32_t)rl; j < nrows; j += LW) ws.rowmap[mine0 + j] = (uint8_t)(((uint32_t)slot << 4) | j);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1346,9 +1348,9 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 n_rounds++; n_dealt++;
 #endif
                 const uint32_t g = g0 + (uint32_t)slot;
-                const uint32_t rm = ws.rowmap[g < n_all ? g : 0u], ch = rm >> 8;
+                const uint32_t rm = ws.rowmap[g < n_all ? g : 0u], ch = rm >> 4;
                 const uint4 p0 = *reinterpret_cast<const uint4 *>(&ws.par[ch][0]), p1 = *reinterpret_cast<const uint4 *>(&ws.par[ch][4]);
-                const uint32_t idx = p1.x + (rm & 0xFFu) * LW + (uint32_t)rl;
+                const uint32_t idx = p1.x + (rm & 0xFu) * LW + (uint32_t)rl;
                 const bool valid = g < n_all && idx < p1.y;
                 uint32_t long_dn;
                 const uint32_t key = eval(valid, s_list[valid ? idx : 0u], p0.x, p0.y, (unsigned long long)p0.z | ((unsigned long long)p0.w << 32), p1.z, ch, long_dn);
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 else {
                     bool giveup_heavy = false, giveup_dense = false;
                     if (longm) {
-                        if (lcnt <= LONG_CAP) {                               // every long candidate is followed to its end: the maximum is exact
+                        if (lcnt <= LCAP) {                                   // every long candidate is followed to its end: the maximum is exact
                             // (farthest first: a candidate at distance d matches d bytes at most, so once the best reaches further than the
                             //  farthest one left, the rest cannot win -- a 1000-periodic stream follows one candidate over 4000 bytes, not four)
                             uint32_t done = 0;
@@ -1444,11 +1446,22 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                 const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
                                 hit = (s_present[b0] & m) != 0;
                             }
-                            if (!hit) {                                       // the two ragged ends, byte by byte
+                            if (!hit) {                                       // the two ragged ends, four bytes per lane and trip
+                                // (r04: byte by byte, a row's 8 lanes took up to 32 trips per end -- every visit of incompressible data comes through
+                                //  here, config 3's first tile 4096 times in a row: 0.36 ms of that 1.4 ms call)
                                 const uint32_t e1r = min(fb_lo << CSH, irel), s2 = max(min(fb_hi << CSH, irel), fb_lo < fb_hi ? ws : e1r);
-                                bool f = false;
-                                for (uint32_t q = ws + rl; q < e1r; q += LW) f = f || sb[q] == b0;
-                                for (uint32_t q = s2 + rl; q < irel; q += LW) f = f || sb[q] == b0;
+                                auto any_eq = [&](uint32_t q0, uint32_t q1) {  // does byte b0 occur at a staged offset in [q0, q1)?  one aligned dword per lane and trip
+                                    bool f = false;
+                                    for (uint32_t wq = (q0 >> 2) + (uint32_t)rl; 4u * wq < q1; wq += LW) {
+                                        uint32_t m = bytes_equal(sw[wq], b0);          // 0xFF in every byte that equals b0 (exact per byte)
+                                        const uint32_t p0 = 4u * wq;
+                                        if (p0 < q0) m &= 0xFFFFFFFFu << (8u * (q0 - p0));
+                                        if (p0 + 4u > q1) m &= 0xFFFFFFFFu >> (8u * (p0 + 4u - q1));
+                                        f = f || m != 0;
+                                    }
+                                    return f;
+                                };
+                                const bool f = any_eq(ws, e1r) || any_eq(s2, irel);
                                 hit = row_ballot<LW>(f, lane) != 0;
                             }
                             best = hit ? (1u << 16) : 0u;
@@ -2568,10 +2581,11 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     bool parsed = false;                                              // flags + tile offsets + total are final
     using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     // lanes per chain in k_match_chain: 8 or 16 = eight or four chains per wavefront, 64 = a wavefront per chain (RSN_LZSS_CHAIN_LANES, A/B)
-    static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 ? v : 8; }();
+    static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 || v == 4 ? v : 8; }();
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
         if (chain_lanes == 64) RSN_LAUNCH(name, (k_match_chain<CC, 64>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         else if (chain_lanes == 8) RSN_LAUNCH(name, (k_match_chain<CC, 8>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        else if (chain_lanes == 4) RSN_LAUNCH(name, (k_match_chain<CC, 4>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         else RSN_LAUNCH(name, (k_match_chain<CC, 16>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         return RSN_OK;
     };

@@ -537,7 +537,7 @@ def test_chain_vs_allpos_switch(oracle):
             "print(hashlib.sha256(lz.CompressAsync(d)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     envs = ({}, {"RSN_LZSS_ALLPOS": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1", "RSN_LZSS_NO_CKEYS": "1"},
-            {"RSN_LZSS_CHAIN_LANES": "64"}, {"RSN_LZSS_CHAIN_LANES": "16", "RSN_LZSS_TAIL_SERIAL": "1"})
+            {"RSN_LZSS_CHAIN_LANES": "64"}, {"RSN_LZSS_CHAIN_LANES": "16", "RSN_LZSS_TAIL_SERIAL": "1"}, {"RSN_LZSS_CHAIN_LANES": "4"})
     for env in envs:
         e = dict(os.environ); e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
