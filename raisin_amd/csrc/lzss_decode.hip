@@ -1296,7 +1296,17 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         }
         if (plain) {
             *out_n = E;
-            if (!d_out || E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
+            if (!d_out || E > out_cap) {
+                // (k_lzd_check's verdict before the capacity answer -- a malformed stream is RSN_ERR_FORMAT on the first call,
+                //  whatever the buffer; a round trip on this path only)
+                if (one_pass) {
+                    RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
+                    RSN_HIP(hipStreamSynchronize(s));
+                    if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+                }
+                *out_n = round_up((size_t)E, 16) + 16;
+                return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap);
+            }
         }
         RSN_LAUNCH("lzss_dec_emit", k_lzd_emit, dim3(n_groups), dim3(DTH), (size_t)TL * 2 + 16, s, d_desc, TL, n_tiles, dgrp, E, d_gtail, plain ? d_out : d_esc, d_summ, plain ? 1 : 0,
                    (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);   // (+16: a run tile reads whole dwords of the tail, up to three bytes past it)

@@ -86,19 +86,44 @@ def CompressFile(algorithms, path, output):
     return out
 
 
+BATCH_BYTES = 4 << 30        # files are read and batched in groups of at most this many bytes: N x 1 GiB inputs never all sit in memory
+
+
 def CompressFiles(algorithms, files, extension):
-    """engine.go:150-154: one .rsn per input.  Several files under one Huffman layer go through rsn_huffman_compress_batch -- the files
-    dealt out over the visible GPUs, upload / encode / download overlapped per device; the outputs are those of the loop."""
+    """engine.go:150-154: one .rsn per input, file after file.  Several files under one Huffman layer go through
+    rsn_huffman_compress_batch -- upload / encode / download overlapped on the device -- in GROUPS of at most BATCH_BYTES, in the loop's
+    order and with the loop's semantics: a file's lines are printed and its .rsn is written before the next group is read, and a file
+    the batch cannot take (empty: the reference panics in heap.Pop, huffman.go:102) or a group that fails falls back to the per-file
+    loop, which stops at the failing file with every earlier .rsn already on disk -- exactly where the reference's loop would stop."""
     files = list(files)
     if len(files) > 1 and list(algorithms) == ["huffman"]:
-        datas = [open(f, "rb").read() for f in files]
-        outs = huffman.CompressBatch(datas)
-        for f, data, out in zip(files, datas, outs):
-            print("Compressing...")
-            open(f + extension, "wb").write(out)
-            print("Original bytes: %d" % len(data))
-            print("Compressed bytes: %d" % len(out))
-            print("Compression ratio: %.2f%%" % (len(out) / len(data) * 100 if data else float("nan")))
+        i = 0
+        while i < len(files):
+            group, datas, size = [], [], 0
+            while i < len(files) and (not group or size + os.path.getsize(files[i]) <= BATCH_BYTES):
+                if os.path.getsize(files[i]) == 0:
+                    break                                        # an empty file ends the group: the loop below meets it in order
+                d = open(files[i], "rb").read()
+                group.append(files[i]); datas.append(d); size += len(d); i += 1
+            outs = None
+            if len(group) > 1:
+                try:
+                    outs = huffman.CompressBatch(datas)
+                except Exception:                               # noqa: BLE001 -- the loop finds the file that fails, after writing the ones before it
+                    outs = None
+            if outs is None:
+                for f in group:
+                    CompressFile(algorithms, f, f + extension)
+            else:
+                for f, data, out in zip(group, datas, outs):
+                    print("Compressing...")
+                    open(f + extension, "wb").write(out)
+                    print("Original bytes: %d" % len(data))
+                    print("Compressed bytes: %d" % len(out))
+                    print("Compression ratio: %.2f%%" % (len(out) / len(data) * 100 if data else float("nan")))
+            if i < len(files) and os.path.getsize(files[i]) == 0:
+                CompressFile(algorithms, files[i], files[i] + extension)   # raises like the reference panics; the earlier files are written
+                i += 1
         return
     for f in files:
         CompressFile(algorithms, f, f + extension)

@@ -177,31 +177,49 @@ int main(int argc, char **argv) {
             if (algorithm.empty()) algorithm = "lzss,huffman";   // reference default "lzss,arithmetic" (cli.go:99); arithmetic is not on this path
             const auto algs = split(algorithm, ',');
             auto out_name = [&](const std::string &f) { return files.size() == 1 ? (out.empty() ? f + ".rsn" : out) : f + "." + (outext.empty() ? "rsn" : outext); };   // cli.go:108-112
-            if (files.size() > 1 && algs.size() == 1 && algs[0] == "huffman") {
-                // engine.CompressFiles loops over the files, one .rsn each (engine.go:150-154).  Independent inputs of one Huffman layer go
-                // through the batch entry point instead: librsn deals them out over the visible GPUs (file k -> device k mod G) and
-                // overlaps upload, encode and download per device; every output equals what the loop below would have written.
-                std::vector<Bytes> datas;
-                for (auto &f : files) datas.push_back(read_file(f));
-                std::vector<const uint8_t *> ins; std::vector<size_t> lens;
-                for (auto &d : datas) { ins.push_back(d.data()); lens.push_back(d.size()); }
-                std::vector<uint8_t *> outs(files.size(), nullptr); std::vector<size_t> out_lens(files.size(), 0);
-                if (rsn_huffman_compress_batch(files.size(), ins.data(), lens.data(), outs.data(), out_lens.data()) != RSN_OK) throw std::runtime_error(rsn_last_error());
-                for (size_t i = 0; i < files.size(); i++) {
-                    printf("Compressing...\n");
-                    write_file(out_name(files[i]), Bytes(outs[i], outs[i] + out_lens[i]));
-                    rsn_free(outs[i]);
-                    printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", datas[i].size(), out_lens[i], (float)out_lens[i] / (float)datas[i].size() * 100.f);
-                }
-            } else
-            for (auto &f : files) {
+            auto one_file = [&](const std::string &f) {            // engine.CompressFile, engine.go:157-172
                 const std::string o = out_name(f);
                 const Bytes data = read_file(f);
                 printf("Compressing...\n");
                 const Bytes c = engine::compress(data, algs);
                 write_file(o, c);
                 printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", data.size(), c.size(), (float)c.size() / (float)data.size() * 100.f);   // engine.go:166-169
-            }
+            };
+            if (files.size() > 1 && algs.size() == 1 && algs[0] == "huffman") {
+                // engine.CompressFiles loops over the files, one .rsn each (engine.go:150-154).  Independent inputs of one Huffman layer go
+                // through the batch entry point -- upload, encode and download overlapped on the device (and dealt over devices with
+                // RSN_BATCH_DEVICES) -- in GROUPS of at most 4 GiB, in the loop's order and with its semantics: a group's files are written
+                // before the next group is read, an empty file (the reference panics, huffman.go:102) ends a group, and a group that fails
+                // is done again by the loop, which stops at the failing file with everything before it on disk.
+                constexpr size_t BATCH_BYTES = (size_t)4 << 30;
+                size_t i = 0;
+                while (i < files.size()) {
+                    std::vector<std::string> group; std::vector<Bytes> datas; size_t size = 0;
+                    while (i < files.size()) {
+                        Bytes d = read_file(files[i]);
+                        if (d.empty() || (!group.empty() && size + d.size() > BATCH_BYTES)) break;
+                        size += d.size(); group.push_back(files[i]); datas.push_back(std::move(d)); i++;
+                    }
+                    bool done = false;
+                    if (group.size() > 1) {
+                        std::vector<const uint8_t *> ins; std::vector<size_t> lens;
+                        for (auto &d : datas) { ins.push_back(d.data()); lens.push_back(d.size()); }
+                        std::vector<uint8_t *> outs(group.size(), nullptr); std::vector<size_t> out_lens(group.size(), 0);
+                        if (rsn_huffman_compress_batch(group.size(), ins.data(), lens.data(), outs.data(), out_lens.data()) == RSN_OK) {
+                            for (size_t k = 0; k < group.size(); k++) {
+                                printf("Compressing...\n");
+                                write_file(out_name(group[k]), Bytes(outs[k], outs[k] + out_lens[k]));
+                                rsn_free(outs[k]);
+                                printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", datas[k].size(), out_lens[k], (float)out_lens[k] / (float)datas[k].size() * 100.f);
+                            }
+                            done = true;
+                        }
+                    }
+                    if (!done) for (auto &f : group) one_file(f);
+                    if (group.empty() && i < files.size()) one_file(files[i++]);   // an empty (or alone oversized) file: the loop's turn, in order
+                }
+            } else
+            for (auto &f : files) one_file(f);
             if (has_delete && del) for (auto &f : files) remove(f.c_str());
         } else if (cmd == "decompress") {
             if (algorithm.empty()) algorithm = "lzss,huffman";

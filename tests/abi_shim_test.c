@@ -79,6 +79,18 @@ int main(int argc, char **argv) {
     uint8_t *g = rsn_call(lz_legacy, (const uint8_t *)"abcabcabcabcabcabcabcabc\n", 25, &n, &rc);
     CHECK(rc == 0 && n == 21 && memcmp(g, "abcabca<6,6>b<12,10>\n", 21) == 0);
     free(g);
+    /* ... and its limit: the shim's lz.Compress panics ("librsn: ... above the ...-byte bound") where the reference would have run its
+     * O(n * W) loop for hours -- 1 MiB + 1 with an unbounded window (window 0) is refused before any work, with this thread's message
+     * (RSN_LEGACY_NO_LIMIT=1 lifts the bound: tests/test_abi_and_host.py) */
+    {
+        const size_t big = ((size_t)1 << 20) + 1;
+        uint8_t *zeros = calloc(big, 1), *lo = NULL; size_t lon = 0;
+        CHECK(rsn_lzss_compress_legacy(zeros, big, 0, &lo, &lon) == RSN_ERR_LIMIT && lo == NULL && lon == 0 && strstr(rsn_last_error(), "legacy"));
+        if (!getenv("RSN_LEGACY_NO_LIMIT")) {
+            uint8_t *x = rsn_call(lz_legacy, zeros, 100, &n, &rc); CHECK(x != NULL && rc == 0); free(x);   /* the next call on the thread is unaffected */
+        }
+        free(zeros);
+    }
     if (nodev) {
         if (rsn_device_count() <= 0) {                       /* no GPU: every codec call fails loudly, none computes on the CPU */
             uint8_t *x = rsn_call(rsn_huffman_compress, (const uint8_t *)"abc", 3, &n, &rc);

@@ -81,6 +81,40 @@ def test_cpp_host_compresses_a_list_of_files_through_the_batch_entry_point(tmp_p
     assert open(paths[0] + ".pyl", "rb").read() == oracle.lzss_compress(datas[0])
 
 
+def test_list_of_files_keeps_the_loops_semantics_when_one_fails(tmp_path, oracle, samiam):
+    """engine.CompressFiles is a loop (engine.go:150-154) -- when the third of four files makes Compress panic (an empty
+    file: heap.Pop on an empty heap, huffman.go:102) the first two .rsn are on disk, the third call fails, the fourth is never made.
+    The batch path keeps that: files go through in order, in groups (BATCH_BYTES), an empty file is the per-file loop's to meet."""
+    from raisin_amd import RsnError, engine
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    datas = [samiam, samiam[::-1] * 2, b"", samiam * 3]
+    paths = []
+    for i, d in enumerate(datas):
+        p = tmp_path / ("g%d.txt" % i)
+        p.write_bytes(d)
+        paths.append(str(p))
+    with pytest.raises(RsnError) as ei:
+        engine.CompressFiles(["huffman"], paths, ".pyh")
+    assert ei.value.code == -2
+    for k in (0, 1):
+        assert open(paths[k] + ".pyh", "rb").read() == oracle.huffman_compress(datas[k])
+    assert not os.path.exists(paths[3] + ".pyh")
+    r = subprocess.run([exe, "-compress", ",".join(paths), "-algorithm=huffman", "-outext=huf"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout.count("Compressing...") >= 2
+    for k in (0, 1):
+        assert open(paths[k] + ".huf", "rb").read() == oracle.huffman_compress(datas[k])
+    assert not os.path.exists(paths[3] + ".huf")
+    old = engine.BATCH_BYTES                                  # groups: three files of which no two fit one group -> three single calls, same bytes
+    engine.BATCH_BYTES = len(samiam) * 2
+    try:
+        engine.CompressFiles(["huffman"], [paths[0], paths[1], paths[3]], ".grp")
+    finally:
+        engine.BATCH_BYTES = old
+    for k in (0, 1, 3):
+        assert open(paths[k] + ".grp", "rb").read() == oracle.huffman_compress(datas[k])
+
+
 def test_benchmark_suite_table(tmp_path, samiam):
     import io
     from raisin_amd import engine
