@@ -157,31 +157,41 @@ __global__ __launch_bounds__(LB) void k_esc_write(const uint8_t *__restrict__ in
 // the bytes it has in registers and a second load Wp earlier that the neighbouring block has just brought into the L2: one flag per block;
 // k_tiles_from_blocks turns them into the tiles' records.  (Config 3: k_tile_periodic read tile + window again from memory, 0.60 ms per
 // GiB; comparing the INPUT is the same as comparing the escaped stream while nothing needs an escape: '<' -> FF is injective on such input.)
+constexpr int ESC_RUN = 8;                  // consecutive 4 KiB chunks per block of k_esc_try: with the engine's window (4096 = one chunk) the bytes "Wp before" are the
+                                            // previous chunk's, still in the lane's registers -- 1.125 N fetched for the comparison instead of 2 N
 __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ fc, unsigned long long *__restrict__ flag,
-                                                uint32_t Wp, uint8_t *__restrict__ same_blk) {
-    const size_t P = (size_t)blockIdx.x * ESC_TILE + threadIdx.x * 16;
-    uint32_t w[4]; int cnt;
-    load16(in, n, P, w, &cnt);                                             // (bytes beyond n read as zero: neither special nor '<')
-    bool same = true;
-    if (Wp) {                                                              // (a multiple of 16: the earlier bytes are one aligned load too)
-        if (P < Wp) same = cnt == 0;
-        else if (cnt) {
-            uint32_t v[4]; int c2;
-            load16(in, n, P - Wp, v, &c2);
-            if (cnt == 16) same = ((w[0] ^ v[0]) | (w[1] ^ v[1]) | (w[2] ^ v[2]) | (w[3] ^ v[3])) == 0;
-            else for (int k = 0; k < cnt; k++) same = same && ((w[k >> 2] ^ v[k >> 2]) >> (8 * (k & 3)) & 0xFF) == 0;
+                                                uint32_t Wp, uint8_t *__restrict__ same_blk, uint32_t n_chunks) {
+    uint32_t prev[4] = {0, 0, 0, 0};
+    int prev_cnt = -1;                                                     // -1: nothing in `prev` (the run's first chunk, or Wp is not a chunk)
+    for (uint32_t k = 0; k < (uint32_t)ESC_RUN; k++) {
+        const uint32_t chunk = blockIdx.x * ESC_RUN + k;
+        if (chunk >= n_chunks) break;                                      // (block-uniform)
+        const size_t P = (size_t)chunk * ESC_TILE + threadIdx.x * 16;
+        uint32_t w[4]; int cnt;
+        load16(in, n, P, w, &cnt);                                         // (bytes beyond n read as zero: neither special nor '<')
+        bool same = true;
+        if (Wp) {                                                          // (a multiple of 16: the earlier bytes are one aligned load too)
+            if (P < Wp) same = cnt == 0;
+            else if (cnt) {
+                uint32_t v[4]; int c2 = 16;
+                if (Wp == (uint32_t)ESC_TILE && prev_cnt >= 0) { v[0] = prev[0]; v[1] = prev[1]; v[2] = prev[2]; v[3] = prev[3]; }
+                else load16(in, n, P - Wp, v, &c2);
+                if (cnt == 16) same = ((w[0] ^ v[0]) | (w[1] ^ v[1]) | (w[2] ^ v[2]) | (w[3] ^ v[3])) == 0;
+                else for (int q = 0; q < cnt; q++) same = same && ((w[q >> 2] ^ v[q >> 2]) >> (8 * (q & 3)) & 0xFF) == 0;
+            }
+            prev[0] = w[0]; prev[1] = w[1]; prev[2] = w[2]; prev[3] = w[3]; prev_cnt = cnt;   // (the INPUT bytes: before '<' becomes FF below)
         }
-    }
-    uint32_t special = 0;
+        uint32_t special = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); w[j] |= bytes_equal(w[j], 0x3Cu); }
-    if (__ballot(special != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1ull);
-    uint8_t *d = fc + P;
-    if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
-    else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-    if (Wp) {
-        const int all = __syncthreads_and(same);
-        if (threadIdx.x == 0) same_blk[blockIdx.x] = (uint8_t)all;
+        for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); w[j] |= bytes_equal(w[j], 0x3Cu); }
+        if (__ballot(special != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1ull);
+        uint8_t *d = fc + P;
+        if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+        else for (int q = 0; q < cnt; q++) d[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+        if (Wp) {
+            const int all = __syncthreads_and(same);
+            if (threadIdx.x == 0) same_blk[chunk] = (uint8_t)all;
+        }
     }
 }
 
@@ -2860,7 +2870,7 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
         if (Wp && !no_fused_periodic) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
         RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
         RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3(n_eb), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same);
+        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
         RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
         copied = h64[0] == 0;
