@@ -1,5 +1,5 @@
 """Measured HBM traffic against algorithmic bytes, per workload and direction, from the committed summaries:
-    python scripts/traffic_report.py <tag>       reads profiles/<tag>_pmc_<workload>.json (+ profiles/<tag>_bench.json for the sizes)
+    python scripts/traffic_report.py <tag> [bench-tag]   reads profiles/<tag>_pmc_<workload>.json (+ profiles/<bench-tag or tag>_bench.json for the sizes)
 Traffic = sum over the workload's kernels of FETCH_SIZE (doubled, gfx950) + WRITE_SIZE at each kernel's LARGEST launch x the number of
 full-size launches a call makes of it (1, except kernels launched once per scan level, whose bytes are negligible).  Algorithmic bytes per
 SURVEY 8d: Huffman encode 2N + C, decode C + N_out; LZSS encode N + C, decode C + N; config 4 = the sum of its two layers."""
@@ -13,7 +13,8 @@ DEC = ("k_lzd_", "k_une_", "k_dec_")
 
 def main():
     tag = sys.argv[1]
-    bench = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench.json")).read().strip().splitlines()[-1])
+    btag = sys.argv[2] if len(sys.argv) > 2 else tag
+    bench = json.loads(open(os.path.join(ROOT, "profiles", btag + "_bench.json")).read().strip().splitlines()[-1])
     oc = bench.get("other_configs", {})
     n = 1 << 30
     rows = []
