@@ -834,6 +834,13 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
 #ifndef RSN_CHAIN_HEAVY
 #define RSN_CHAIN_HEAVY 128
 #endif
+// TIMING PROBE (-DRSN_CHAIN_PROBE_B2, never in the product: it misses the matches of exactly two bytes): buckets keyed by a hash of the
+// bigram AND three bits of the third byte, tag = two more bits of the third byte -- what the walk would cost if a visit only met the
+// candidates that share a trigram.  See DESIGN 8.
+#ifdef RSN_CHAIN_PROBE_B2
+__device__ __forceinline__ uint32_t probe_h(uint32_t b0, uint32_t b1, uint32_t b2) { return ((((b0 * 37u) ^ (b1 * 101u)) & 0x3FFu) << 3) | (b2 & 7u); }
+__device__ __forceinline__ uint32_t probe_tag(uint32_t b2) { return (b2 >> 3) & 3u; }
+#endif
 template <class C, int LW>
 __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
     // (a start every 64 positions for 128 walkers; a quad per chain is 256 walkers: a start every 32)
@@ -892,7 +899,11 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const uint32_t rlo = (uint32_t)(max(0ll, q0 - (long long)W) - r0), rhi = (uint32_t)(min((long long)E - 1, t0 + (long long)CT) - r0);
     for (uint32_t rel = tid; rel < (uint32_t)NS; rel += CTH) {
         if (rel < rlo || rel >= rhi) continue;
+#ifdef RSN_CHAIN_PROBE_B2
+        const uint32_t b0 = sb[rel], h = probe_h(b0, sb[rel + 1], sb[rel + 2]);
+#else
         const uint32_t b0 = sb[rel], h = (b0 << 5) | (sb[rel + 1] & 31u);
+#endif
         atomicAdd(&s_cur[h >> 1], 1u << (16 * (h & 1)));
         const unsigned long long bit = 1ull << (rel >> CSH);
         if (!(s_present[b0] & bit)) atomicOr(&s_present[b0], bit);
@@ -923,9 +934,15 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         for (int g = 0; g < (CTH >> CSH); g++) {
             if ((tid >> CSH) == g && rel >= rlo && rel < rhi) {
                 const uint32_t b1 = sb[rel + 1];
+#ifdef RSN_CHAIN_PROBE_B2
+                const uint32_t h = probe_h(sb[rel], b1, sb[rel + 2]), sh = 16 * (h & 1);
+                const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
+                s_list[slot] = (uint16_t)((rel << C::TAGB) | (probe_tag(sb[rel + 2]) & TAGM));
+#else
                 const uint32_t h = ((uint32_t)sb[rel] << 5) | (b1 & 31u), sh = 16 * (h & 1);
                 const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
                 s_list[slot] = (uint16_t)((rel << C::TAGB) | ((b1 >> 5) & TAGM));
+#endif
             }
             __syncthreads();
         }
@@ -1211,8 +1228,13 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             if (mine) {
                 irel = HWMAX + kp; capE = E - ((uint32_t)(t0 - CH) + kp);
                 const uint32_t b0 = sb[irel], b1 = sb[irel + 1];
+#ifdef RSN_CHAIN_PROBE_B2
+                const uint32_t h = probe_h(b0, b1, sb[irel + 2]);
+                tag = probe_tag(sb[irel + 2]) & TAGM;
+#else
                 const uint32_t h = (b0 << 5) | (b1 & 31u);
                 tag = (b1 >> 5) & TAGM;
+#endif
                 lo = h ? (uint32_t)ends[h - 1] : 0u; hi = ends[h];
                 const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
                 pat0 = lds_load8(sw, irel + C::OFF0);
