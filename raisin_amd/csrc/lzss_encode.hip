@@ -1371,7 +1371,13 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
             {
                 const uint32_t mine0 = pre - nrows;                               // rows of the chains before this one
-                for (uint32_t j = (uint32_t)rl; j < nrows; j += LW) ws.rowmap[mine0 + j] = (uint8_t)(((uint32_t)slot << 4) | j);
+                // (at most HEAVY_ROWS - 1 rows: a fixed number of predicated byte stores -- as a loop the compiler vectorised it into
+                //  ~47 VALU instructions per wavefront-iteration, a tenth of the walk: r04)
+#pragma unroll
+                for (uint32_t t = 0; t < (HEAVY_ROWS + LW - 1) / LW; t++) {
+                    const uint32_t j = (uint32_t)rl + t * LW;
+                    if (j < nrows) ws.rowmap[mine0 + j] = (uint8_t)(((uint32_t)slot << 4) | j);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
