@@ -167,3 +167,32 @@ def test_huffman_rune_fuzz(mods, oracle, seed):
         want = None
     if want is not None:
         assert huffman.Decompress(c) == want
+
+
+@pytest.mark.parametrize("seed", range(6 * MORE))
+def test_fuzz_sharded_huffman_stream(mods, oracle, seed):
+    """rsn_huffman_compress_sharded on random inputs and slice counts: bytes == the single call's == the oracle's.  Inputs mix ASCII,
+    valid multi-byte sequences and invalid bytes, so that cuts fall next to (and would fall inside) sequences of every length and
+    slices differ in whether they hold runes at all."""
+    lz, huffman, RsnError = mods
+    rng = random.Random(9000 + seed)
+    pieces = []
+    target = rng.choice((70, 300, 5000, 70000, 400000))
+    size = 0
+    while size < target:
+        kind = rng.random()
+        if kind < 0.35:
+            p = bytes(rng.choice(b"abcdefgh \n\\|0123456789") for _ in range(rng.randint(1, 400)))
+        elif kind < 0.6:
+            p = "".join(rng.choice("é€𝄞ßж中🙂") for _ in range(rng.randint(1, 120))).encode()
+        elif kind < 0.8:
+            p = bytes(rng.randrange(256) for _ in range(rng.randint(1, 200)))          # mostly invalid sequences
+        else:
+            p = bytes([rng.choice((0xE2, 0xF0, 0xC3, 0x82, 0xAC))]) * rng.randint(1, 9)  # lead bytes and continuation bytes on their own
+        pieces.append(p)
+        size += len(p)
+    data = b"".join(pieces)
+    ref = oracle.huffman_compress(data)
+    assert huffman.Compress(data) == ref
+    for G in (2, rng.randint(3, 9), rng.randint(10, 40)):
+        assert huffman.CompressSharded(data, G) == ref, (seed, G, len(data))
