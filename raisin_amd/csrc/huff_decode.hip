@@ -1138,18 +1138,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     a.blk_off = d_blk_off; a.out = d_out; a.out_cap = out_cap;
     struct Tail { unsigned long long total; uint16_t last_exit; int changed; };
     Tail *ht = (Tail *)hp;
-    a.pass = 0;
-    rc = launch_sync(); if (rc) return rc;
-    for (uint32_t pass = 1;; pass++) {
-        if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
-        ht->changed = 0;
-        if (n_blk > 1) {                                              // (a single block starts from the exact entry and iterates to its fixed point in LDS)
-            a.pass = (int)pass;
-            RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
-            rc = launch_sync(); if (rc) return rc;
-            RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
-        }
-        rc = scan_u64(c, s, "huff_dec_scan", a.blk_bytes, d_blk_off, n_blk, d_total); if (rc) return rc;
+    auto launch_emit = [&]() -> int {
         // (8-byte table entries with the symbols already spread to bytes measured slower than unpacking the 4-byte ones: 1.19 vs 0.98 ms)
         // (This kernel scales almost linearly with blocks per CU up to the four its LDS allows.  Without the LDS output stage --
         //  a lane's dwords straight to memory -- seven blocks fit, but the scattered partial-line stores cost more than that
@@ -1158,10 +1147,39 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         else if (ascii) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
         else if (short_codes) RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
         else RSN_LAUNCH("huff_dec_emit", (k_dec_emit<false, false, false>), dim3(grid_p), dim3(DB), 0, s, a, n_blk);
+        return RSN_OK;
+    };
+    auto offsets_and_bytes = [&]() -> int {                             // D2 + D3 + the read-back of total and final exit, queued
+        int rc2 = scan_u64(c, s, "huff_dec_scan", a.blk_bytes, d_blk_off, n_blk, d_total); if (rc2) return rc2;
+        rc2 = launch_emit(); if (rc2) return rc2;
         RSN_HIP(hipMemcpyAsync(&ht->total, d_total, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipMemcpyAsync(&ht->last_exit, a.exit_rel + (a.n_sub - 1), 2, hipMemcpyDeviceToHost, s));
+        return RSN_OK;
+    };
+    a.pass = 0;
+    rc = launch_sync(); if (rc) return rc;
+    ht->changed = 0;
+    if (n_blk > 1) {                                                  // (a single block starts from the exact entry and iterates to its fixed point in LDS)
+        a.pass = 1;
+        RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
+        rc = launch_sync(); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
+    }
+    rc = offsets_and_bytes(); if (rc) return rc;                      // ... on the assumption that the one fixing pass settled it (it nearly always does)
+    RSN_HIP(hipStreamSynchronize(s));
+    if (ht->changed) {
+        // the fixing pass handed some block a different exit: more passes, the synchronisation alone, until nothing changes (a code
+        // that does not self-synchronise -- all lengths even, say -- can take as many passes as there are blocks), then D2 + D3 again
+        for (uint32_t pass = 2; ht->changed; pass++) {
+            if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
+            a.pass = (int)pass;
+            RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
+            rc = launch_sync(); if (rc) return rc;
+            RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+        }
+        rc = offsets_and_bytes(); if (rc) return rc;
         RSN_HIP(hipStreamSynchronize(s));
-        if (!ht->changed) break;
     }
     if (ht->last_exit != 0)
         return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
