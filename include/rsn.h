@@ -163,6 +163,11 @@ RSN_API int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, 
  * would index out of range.                                                   */
 RSN_API int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap);
 
+/* Where rsn_huffman_compress_sharded cuts `in` into slices: cuts[0] = 0 < ... < cuts[S] = n, every cut on a rune start of Go's
+ * decoding of the whole input (huffman.go:309: a UTF-8 sequence is never split).  Returns S (<= shards; short inputs get fewer
+ * slices), or a negative error; cuts must hold shards + 1 entries.                                                           */
+RSN_API int64_t rsn_huffman_slice_cuts(const uint8_t *in, size_t n, int shards, size_t *cuts, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ SYMBOLS = [
     "rsn_huffman_compress_bound", "rsn_lzss_compress_bound",
     "rsn_huffman_compress_dev", "rsn_huffman_decompress_dev", "rsn_lzss_compress_dev", "rsn_lzss_decompress_dev",
     "rsn_prof_enable", "rsn_prof_reset", "rsn_prof_get", "rsn_huffman_table",
-    "rsn_huffman_plan", "rsn_huffman_parse_header",
+    "rsn_huffman_plan", "rsn_huffman_parse_header", "rsn_huffman_slice_cuts",
 ]
 
 
@@ -85,6 +85,8 @@ def lib():
     L.rsn_huffman_plan.restype = ctypes.c_int64
     L.rsn_huffman_parse_header.argtypes = [ctypes.c_char_p, sz, vp, vp, sz]
     L.rsn_huffman_parse_header.restype = ctypes.c_int64
+    L.rsn_huffman_slice_cuts.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, szp, sz]
+    L.rsn_huffman_slice_cuts.restype = ctypes.c_int64
     L.rsn_huffman_compress_sharded.argtypes = [ctypes.c_char_p, sz, ctypes.c_int, ctypes.POINTER(u8p), szp]
     L.rsn_huffman_compress_batch.argtypes = [sz, ctypes.POINTER(ctypes.c_char_p), szp, ctypes.POINTER(u8p), szp]
     _lib = L

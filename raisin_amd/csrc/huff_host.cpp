@@ -46,6 +46,32 @@ int go_encode_rune(uint32_t r, uint8_t o[4]) {
     }
 }
 
+// does a rune of Go's decoding of in[0, n) begin at q?  A byte that is not a continuation byte always begins one (a valid sequence
+// or U+FFFD); a continuation byte does unless a valid sequence that begins at one of the three bytes before it reaches it -- and the
+// nearest non-continuation byte before q is the only one that can begin such a sequence.
+static bool is_rune_start(const uint8_t *in, size_t n, size_t q) {
+    if ((in[q] & 0xC0) != 0x80) return true;
+    for (size_t k = 1; k <= 3 && k <= q; k++) {
+        if ((in[q - k] & 0xC0) == 0x80) continue;
+        int sz = 1;
+        (void)go_decode_rune(in + (q - k), n - (q - k), &sz);
+        return (size_t)sz <= k;
+    }
+    return true;                                                          // three continuation bytes before it: no sequence is that long
+}
+
+void huff_slice_cuts(const uint8_t *in, size_t n, int shards, std::vector<size_t> &cut) {
+    cut.assign(1, 0);
+    size_t G = (size_t)std::max(1, std::min(shards, 256));
+    G = std::min(G, std::max<size_t>(1, n / 64));                        // (a slice of a few bytes is all overhead)
+    for (size_t w = 1; w < G; w++) {
+        size_t p = (size_t)((unsigned __int128)n * w / G);
+        while (p > cut.back() && !is_rune_start(in, n, p)) p--;
+        if (p > cut.back()) cut.push_back(p);
+    }
+    cut.push_back(n);
+}
+
 namespace {
 // Go container/heap (go1.15 src/container/heap/heap.go) over tree nodes with
 // Less(i,j) = freq[i] < freq[j] (huffman.go:43-45).  Ties are broken only by

@@ -42,6 +42,11 @@ uint32_t go_decode_rune(const uint8_t *p, size_t avail, int *size);
 int go_encode_rune(uint32_t r, uint8_t out[4]);   // string(rune) (huffman.go:138,314)
 static inline int utf8_len(uint32_t r) { return r < 0x80 ? 1 : r < 0x800 ? 2 : r < 0x10000 ? 3 : 4; }
 
+// Where one input may be cut into `shards` slices that are encoded apart (rsn_huffman_compress_sharded): 0 = cut[0] < cut[1] < ... <
+// cut[S] = n, every cut on a rune START of Go's decoding of the whole string (huffman.go:309), so that no UTF-8 sequence is split and
+// the slices' runes are the input's; fewer slices than asked where the input is short (64 bytes a slice at least).
+void huff_slice_cuts(const uint8_t *in, size_t n, int shards, std::vector<size_t> &cut);
+
 // buildTree (huffman.go:58-103) incl. Go container/heap order.  syms: any order,
 // destroyed.  Returns false (with msg) for an empty table.
 bool build_tree(std::vector<HuffSym> &syms, HuffTree &t, std::string &msg);

@@ -667,16 +667,6 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
 // split is exercised on a one-GPU box); on a node with several GPUs each slice has its own PCIe link, histogram and emit.
 // Cuts fall on rune starts (a UTF-8 sequence is never split: huffman.go:309 decodes the whole string).
 namespace {
-bool is_rune_start(const uint8_t *in, size_t n, size_t q) {
-    if ((in[q] & 0xC0) != 0x80) return true;                              // not a continuation byte: always begins a rune (valid or U+FFFD)
-    for (size_t k = 1; k <= 3 && k <= q; k++) {
-        if ((in[q - k] & 0xC0) == 0x80) continue;
-        int sz = 1;
-        (void)go_decode_rune(in + (q - k), n - (q - k), &sz);             // the nearest byte before q that can begin a sequence: does it reach q?
-        return (size_t)sz <= k;
-    }
-    return true;                                                          // three continuation bytes before it: no sequence is that long
-}
 struct ShardSync {
     std::mutex mu; std::condition_variable cv;
     size_t arrived = 0, generation = 0, parties;
@@ -707,14 +697,8 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
     const char *bd = getenv("RSN_BATCH_DEVICES");
     const int n_dev = std::max(1, std::min(visible, !bd || !*bd ? 1 : (!strcmp(bd, "all") ? visible : atoi(bd))));
     if (G <= 0) G = n_dev;
-    G = (int)std::min<size_t>((size_t)std::min(G, 256), std::max<size_t>(1, n / 64));   // (a slice of a few bytes is all overhead)
-    std::vector<size_t> cut{0};
-    for (int w = 1; w < G; w++) {
-        size_t p = (size_t)((unsigned __int128)n * (unsigned)w / (unsigned)G);
-        while (p > cut.back() && !is_rune_start(in, n, p)) p--;
-        if (p > cut.back()) cut.push_back(p);
-    }
-    cut.push_back(n);
+    std::vector<size_t> cut;
+    huff_slice_cuts(in, n, G, cut);                                       // on rune starts (huff_host.cpp: host logic, tested without a device)
     const size_t S = cut.size() - 1;                                      // slices
     if (S == 1) return huffman_compress_single(in, n, out, out_n);
 
@@ -871,6 +855,17 @@ int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n
         out_runes[k] = t.rune[id]; out_codes[k] = hc.code[id]; out_lens[k] = hc.len[id];
     }
     return (int64_t)hc.dfs.size();
+}
+
+int64_t rsn_huffman_slice_cuts(const uint8_t *in, size_t n, int shards, size_t *cuts, size_t cap) {
+    Ctx &c = ctx();
+    if ((!in && n) || !cuts) return c.fail(RSN_ERR_ARG, "null argument");
+    if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input");
+    std::vector<size_t> cut;
+    huff_slice_cuts(in, n, shards, cut);
+    if (cut.size() > cap) return c.fail(RSN_ERR_CAPACITY, "%zu cuts, room for %zu", cut.size(), cap);
+    for (size_t i = 0; i < cut.size(); i++) cuts[i] = cut[i];
+    return (int64_t)cut.size() - 1;
 }
 
 int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap) {

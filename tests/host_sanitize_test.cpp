@@ -37,6 +37,20 @@ int main() {
         std::string out;
         lzss_compress_legacy_host((const uint8_t *)in.data(), in.size(), (long long)(rng() % 3 ? 4096 : 17), out);
     }
+    for (int it = 0; it < 400; it++) {                                    // slice cuts of the sharded Huffman stream: rune starts, strictly increasing
+        std::string in;
+        const int n = 1 + (int)(rng() % 3000);
+        static const char *pieces[] = {"a", "\xC3\xA9", "\xE2\x82\xAC", "\xF0\x9D\x84\x9E", "\x80", "\xE2\x82", "\xF0\x9D", "\xFF", "\xC3", "\xBF\xBF\xBF\xBF"};
+        while ((int)in.size() < n) in += pieces[rng() % 10];
+        std::vector<size_t> cut;
+        const int G = 1 + (int)(rng() % 40);
+        huff_slice_cuts((const uint8_t *)in.data(), in.size(), G, cut);
+        if (cut.front() != 0 || cut.back() != in.size() || cut.size() > (size_t)G + 1) { printf("cuts: bad ends\n"); return 1; }
+        std::vector<char> start(in.size() + 1, 0);                          // Go's decoding of the whole string, rune by rune
+        for (size_t i = 0; i < in.size();) { start[i] = 1; int sz = 1; (void)go_decode_rune((const uint8_t *)in.data() + i, in.size() - i, &sz); i += (size_t)sz; }
+        start[in.size()] = 1;
+        for (size_t k = 0; k + 1 < cut.size(); k++) if (cut[k] >= cut[k + 1] || !start[cut[k]]) { printf("cuts: %zu is not a rune start (it %d)\n", cut[k], it); return 1; }
+    }
     printf("host sanitizer run ok\n");
     return 0;
 }

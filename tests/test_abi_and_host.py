@@ -272,3 +272,28 @@ def test_cgo_recipe_check_catches_the_r3_defects(tmp_path):
     _, _, imps = S.import_block(src)
     probs = S.check_build({"lzss.go": kept_with_sync, "lzss_purego.go": moved}, set(S.package_level_defs(src)), {i for i, _ in imps}, "lz")
     assert any("imports sync and does not use it" in p for p in probs), probs
+
+
+def test_slice_cuts_fall_on_rune_starts(built):
+    """rsn_huffman_slice_cuts (host logic of rsn_huffman_compress_sharded, no device needed): every cut is a rune start of Go's decoding
+    of the whole input (the third, pure-Python statement of it in test_oracle.go_runes gives the starts), so no UTF-8 sequence is split
+    and the slices' runes concatenate to the input's; cuts are strictly increasing, end at n, and short inputs get fewer slices."""
+    from test_oracle import go_runes
+    L = built.lib()
+    rng = random.Random(5)
+    alphabet = [b"a", b"z", "é".encode(), "€".encode(), "𝄞".encode(), b"\x80", b"\xE2\x82", b"\xF0\x9D", b"\xFF", b"\xC3", b"\xBF" * 4, b"\xED\xA0\x80"]
+    for it in range(300):
+        data = b"".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 1500)))
+        G = rng.randrange(1, 50)
+        cuts = (ctypes.c_size_t * (G + 1))()
+        S = L.rsn_huffman_slice_cuts(data, len(data), G, cuts, G + 1)
+        assert 1 <= S <= G and S <= max(1, len(data) // 64)
+        cs = [cuts[i] for i in range(S + 1)]
+        assert cs[0] == 0 and cs[-1] == len(data) and all(a < b for a, b in zip(cs, cs[1:]))
+        runes = go_runes(data)
+        for a, b in zip(cs, cs[1:]):                      # the slices decode, each on its own, to the input's runes in order
+            k = len(go_runes(data[a:b]))
+            assert go_runes(data[a:b]) == runes[:k], (it, a, b)
+            runes = runes[k:]
+        assert runes == []
+    assert L.rsn_huffman_slice_cuts(b"", 0, 3, (ctypes.c_size_t * 4)(), 4) == -2
