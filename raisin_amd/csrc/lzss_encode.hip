@@ -719,10 +719,13 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
 // KEY_UNKNOWN; if the true chain ever lands on one (k_parse_mark notices), that strip is redone for
 // all positions by k_match_hash and the parse is repeated -- correctness never rests on the merge,
 // only the speed does.
+#ifndef RSN_CHAIN_CSH
+#define RSN_CHAIN_CSH 9
+#endif
 template <int CT_, int CTH_, int CS_>
 struct ChainCfg {
     static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
-    static constexpr int CSH = 8;                           // a bucket's entries are ordered by staged offset >> CSH
+    static constexpr int CSH = RSN_CHAIN_CSH;               // a bucket's entries are ordered by staged offset >> CSH
     static constexpr int CH = 128;                          // warm-up positions before the tile
     static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
     static constexpr int OFFB = NS <= 8192 ? 13 : NS <= 16384 ? 14 : 15;   // bits of a staged offset in a list entry
@@ -928,21 +931,22 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     __syncthreads();
     // scatter in rounds of 2^CSH consecutive offsets with a barrier between them: inside a bucket the
     // entries end up ordered by offset >> CSH, which is all the window bisection below needs
+    // (bucket and entry are worked out by all threads at once, before the rounds: between two barriers only the atomic and the store)
     for (uint32_t base = 0; base < (uint32_t)NS; base += CTH) {
         const uint32_t rel = base + tid;
+        const bool in = rel >= rlo && rel < rhi;
+        const uint32_t b1 = sb[in ? rel + 1 : 0u];
+#ifdef RSN_CHAIN_PROBE_B2
+        const uint32_t h = probe_h(sb[in ? rel : 0u], b1, sb[in ? rel + 2 : 0u]), ent = (rel << C::TAGB) | (probe_tag(sb[in ? rel + 2 : 0u]) & TAGM);
+#else
+        const uint32_t h = ((uint32_t)sb[in ? rel : 0u] << 5) | (b1 & 31u), ent = (rel << C::TAGB) | ((b1 >> 5) & TAGM);
+#endif
+        const uint32_t sh = 16 * (h & 1);
 #pragma unroll
         for (int g = 0; g < (CTH >> CSH); g++) {
-            if ((tid >> CSH) == g && rel >= rlo && rel < rhi) {
-                const uint32_t b1 = sb[rel + 1];
-#ifdef RSN_CHAIN_PROBE_B2
-                const uint32_t h = probe_h(sb[rel], b1, sb[rel + 2]), sh = 16 * (h & 1);
+            if ((tid >> CSH) == g && in) {
                 const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
-                s_list[slot] = (uint16_t)((rel << C::TAGB) | (probe_tag(sb[rel + 2]) & TAGM));
-#else
-                const uint32_t h = ((uint32_t)sb[rel] << 5) | (b1 & 31u), sh = 16 * (h & 1);
-                const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
-                s_list[slot] = (uint16_t)((rel << C::TAGB) | ((b1 >> 5) & TAGM));
-#endif
+                s_list[slot] = (uint16_t)ent;
             }
             __syncthreads();
         }
@@ -2617,7 +2621,10 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     uint32_t *d_flags = d_entry + n_pt;
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
-    using CC = ChainCfg<8192, 1024, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
+#ifndef RSN_CHAIN_CTH
+#define RSN_CHAIN_CTH 1024
+#endif
+    using CC = ChainCfg<8192, RSN_CHAIN_CTH, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     // lanes per chain in k_match_chain: 8 or 16 = eight or four chains per wavefront, 64 = a wavefront per chain (RSN_LZSS_CHAIN_LANES, A/B)
     static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 || v == 4 ? v : 8; }();
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
