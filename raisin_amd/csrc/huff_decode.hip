@@ -34,7 +34,11 @@
 namespace rsn {
 
 
-constexpr int DB = 256;             // lanes per block
+#ifndef RSN_DEC_DB
+#define RSN_DEC_DB 256
+#endif
+constexpr int DB = RSN_DEC_DB;      // lanes per block
+constexpr int FDB = 256;            // lanes per block of k_dec_flat
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits; 128: emit 5 % faster, sync 40 % slower -- its warm-up is per subsequence)
 constexpr int SBITS = SW * 32;
 constexpr int ORG_WORDS = 8;              // words staged in front of the block: warm-up room for the entry guess
@@ -42,7 +46,7 @@ constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are of
 constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
 constexpr int LUT_BITS_MAX = 11;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
-constexpr int OUT_STAGE = 16384;    // bytes of block output staged in LDS (larger blocks store directly)
+constexpr int OUT_STAGE = DB * 64;  // bytes of block output staged in LDS (larger blocks store directly)
 constexpr int OUT_STAGE_RUNE = 40960; // the same for rune alphabets: a rune is up to four bytes (two blocks per CU instead of four, but coalesced stores)
 constexpr int CHILD_LDS = 256;      // child[] of a byte alphabet (<= 2 * 127 entries) is staged in LDS
 constexpr int LUT2_LDS = 768;       // second-level entries that fit in LDS (larger second levels are read through L2)
@@ -139,6 +143,13 @@ __device__ __forceinline__ uint32_t window32(const uint32_t *s_data, uint32_t po
     const uint32_t p = grp(pos >> 5);
     return __builtin_amdgcn_alignbit(s_data[p + 1], s_data[p], pos & 31);
 }
+// The same for a walk that stays inside ONE group of eight words (a lane inside its own subsequence, or inside the one before it
+// during the warm-up): there grp(w) = w + g with g the group's number, so a position that carries 32 g on top -- sp = pos + 32 g,
+// the same low five bits -- gives the dword address with one shift and one mask instead of grp()'s five instructions.
+__device__ __forceinline__ uint32_t window32_sp(const uint32_t *s_data, uint32_t sp) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(s_data) + ((sp >> 3) & ~3u));
+    return __builtin_amdgcn_alignbit(w[1], w[0], sp);                     // (v_alignbit_b32 shifts by the low five bits)
+}
 __device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) { return (s_data[grp(q >> 5)] >> (q & 31)) & 1; }
 // Index of the first-level table entry for a window (the lane's own copy of it when the table is replicated).
 __device__ __forceinline__ uint32_t lut_index(const DecArgs &a, uint32_t win, uint32_t lane_r) { return ((win & ((1u << a.K) - 1u)) << a.rep_log2) | lane_r; }
@@ -146,16 +157,23 @@ __device__ __forceinline__ uint32_t lut_index(const DecArgs &a, uint32_t win, ui
 // One codeword at `pos`: returns the rune and advances pos.  No state is carried between
 // symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
 // Table entries.  Rune alphabets:  len << 24 | rune, or a LONG entry when the code is longer than K bits.
-// Byte alphabets (unified):        sym1 | sym2 << 7 | sym3 << 14 | bits of all n << 21 | n << 25 | bits of the first << 27
-//                                  (n = 1..3 whole codewords inside the window), or a LONG entry.
+// Byte alphabets (unified):        sym1 | sym2 << 8 | sym3 << 16 | bits of all n << 24 | n << 28, n = 1..3 whole codewords inside
+//                                  the window, or a LONG entry.  The symbols are 7 bits wide and sit where the output bytes
+//                                  do (r04: e & 0x7F7F7F IS the three bytes -- six instructions of unpacking per lookup less
+//                                  in the writing walk); the bits of the FIRST codeword, which only the single steps at a
+//                                  subsequence's end read, are spread over what is left: bits 7, 15, 23 and 30.
 // LONG entry:                      0x80000000 | sb << 26 | x.  sb > 0: the next sb bits of the window index the
 //                                  2^sb-entry sub-table at lut2[x] (one more dependent lookup instead of one per bit);
 //                                  sb == 0: x is the tree node the K bits lead to, walked bit by bit.
 // Second-level entries:            len << 24 | rune (len counts all bits of the code), or 0x80000000 | node when the
 //                                  code is longer than K + sb bits still (the bit-by-bit walk goes on from there).
-__host__ __device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 21) & 15u; }
-__host__ __device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 25) & 3u; }
-__device__ __forceinline__ uint32_t u_len1(uint32_t e) { return (e >> 27) & 15u; }
+__host__ __device__ __forceinline__ uint32_t u_used(uint32_t e) { return (e >> 24) & 15u; }
+__host__ __device__ __forceinline__ uint32_t u_n(uint32_t e) { return (e >> 28) & 3u; }
+__host__ __device__ __forceinline__ uint32_t u_len1(uint32_t e) { return ((e >> 7) & 1u) | ((e >> 14) & 2u) | ((e >> 21) & 4u) | ((e >> 27) & 8u); }
+__host__ __device__ __forceinline__ uint32_t u_bytes(uint32_t e) { return e & 0x007F7F7Fu; }
+__host__ __device__ __forceinline__ uint32_t u_entry(uint32_t syms, uint32_t used, uint32_t n, uint32_t len1) {   // syms: sym1 | sym2 << 8 | sym3 << 16
+    return syms | (used << 24) | (n << 28) | ((len1 & 1u) << 7) | ((len1 & 2u) << 14) | ((len1 & 4u) << 21) | ((len1 & 8u) << 27);
+}
 
 struct Lut2 { const uint32_t *lds; bool in_lds; };   // where the second level is (uniform per launch)
 
@@ -194,50 +212,74 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t 
     return decode_long(a, s_data, win, ent, pos, l2);
 }
 
+template <bool ASCII, bool SHORT>
+__device__ __forceinline__ uint32_t decode_one_sp(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &sp, uint32_t spo, const Lut2 &l2) {
+    const uint32_t win = window32_sp(s_data, sp);
+    const uint32_t ent = s_lut[lut_index(a, win, lane_r)];
+    if (SHORT || !(ent & 0x80000000u)) {
+        if (ASCII) { sp += u_len1(ent); return ent & 0x7Fu; }
+        sp += ent >> 24;
+        return ent & 0x1FFFFFu;
+    }
+    uint32_t pos = sp - spo;
+    const uint32_t r = decode_long(a, s_data, win, ent, pos, l2);
+    sp = pos + spo;
+    return r;
+}
+
 // Walk from block-relative bit `pos` to the first code boundary >= lim.  A code that runs past
 // the end of the payload can only be the last one of the walk: checked once, after the loop.
 template <bool ASCII, bool SHORT, bool MULTI>
 __device__ __forceinline__ uint32_t advance(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, const Lut2 &l2,
-                                            uint32_t &pos, uint32_t lim) {
+                                            uint32_t &pos, uint32_t lim, uint32_t grp_no) {
+    // grp_no: the group of eight staged words every codeword of this walk STARTS in (positions [256 grp_no, 256 grp_no + 256) of the
+    // block image): the walk runs on sp = pos + 32 grp_no, see window32_sp
+    const uint32_t spo = 32u * grp_no, slim = lim + spo;
+    uint32_t sp = pos + spo;
     uint32_t nb = 0;
     if (ASCII && MULTI) {
         // up to 3 codewords per table lookup while a whole K-bit step stays inside the subsequence
-        const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
+        const uint32_t K = (uint32_t)a.K, safe = lim >= K ? slim - K : 0;
         // ... and two lookups per 32-bit window (r04): the first takes <= K <= 11 bits, so >= 21 bits of the window are left for the
         // second -- one window fetch (address arithmetic, an LDS round trip, the funnel shift) and one loop turn per two lookups
-        while (pos <= safe && lim >= K) {
-            const uint32_t win = window32(s_data, pos);
+        while (sp <= safe && lim >= K) {
+            const uint32_t win = window32_sp(s_data, sp);
             const uint32_t e = s_lut[lut_index(a, win, lane_r)];
-            if (!SHORT && (e & 0x80000000u)) { (void)decode_long(a, s_data, win, e, pos, l2); nb++; continue; }   // first code longer than K bits
+            if (!SHORT && (e & 0x80000000u)) { uint32_t q = sp - spo; (void)decode_long(a, s_data, win, e, q, l2); sp = q + spo; nb++; continue; }   // first code longer than K bits
             const uint32_t u1 = u_used(e);
-            pos += u1; nb += u_n(e);
-            if (pos <= safe) {
+            sp += u1; nb += u_n(e);
+            if (sp <= safe) {
                 const uint32_t e2 = s_lut[lut_index(a, win >> u1, lane_r)];
-                if (SHORT || !(e2 & 0x80000000u)) { pos += u_used(e2); nb += u_n(e2); }      // (a long code waits for the next turn's fresh window)
+                if (SHORT || !(e2 & 0x80000000u)) { sp += u_used(e2); nb += u_n(e2); }      // (a long code waits for the next turn's fresh window)
             }
         }
     }
-    while (pos < lim) {
-        const uint32_t r = decode_one<ASCII, SHORT>(a, s_data, s_lut, lane_r, pos, l2);
+    while (sp < slim) {
+        const uint32_t r = decode_one_sp<ASCII, SHORT>(a, s_data, s_lut, lane_r, sp, spo, l2);
         nb += ASCII ? 1 : dev_utf8_len(r);
     }
+    pos = sp - spo;
     return nb;
 }
 
 template <bool ASCII, bool SHORT, bool MULTI>
 __device__ __forceinline__ void walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, const Lut2 &l2,
-                                     uint32_t pos, uint32_t lim, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
-    *nbytes = advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, pos, lim);
+                                     uint32_t pos, uint32_t lim, uint32_t grp_no, uint32_t end_rel, uint32_t *exit_pos, uint32_t *nbytes) {
+    *nbytes = advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, pos, lim, grp_no);
     *exit_pos = pos > end_rel ? BAD_POS : pos;
 }
 
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
-    __shared__ uint32_t s_data[DATA_PHYS];
+    __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
     __shared__ uint32_t s_lut[LUT_WORDS];
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
+#ifdef RSN_DEC_LDS_PAD
+    __shared__ uint32_t s_padding[RSN_DEC_LDS_PAD / 4];
+    if (a.n_sub == 0xFFFFFFFFu) s_padding[threadIdx.x] = 1;   // (occupancy probe: keeps the array alive)
+#endif
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
     const int tid = threadIdx.x;
@@ -289,7 +331,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
                 // codewords, so the first boundary at or after my0 is very likely the true entry
                 const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
                 uint32_t q = start;
-                (void)advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, q, my0);   // (several codewords per lookup here too)
+                (void)advance<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, q, my0, (uint32_t)tid);   // (several codewords per lookup here too; the group before the lane's own)
                 e = q;
             }
         } else {
@@ -311,7 +353,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         for (int round = 0; round <= DB; round++) {
             if (live && !have) {
                 if (e == BAD_POS) { x = BAD_POS; nb = 0; }
-                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, e, lim, end_rel, &x, &nb);
+                else walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, e, lim, (uint32_t)tid + 1u, end_rel, &x, &nb);
                 have = true;
             }
             s_exit[tid] = x;
@@ -338,7 +380,9 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
         if ((tid & 63) == 0) s_part[tid >> 6] = sum;
         __syncthreads();
         if (tid == 0) {
-            a.blk_bytes[blk] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            unsigned long long all = 0;
+            for (int k = 0; k < DB / 64; k++) all += s_part[k];
+            a.blk_bytes[blk] = all;
         }
     }
 }
@@ -379,13 +423,17 @@ __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_da
 
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
-    __shared__ uint32_t s_data[DATA_PHYS];
+    __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
     __shared__ uint32_t s_lut[LUT_WORDS];
     constexpr int STAGE = ASCII ? OUT_STAGE : OUT_STAGE_RUNE;
     __shared__ __attribute__((aligned(16))) uint8_t s_out[STAGE + 32];
     __shared__ uint32_t s_wsum[DB / 64];
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
+#ifdef RSN_DEC_LDS_PAD
+    __shared__ uint32_t s_padding[RSN_DEC_LDS_PAD / 4];
+    if (a.n_sub == 0xFFFFFFFFu) s_padding[threadIdx.x] = 1;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
@@ -422,15 +470,16 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
             if (live && er != BAD_REL && nb != 0) {
                 const uint32_t o0 = al + my_off;
                 uint32_t *o = reinterpret_cast<uint32_t *>(s_out) + (o0 >> 2);
-                uint32_t cnt = o0 & 3, remaining = nb, pos = my0 + er;
+                const uint32_t spo = 32u * ((uint32_t)tid + 1u);           // every codeword the lane owes starts inside its own group: see window32_sp
+                uint32_t cnt = o0 & 3, remaining = nb, pos = my0 + er + spo;
                 unsigned long long acc = 0;
                 while (remaining) {
-                    const uint32_t win = window32(s_data, pos);
+                    const uint32_t win = window32_sp(s_data, pos);
                     const uint32_t e = s_lut[lut_index(a, win, lane_r)];
                     uint32_t bytes, take, used;
-                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q - pos; }
+                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos - spo; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q + spo - pos; }
                     else {
-                        bytes = (e & 0x7Fu) | ((e << 1) & 0x7F00u) | ((e << 2) & 0x7F0000u);
+                        bytes = u_bytes(e);
                         take = min(u_n(e), remaining);                    // (the last lookup may list more codewords than the lane owes:
                         used = u_used(e);                                 //  whatever lies above `cnt` bytes is masked off at the end, pos is dead by then)
                     }
@@ -441,7 +490,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                     if (used <= (uint32_t)LUT_BITS_MAX && remaining) {
                         const uint32_t e2 = s_lut[lut_index(a, win >> used, lane_r)];
                         if (SHORT || !(e2 & 0x80000000u)) {
-                            const uint32_t b2 = (e2 & 0x7Fu) | ((e2 << 1) & 0x7F00u) | ((e2 << 2) & 0x7F0000u);
+                            const uint32_t b2 = u_bytes(e2);
                             const uint32_t t2 = min(u_n(e2), remaining);
                             acc |= (unsigned long long)b2 << (8 * cnt);   // (remaining != 0: the first lookup was taken whole, acc holds nothing above cnt)
                             cnt += t2; remaining -= t2; pos += u_used(e2);
@@ -511,7 +560,7 @@ __device__ __forceinline__ uint32_t slot_walk(const DecArgs &a, const uint32_t *
         const uint32_t e = s_lut[lut_index(a, win, lane_r)];
         uint32_t bytes, take;
         if (!SHORT && (e & 0x80000000u)) { bytes = decode_long(a, s_data, win, e, pos, l2); take = 1; }
-        else { bytes = (e & 0x7Fu) | ((e << 1) & 0x7F00u) | ((e << 2) & 0x7F0000u); take = u_n(e); pos += u_used(e); }
+        else { bytes = u_bytes(e); take = u_n(e); pos += u_used(e); }
         acc |= (unsigned long long)bytes << (8 * cnt);
         cnt += take; nb += take;
         if (cnt >= 4) { *slot++ = (uint32_t)acc; acc >>= 32; cnt -= 4; }
@@ -529,7 +578,7 @@ __device__ __forceinline__ uint32_t slot_walk(const DecArgs &a, const uint32_t *
 template <bool SHORT>
 __global__ __launch_bounds__(DB) void k_dec_fused(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_slots[];   // DB * slotw words (+ 8): the lanes' slots, then the output image
-    __shared__ uint32_t s_data[DATA_PHYS];
+    __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
     __shared__ uint32_t s_lut[LUT_WORDS];
     __shared__ uint32_t s_exit[DB];
     __shared__ uint32_t s_wsum[DB / 64];
@@ -570,7 +619,7 @@ __global__ __launch_bounds__(DB) void k_dec_fused(DecArgs a) {
         else {
             const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
             uint32_t q = start;
-            (void)advance<true, SHORT, true>(a, s_data, s_lut, lane_r, l2, q, my0);
+            (void)advance<true, SHORT, true>(a, s_data, s_lut, lane_r, l2, q, my0, (uint32_t)tid);
             e = q;
         }
         bool have = false;
@@ -701,18 +750,18 @@ struct FlatArgs {
     uint8_t lut[128];            // 2^L bytes: field value -> symbol.  In the kernel-argument segment: no upload, no extra stream op
 };
 constexpr int FLAT_LANE_SYMS = 32;
-constexpr int FLAT_SYMS = DB * FLAT_LANE_SYMS;                  // symbols per block
+constexpr int FLAT_SYMS = FDB * FLAT_LANE_SYMS;                  // symbols per block
 
 template <int L>
-__global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
-    constexpr int WORDS = DB * L + 2;
+__global__ __launch_bounds__(FDB) void k_dec_flat(FlatArgs a) {
+    constexpr int WORDS = FDB * L + 2;
     constexpr int RL = 5;                                       // 32 dword copies per entry: the copy index IS the bank
     __shared__ uint32_t s_data[WORDS + WORDS / 32 + 2];
     __shared__ uint32_t s_lut[(1 << L) << RL];
     const int tid = threadIdx.x;
     {   // the table is read through the kernel-argument segment pointer: indexing the by-value copy would spill it to scratch
         const uint8_t *lut = (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FlatArgs, lut);
-        for (int i = tid; i < ((1 << L) << RL); i += DB) s_lut[i] = lut[i >> RL];
+        for (int i = tid; i < ((1 << L) << RL); i += FDB) s_lut[i] = lut[i >> RL];
     }
     const uint32_t n_chunks = (uint32_t)((a.n_sym + FLAT_SYMS - 1) / FLAT_SYMS);
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {   // persistent: the table is staged once
@@ -722,14 +771,14 @@ __global__ __launch_bounds__(DB) void k_dec_flat(FlatArgs a) {
     const uint32_t o0 = (uint32_t)(bit0 & 31);
     if ((w0 + WORDS) * 4 <= a.nbytes) {                         // interior block: branch-free, loads issued together
         const uint32_t *src = reinterpret_cast<const uint32_t *>(a.base) + w0;
-        constexpr int PER = (WORDS + DB - 1) / DB;
+        constexpr int PER = (WORDS + FDB - 1) / FDB;
         uint32_t v[PER];
 #pragma unroll
-        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) v[k] = ld4<(RSN_NT_MASK & 8) != 0>(src + i); }
+        for (int k = 0; k < PER; k++) { const int i = tid + k * FDB; if (i < WORDS) v[k] = ld4<(RSN_NT_MASK & 8) != 0>(src + i); }
 #pragma unroll
-        for (int k = 0; k < PER; k++) { const int i = tid + k * DB; if (i < WORDS) s_data[swz(i)] = __builtin_bswap32(v[k]); }
+        for (int k = 0; k < PER; k++) { const int i = tid + k * FDB; if (i < WORDS) s_data[swz(i)] = __builtin_bswap32(v[k]); }
     } else {
-        for (int i = tid; i < WORDS; i += DB) {
+        for (int i = tid; i < WORDS; i += FDB) {
             const size_t off = (w0 + i) * 4;
             uint32_t v = 0;
             if (off + 4 <= a.nbytes) v = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.base + off));
@@ -978,7 +1027,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         for (uint32_t i = 0; i < tree.n_leaves; i++) fa.lut[codes.code[i]] = (uint8_t)tree.rune[i];
         const dim3 grid((uint32_t)std::min<size_t>(ceil_div((size_t)n_sym, FLAT_SYMS), 256 * 8));
         switch (L) {
-#define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(DB), 0, s, fa); break;
+#define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(FDB), 0, s, fa); break;
             RSN_FLAT_CASE(1) RSN_FLAT_CASE(2) RSN_FLAT_CASE(3) RSN_FLAT_CASE(4) RSN_FLAT_CASE(5) RSN_FLAT_CASE(6)
             RSN_FLAT_CASE(7)   // ASCII alphabets hold at most 2^7 symbols
 #undef RSN_FLAT_CASE
@@ -1013,11 +1062,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
                 uint32_t q = used;
                 while (!tree.is_leaf(node) && q < (uint32_t)K) { node = ((v >> (K - 1 - q)) & 1) ? tree.right[node] : tree.left[node]; q++; }
                 if (!tree.is_leaf(node)) break;                                   // ran out of bits inside a codeword
-                syms |= (tree.rune[node] & 0x7Fu) << (7 * nsym);
+                syms |= (tree.rune[node] & 0x7Fu) << (8 * nsym);
                 if (nsym == 0) len1 = q;
                 used = q; nsym++;
             }
-            lut[v] = syms | (used << 21) | (nsym << 25) | (len1 << 27);           // nsym >= 1 here: the first codeword fits
+            lut[v] = u_entry(syms, used, nsym, len1);                             // nsym >= 1 here: the first codeword fits
         }
     }
     if (!prebuilt && !short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
