@@ -153,6 +153,11 @@ __device__ __forceinline__ uint32_t window32_sp(const uint32_t *s_data, uint32_t
 __device__ __forceinline__ uint32_t bit_at(const uint32_t *s_data, uint32_t q) { return (s_data[grp(q >> 5)] >> (q & 31)) & 1; }
 // Index of the first-level table entry for a window (the lane's own copy of it when the table is replicated).
 __device__ __forceinline__ uint32_t lut_index(const DecArgs &a, uint32_t win, uint32_t lane_r) { return ((win & ((1u << a.K) - 1u)) << a.rep_log2) | lane_r; }
+// The entry itself, addressed in BYTES (index and copy number shifted once: an AND and a shift-OR per lookup, not three instructions).
+__device__ __forceinline__ uint32_t lut_at(const DecArgs &a, const uint32_t *s_lut, uint32_t win, uint32_t lane_r) {
+    const uint32_t off = ((win & ((1u << a.K) - 1u)) << (a.rep_log2 + 2)) | (lane_r << 2);
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(s_lut) + off);
+}
 
 // One codeword at `pos`: returns the rune and advances pos.  No state is carried between
 // symbols, so the loop has no refill branch: a wavefront never diverges inside a step.
@@ -203,7 +208,7 @@ __device__ __forceinline__ uint32_t decode_long(const DecArgs &a, const uint32_t
 template <bool ASCII, bool SHORT>
 __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &pos, const Lut2 &l2) {
     const uint32_t win = window32(s_data, pos);
-    const uint32_t ent = s_lut[lut_index(a, win, lane_r)];
+    const uint32_t ent = lut_at(a, s_lut, win, lane_r);
     if (SHORT || !(ent & 0x80000000u)) {
         if (ASCII) { pos += u_len1(ent); return ent & 0x7Fu; }
         pos += ent >> 24;
@@ -215,7 +220,7 @@ __device__ __forceinline__ uint32_t decode_one(const DecArgs &a, const uint32_t 
 template <bool ASCII, bool SHORT>
 __device__ __forceinline__ uint32_t decode_one_sp(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, uint32_t &sp, uint32_t spo, const Lut2 &l2) {
     const uint32_t win = window32_sp(s_data, sp);
-    const uint32_t ent = s_lut[lut_index(a, win, lane_r)];
+    const uint32_t ent = lut_at(a, s_lut, win, lane_r);
     if (SHORT || !(ent & 0x80000000u)) {
         if (ASCII) { sp += u_len1(ent); return ent & 0x7Fu; }
         sp += ent >> 24;
@@ -244,12 +249,12 @@ __device__ __forceinline__ uint32_t advance(const DecArgs &a, const uint32_t *s_
         // second -- one window fetch (address arithmetic, an LDS round trip, the funnel shift) and one loop turn per two lookups
         while (sp <= safe && lim >= K) {
             const uint32_t win = window32_sp(s_data, sp);
-            const uint32_t e = s_lut[lut_index(a, win, lane_r)];
+            const uint32_t e = lut_at(a, s_lut, win, lane_r);
             if (!SHORT && (e & 0x80000000u)) { uint32_t q = sp - spo; (void)decode_long(a, s_data, win, e, q, l2); sp = q + spo; nb++; continue; }   // first code longer than K bits
             const uint32_t u1 = u_used(e);
             sp += u1; nb += u_n(e);
             if (sp <= safe) {
-                const uint32_t e2 = s_lut[lut_index(a, win >> u1, lane_r)];
+                const uint32_t e2 = lut_at(a, s_lut, win >> u1, lane_r);
                 if (SHORT || !(e2 & 0x80000000u)) { sp += u_used(e2); nb += u_n(e2); }      // (a long code waits for the next turn's fresh window)
             }
         }
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                 unsigned long long acc = 0;
                 while (remaining) {
                     const uint32_t win = window32_sp(s_data, pos);
-                    const uint32_t e = s_lut[lut_index(a, win, lane_r)];
+                    const uint32_t e = lut_at(a, s_lut, win, lane_r);
                     uint32_t bytes, take, used;
                     if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos - spo; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q + spo - pos; }
                     else {
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                     if (cnt >= 4) { atomicOr(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
                     // the second lookup out of the same window (r04): `used` <= 11 bits are gone, >= 21 are left
                     if (used <= (uint32_t)LUT_BITS_MAX && remaining) {
-                        const uint32_t e2 = s_lut[lut_index(a, win >> used, lane_r)];
+                        const uint32_t e2 = lut_at(a, s_lut, win >> used, lane_r);
                         if (SHORT || !(e2 & 0x80000000u)) {
                             const uint32_t b2 = u_bytes(e2);
                             const uint32_t t2 = min(u_n(e2), remaining);
@@ -557,7 +562,7 @@ __device__ __forceinline__ uint32_t slot_walk(const DecArgs &a, const uint32_t *
     const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
     while (pos <= safe && lim >= K) {                             // a whole K-bit window inside the subsequence: up to three codewords
         const uint32_t win = window32(s_data, pos);
-        const uint32_t e = s_lut[lut_index(a, win, lane_r)];
+        const uint32_t e = lut_at(a, s_lut, win, lane_r);
         uint32_t bytes, take;
         if (!SHORT && (e & 0x80000000u)) { bytes = decode_long(a, s_data, win, e, pos, l2); take = 1; }
         else { bytes = u_bytes(e); take = u_n(e); pos += u_used(e); }
@@ -1189,6 +1194,9 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     Tail *ht = (Tail *)hp;
     auto launch_emit = [&]() -> int {
         // (8-byte table entries with the symbols already spread to bytes measured slower than unpacking the 4-byte ones: 1.19 vs 0.98 ms)
+        // (r04: a lookup's bytes as ONE four-byte LDS store at the lane's byte offset instead of the 64-bit collector and the ORs -- gfx950
+        //  takes dword stores at any address, scripts/probes/lds_unaligned.cpp, and the walk drops from 46 to 25 vector instructions a turn --
+        //  measured 1.40 against 0.80 ms: the LDS serialises a wavefront's unaligned stores.)
         // (This kernel scales almost linearly with blocks per CU up to the four its LDS allows.  Without the LDS output stage --
         //  a lane's dwords straight to memory -- seven blocks fit, but the scattered partial-line stores cost more than that
         //  buys: 1.66 vs 0.96 ms.)
