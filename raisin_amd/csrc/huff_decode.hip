@@ -44,7 +44,10 @@ constexpr int SBITS = SW * 32;
 constexpr int ORG_WORDS = 8;              // words staged in front of the block: warm-up room for the entry guess
 constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are offset by this
 constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
-constexpr int LUT_BITS_MAX = 11;
+#ifndef RSN_LUT_BITS
+#define RSN_LUT_BITS 11
+#endif
+constexpr int LUT_BITS_MAX = RSN_LUT_BITS;
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int OUT_STAGE = DB * 64;  // bytes of block output staged in LDS (larger blocks store directly)
 constexpr int OUT_STAGE_RUNE = 40960; // the same for rune alphabets: a rune is up to four bytes (two blocks per CU instead of four, but coalesced stores)
@@ -426,6 +429,12 @@ __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_da
     }
 }
 
+// TIMING PROBE (-DRSN_EMIT_PROBE_PLAIN, wrong output): plain stores instead of the ORs -- what the LDS atomics cost the walk
+#ifdef RSN_EMIT_PROBE_PLAIN
+#define RSN_EMIT_WORD(p, v) (*(p) = (v))
+#else
+#define RSN_EMIT_WORD(p, v) atomicOr((p), (v))
+#endif
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                     }
                     acc |= (unsigned long long)bytes << (8 * cnt);
                     cnt += take; remaining -= take; pos += used;
-                    if (cnt >= 4) { atomicOr(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
+                    if (cnt >= 4) { RSN_EMIT_WORD(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
                     // the second lookup out of the same window (r04): `used` <= 11 bits are gone, >= 21 are left
                     if (used <= (uint32_t)LUT_BITS_MAX && remaining) {
                         const uint32_t e2 = lut_at(a, s_lut, win >> used, lane_r);
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                             const uint32_t t2 = min(u_n(e2), remaining);
                             acc |= (unsigned long long)b2 << (8 * cnt);   // (remaining != 0: the first lookup was taken whole, acc holds nothing above cnt)
                             cnt += t2; remaining -= t2; pos += u_used(e2);
-                            if (cnt >= 4) { atomicOr(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
+                            if (cnt >= 4) { RSN_EMIT_WORD(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
                         }
                     }
                 }

@@ -1006,11 +1006,11 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
 
 // ------------------------------------------------------------------ L4: unescape
 // Every lane takes its 16 bytes with one load; the 5C bytes become a 16-bit mask.
-__device__ __forceinline__ uint32_t load16_esc(const uint8_t *__restrict__ esc, uint32_t E, uint32_t s, uint32_t w[4]) {
+__device__ __forceinline__ uint32_t load16_esc(const uint8_t *__restrict__ esc, size_t E, size_t s, uint32_t w[4]) {
     w[0] = w[1] = w[2] = w[3] = 0;
     if (s + 16 <= E) { const uint4 v = *reinterpret_cast<const uint4 *>(esc + s); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; return 16; }
     if (s >= E) return 0;
-    const uint32_t len = E - s;
+    const uint32_t len = (uint32_t)(E - s);
     for (uint32_t k = 0; k < len; k++) w[k >> 2] |= (uint32_t)esc[s + k] << (8 * (k & 3));
     return len;
 }
@@ -1024,18 +1024,18 @@ __device__ __forceinline__ uint32_t run_summary(uint32_t m, uint32_t len) {
 }
 
 // per-block summary: is the whole block 5C, and the parity of its trailing 5C run
-__global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ esc, uint32_t E, uint8_t *__restrict__ summ) {
+__global__ __launch_bounds__(ZB) void k_une_summary(const uint8_t *__restrict__ esc, size_t E, uint8_t *__restrict__ summ) {
     __shared__ uint32_t s_last;          // highest index in the block that is not 5C, +1 (0 = none)
     if (threadIdx.x == 0) s_last = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * ZTILE;
+    const size_t base = (size_t)blockIdx.x * ZTILE;                        // (escaped streams of 4 GiB and more: r04)
     uint32_t w[4];
     const uint32_t len = load16_esc(esc, E, base + threadIdx.x * 16, w);
     const uint32_t non = ~mask_5c(w) & (len >= 16 ? 0xFFFFu : ((1u << len) - 1u));
     if (non) atomicMax(&s_last, threadIdx.x * 16 + 32u - (uint32_t)__builtin_clz(non));
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t blen = min((uint32_t)ZTILE, E - base);
+        const uint32_t blen = (uint32_t)min((size_t)ZTILE, E - base);
         summ[blockIdx.x] = (uint8_t)((s_last == 0 ? 2 : 0) | ((blen - s_last) & 1));   // bit1: all 5C; bit0: trailing-run parity
     }
 }
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(1024) void k_une_carry(const uint8_t *__restrict__ 
 }
 
 // shared front end of count/write: loads the lane's bytes and returns the escape state at their start
-__device__ __forceinline__ uint32_t lane_in_parity(const uint8_t *__restrict__ esc, uint32_t E, uint32_t base, uint32_t blk_par, uint8_t *s_sum,
+__device__ __forceinline__ uint32_t lane_in_parity(const uint8_t *__restrict__ esc, size_t E, size_t base, uint32_t blk_par, uint8_t *s_sum,
                                                    uint32_t w[4], uint32_t *len) {
     const int tid = threadIdx.x;
     *len = load16_esc(esc, E, base + tid * 16, w);
@@ -1100,12 +1100,12 @@ __device__ __forceinline__ uint32_t lane_in_parity(const uint8_t *__restrict__ e
     return par;
 }
 
-__global__ __launch_bounds__(ZB) void k_une_count(const uint8_t *__restrict__ esc, uint32_t E, const uint8_t *__restrict__ in_par,
+__global__ __launch_bounds__(ZB) void k_une_count(const uint8_t *__restrict__ esc, size_t E, const uint8_t *__restrict__ in_par,
                                                   unsigned long long *__restrict__ blk_len) {
     __shared__ uint8_t s_sum[ZB];
     __shared__ uint32_t part[ZB / 64];
     uint32_t w[4], len;
-    uint32_t st = lane_in_parity(esc, E, blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
+    uint32_t st = lane_in_parity(esc, E, (size_t)blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
     uint32_t cnt = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
@@ -1126,14 +1126,14 @@ __device__ __forceinline__ uint32_t une_bytes_equal(uint32_t w, uint32_t c) {
 }
 
 // the block's output is contiguous: bytes go to LDS first, then out in 16-byte units
-__global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ esc, uint32_t E, const uint8_t *__restrict__ in_par,
+__global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ esc, size_t E, const uint8_t *__restrict__ in_par,
                                                   const unsigned long long *__restrict__ blk_off, uint8_t *__restrict__ out) {
     __shared__ uint8_t s_sum[ZB];
     __shared__ uint32_t wsum[ZB / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_out[ZTILE / 4 + 8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t w[4], len;
-    const uint32_t st0 = lane_in_parity(esc, E, blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
+    const uint32_t st0 = lane_in_parity(esc, E, (size_t)blockIdx.x * ZTILE, in_par[blockIdx.x], s_sum, w, &len);
     uint32_t st = st0, cnt = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
@@ -1185,10 +1185,44 @@ __global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ es
 }
 
 // ======================================================================= host side
-int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+namespace {
+
+// L4 over an escaped stream of any length: d_esc[0, E) -> d_out.  have_summ: the per-block summaries are in place already (the tile
+// path's emit kernel writes them on its way out).  Scratch slot 16.
+int lzss_unescape(Ctx &c, hipStream_t s, const uint8_t *d_esc, size_t E, bool have_summ, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    void *p; int rc;
+    if (ceil_div(E, (size_t)ZTILE) > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
+    const uint32_t n_ub = (uint32_t)ceil_div(E, (size_t)ZTILE);          // unescape blocks
+    rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)round_up(n_ub, 16) * 2 + 64, &p); if (rc) return rc;
+    unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
+    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + round_up(n_ub, 16);   // both 16-byte aligned
+    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    unsigned long long *h64 = (unsigned long long *)hp;
+    if (!have_summ) RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);
+    RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(1024), 0, s, (const uint8_t *)d_summ, n_ub, d_inpar);
+    RSN_LAUNCH("lzss_une_count", k_une_count, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, (const uint8_t *)d_inpar, d_ulen);
+    rc = scan_u64(c, s, "lzss_dec_scan", d_ulen, d_uoff, n_ub, d_utot); if (rc) return rc;
+    RSN_HIP(hipMemcpyAsync(h64, d_utot, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    const size_t total = (size_t)h64[0];
+    *out_n = total;
+    if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
+    RSN_LAUNCH("lzss_une_write", k_une_write, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, (const uint8_t *)d_inpar, (const unsigned long long *)d_uoff, d_out);
+    RSN_HIP(hipStreamSynchronize(s));
+    return RSN_OK;
+}
+
+int lzss_decode_sections(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
+
+// One stream of less than 4 GiB, compressed and decoded.  esc_dst == nullptr: the decoder proper (-> d_out).  Otherwise only the token
+// expansion (L1 .. L3): the ESCAPED stream goes to esc_dst (16-byte aligned, room for the whole of it plus 64 bytes: the caller knows
+// its length from its own counting pass) and *out_n is that length -- what lzss_decode_sections runs per section.
+int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, uint8_t *esc_dst) {
     *out_n = 0;
     if (n == 0) return RSN_OK;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "lzss: device buffers must be 16-byte aligned");
+    static const size_t sec_env = [] { const char *e = getenv("RSN_LZSS_DEC_SECTION_MIB"); return e ? (size_t)std::max(atoi(e), 1) << 20 : (size_t)0; }();   // testing switch: sections on small streams
+    if (!esc_dst && (n >= (1ull << 32) - 65536 || (sec_env && n > sec_env / 2))) return lzss_decode_sections(c, s, d_in, n, d_out, out_cap, out_n);
     if (n >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: compressed input too large for one call");
     void *p; int rc;
     const uint32_t n_cb = (uint32_t)ceil_div(n, ZTILE);
@@ -1212,22 +1246,24 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     RSN_HIP(hipStreamSynchronize(s));
     if (hflag[0] & 1) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
     if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
-    if (h64[0] >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
+    if (h64[0] >= (1ull << 32) - 65536 || (sec_env && !esc_dst && h64[0] > sec_env)) {
+        if (esc_dst) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
+        return lzss_decode_sections(c, s, d_in, n, d_out, out_cap, out_n);   // (counts again: a stream of 4 GiB does not notice)
+    }
     const bool one_pass = !three_pass && hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
-    if (!d_out) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens
+    if (!d_out && !esc_dst) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens
         *out_n = round_up((size_t)E, 16) + 16;
         return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %u bytes", E);
     }
     static const bool no_plain = getenv("RSN_LZSS_DEC_UNESCAPE") != nullptr;   // A/B switch: always the separate unescape passes
-    const bool plain = hflag[4] == 0 && !no_plain;                      // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
-    rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc;
-    uint8_t *d_esc = (uint8_t *)p;
+    const bool plain = hflag[4] == 0 && !no_plain && !esc_dst;          // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
+    uint8_t *d_esc = esc_dst;
+    if (!d_esc) { rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc; d_esc = (uint8_t *)p; }
     const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);                 // unescape blocks
     rc = dev_buf(c, 16, ((size_t)n_ub * 2 + 2) * 8 + (size_t)round_up(n_ub, 16) * 2 + 64, &p); if (rc) return rc;
-    unsigned long long *d_ulen = (unsigned long long *)p, *d_uoff = d_ulen + n_ub, *d_utot = d_uoff + n_ub;
-    uint8_t *d_summ = (uint8_t *)(d_utot + 2), *d_inpar = d_summ + round_up(n_ub, 16);   // both 16-byte aligned
+    uint8_t *d_summ = (uint8_t *)((unsigned long long *)p + (size_t)n_ub * 2 + 2);   // (lzss_unescape's layout of slot 16: k_lzd_emit leaves the block summaries where it looks for them)
     // ---- L2
     const uint32_t n_tiles = (uint32_t)ceil_div(E, DT), dgrp = group_tiles(n_tiles), n_groups = (uint32_t)ceil_div(n_tiles, dgrp);
     rc = dev_buf(c, 19, (size_t)n_tiles * 8 + 64, &p); if (rc) return rc;
@@ -1335,19 +1371,105 @@ int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         }
         RSN_LAUNCH("lzss_dec_gather", k_lzd_gather, dim3(grid), dim3(ZB), 0, s, d_src, d_esc, E);
     }
-    // ---- unescape
-    if (!tile_path) RSN_LAUNCH("lzss_une_summary", k_une_summary, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_summ);   // the tile path's emit kernel wrote them
-    RSN_LAUNCH("lzss_une_carry", k_une_carry, dim3(1), dim3(1024), 0, s, d_summ, n_ub, d_inpar);
-    RSN_LAUNCH("lzss_une_count", k_une_count, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_inpar, d_ulen);
-    rc = scan_u64(c, s, "lzss_dec_scan", d_ulen, d_uoff, n_ub, d_utot); if (rc) return rc;
-    RSN_HIP(hipMemcpyAsync(h64, d_utot, 8, hipMemcpyDeviceToHost, s));
-    RSN_HIP(hipStreamSynchronize(s));
-    const size_t total = (size_t)h64[0];
-    *out_n = total;
-    if (!d_out || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
-    RSN_LAUNCH("lzss_une_write", k_une_write, dim3(n_ub), dim3(ZB), 0, s, d_esc, E, d_inpar, d_uoff, d_out);
-    RSN_HIP(hipStreamSynchronize(s));
-    return RSN_OK;
+    if (esc_dst) { RSN_HIP(hipStreamSynchronize(s)); *out_n = E; return RSN_OK; }
+    // ---- unescape (the tile path's emit kernel has left the block summaries in slot 16, where lzss_unescape expects them)
+    return lzss_unescape(c, s, d_esc, (size_t)E, tile_path, d_out, out_cap, out_n);
+}
+
+// ---------------------------------------------------------------- streams of 4 GiB and more (r04), compressed or decoded
+// The tile kernels count positions in 32 bits, so a long stream is expanded SECTION BY SECTION: the counting pass over the whole
+// stream gives every 4 KiB block of the compressed stream its offset in the escaped one; cuts are taken at block starts (moved past
+// a token that straddles one) so that a section holds at most 1 GiB on either side; and a section is decoded as a stream of its own
+// that BEGINS WITH THE ESCAPED BYTES BEFORE IT, as many as the largest back-pointer of the stream reaches (the escaped stream holds
+// no '<' -- lzss.go:373-377 -- so those bytes parse as literals and every pointer of the section finds what it points at).  The
+// expansion of that virtual stream is written over the place it came from: the prefix lands on itself, the section behind it.
+// Unescaping then runs once over the whole escaped stream (its kernels count blocks, not bytes).
+int lzss_decode_sections(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    static const size_t sec_env = [] { const char *e = getenv("RSN_LZSS_DEC_SECTION_MIB"); return e ? (size_t)std::max(atoi(e), 1) << 20 : (size_t)0; }();
+    const size_t SEC = sec_env ? sec_env : (size_t)1 << 30;
+    static const bool dbg = getenv("RSN_DEBUG") != nullptr;
+    void *p; int rc;
+    if (ceil_div(n, (size_t)ZTILE) > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "lzss: compressed input too large for one call");
+    const uint32_t n_cb = (uint32_t)ceil_div(n, (size_t)ZTILE);
+    std::vector<unsigned long long> boff((size_t)n_cb + 1);
+    int hflag[6];
+    {   // the counting pass over the whole stream (its per-span outputs are not kept: every section counts its own)
+        rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 4) * 8, &p); if (rc) return rc;
+        unsigned long long *d_blen = (unsigned long long *)p, *d_boff = d_blen + n_cb, *d_btot = d_boff + n_cb;
+        int *d_flag = (int *)(d_btot + 1);
+        RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));
+        rc = dev_buf(c, 27, (size_t)n_cb * ZB * 2 + (size_t)n_cb * 8 + 64, &p); if (rc) return rc;
+        unsigned long long *d_need = (unsigned long long *)p; uint16_t *d_span = (uint16_t *)(d_need + n_cb);
+        RSN_LAUNCH("lzss_dec_count", k_lzd_count2, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_span, d_need, (uint32_t *)(d_flag + 2), d_flag);
+        rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
+        RSN_LAUNCH("lzss_dec_tiles", k_lzd_check, dim3((uint32_t)ceil_div(n_cb, 256)), dim3(256), 0, s, (const unsigned long long *)d_need, (const unsigned long long *)d_boff, n_cb, d_flag);
+        RSN_HIP(hipMemcpyAsync(boff.data(), d_boff, (size_t)n_cb * 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipMemcpyAsync(&boff[n_cb], d_btot, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipMemcpyAsync(hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+    }
+    if (hflag[0] & 1) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
+    if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+    const size_t E = (size_t)boff[n_cb];
+    const size_t hmax = (size_t)(uint32_t)hflag[2];                       // the largest back-pointer of a token that produces anything
+    if (E == 0) return RSN_OK;
+    if (!d_out) { *out_n = round_up(E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %zu bytes", E); }
+    if (hmax + 16 > SEC && hmax + 16 > ((size_t)1 << 30)) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 4 GiB and more with back-pointers beyond 1 GiB");
+    rc = dev_buf(c, 15, E + 64, &p); if (rc) return rc;
+    uint8_t *d_esc = (uint8_t *)p;
+    // the first item that STARTS at or after compressed position q (a block start): the tokens are known to be well-formed
+    auto item_start = [&](size_t q, size_t *out) -> int {
+        if (q == 0 || q >= n) { *out = std::min(q, n); return RSN_OK; }
+        uint8_t buf[2 * MAXTOK];
+        const size_t lo = q >= (size_t)MAXTOK ? q - MAXTOK : 0, hi = std::min(n, q + MAXTOK);
+        RSN_HIP(hipMemcpyAsync(buf, d_in + lo, hi - lo, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        *out = q;
+        for (size_t k = q; k-- > lo;) {                                   // the last '<' or '>' before q
+            if (buf[k - lo] == '>') break;
+            if (buf[k - lo] == '<') {                                     // q lies inside this token: the item after it
+                size_t e = k + 1;
+                while (e < hi && buf[e - lo] != '>') e++;
+                if (e >= hi) return c.fail(RSN_ERR_DEVICE, "lzss: a token without its end at a section cut");
+                *out = std::max(q, e + 1);
+                break;
+            }
+        }
+        return RSN_OK;
+    };
+    size_t sec_buf = 0;
+    uint8_t *d_v = nullptr;
+    uint32_t b0 = 0;
+    size_t c0 = 0;
+    int n_sec = 0;
+    while (b0 < n_cb) {
+        // the section's last block: at most SEC escaped bytes and SEC compressed bytes (one block at least)
+        uint32_t lo_b = b0 + 1, hi_b = (uint32_t)std::min<size_t>(n_cb, (size_t)b0 + std::max<size_t>(SEC / ZTILE, 1));
+        while (lo_b < hi_b) { const uint32_t mid = lo_b + (hi_b - lo_b + 1) / 2; if (boff[mid] - boff[b0] <= SEC) lo_b = mid; else hi_b = mid - 1; }
+        const uint32_t b1 = lo_b;
+        size_t c1; rc = item_start((size_t)b1 * ZTILE, &c1); if (rc) return rc;
+        if (b1 == n_cb) c1 = n;
+        const size_t e0 = (size_t)boff[b0], e1 = (size_t)boff[b1];
+        // the escaped bytes in front: the largest back-pointer's worth, a little more so that the destination is 16-byte aligned
+        const size_t W = e0 <= hmax ? e0 : hmax + ((e0 - hmax) & 15);
+        const size_t vn = W + (c1 - c0);
+        if (vn + 64 > sec_buf) { sec_buf = vn + 64 + (vn >> 3); rc = dev_buf(c, 36, sec_buf, &p); if (rc) return rc; d_v = (uint8_t *)p; }
+        if (W) RSN_HIP(hipMemcpyAsync(d_v, d_esc + (e0 - W), W, hipMemcpyDeviceToDevice, s));
+        if (c1 > c0) RSN_HIP(hipMemcpyAsync(d_v + W, d_in + c0, c1 - c0, hipMemcpyDeviceToDevice, s));
+        size_t got = 0;
+        if (vn) {
+            rc = lzss_decode_impl(c, s, d_v, vn, nullptr, 0, &got, d_esc + (e0 - W)); if (rc) return rc;
+            if (got != W + (e1 - e0)) return c.fail(RSN_ERR_DEVICE, "lzss: section %d expands to %zu bytes, the counting pass says %zu", n_sec, got, W + (e1 - e0));
+        }
+        if (dbg) fprintf(stderr, "lzss decode section %d: blocks [%u, %u), compressed [%zu, %zu), escaped [%zu, %zu), %zu bytes in front\n", n_sec, b0, b1, c0, c1, e0, e1, W);
+        b0 = b1; c0 = c1; n_sec++;
+    }
+    return lzss_unescape(c, s, d_esc, E, false, d_out, out_cap, out_n);
+}
+}  // namespace
+
+int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    return lzss_decode_impl(c, s, d_in, n, d_out, out_cap, out_n, nullptr);
 }
 
 }  // namespace rsn

@@ -676,6 +676,47 @@ def test_sections_give_the_same_stream(oracle):
     assert res[0] == res[1] == res[2]
 
 
+def test_decode_sections_give_the_same_bytes(oracle):
+    """A stream of 4 GiB and more -- compressed or decoded -- is expanded section by section (lzss_decode_sections): cuts at 4 KiB
+    block starts of the compressed stream, moved past a token that straddles one; a section is decoded as a stream of its own that
+    begins with the escaped bytes before it (the largest back-pointer's worth), and lands on the place those came from.
+    RSN_LZSS_DEC_SECTION_MIB=1 / 3 forces sections of 1 and 3 MiB on streams of 8-24 MiB (a process of its own: the switch is read
+    once): text; noise with escapes, periodic data, runs and a 37-byte period mixed; a window of 16 (short tokens: many cuts fall
+    inside one); streams with 5C / FF / '<' bytes, whose escape pairs the cuts split.  Every result is the input."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "import workloads as W\nfrom raisin_amd import lz\n"
+            "g = torch.Generator().manual_seed(5)\n"
+            "text = W.config_input('4', 24 << 20)\n"
+            "parts = []\n"
+            "for k in range(16):\n"
+            "    kind = k %% 4\n"
+            "    if kind == 0: parts.append(W.config_input('4', 24 << 20)[(k + 3) << 20:(k + 4) << 20])\n"
+            "    elif kind == 1: parts.append(torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, generator=g))\n"
+            "    elif kind == 2: parts.append(W.config_input('3', 1 << 20))\n"
+            "    else: parts.append(torch.randint(97, 101, ((1 << 20) // 37 + 1,), dtype=torch.uint8, generator=g).repeat_interleave(37)[:1 << 20])\n"
+            "mixed = torch.cat(parts)\n"
+            "esc = torch.tensor([0x5C, 0x3C, 0xFF, 0x5C, 0x5C, 0x41, 0x3C, 0x3C], dtype=torch.uint8)[torch.randint(0, 8, (8 << 20,), generator=g)]\n"
+            "for name, t, w in (('text', text, 4096), ('mixed', mixed, 4096), ('text-w16', text[:8 << 20], 16), ('escapes', esc, 4096), ('escapes-w100', esc, 100)):\n"
+            "    d = t.cuda()\n"
+            "    c = lz.compress_tensor(d, window=w)\n"
+            "    back = lz.decompress_tensor(c)\n"
+            "    print(name, c.numel(), back.numel() == d.numel() and bool(torch.equal(back, d)), hashlib.sha256(bytes(back.cpu().numpy())).hexdigest())\n" % root)
+    res = []
+    for env in ({}, {"RSN_LZSS_DEC_SECTION_MIB": "1"}, {"RSN_LZSS_DEC_SECTION_MIB": "3", "RSN_DEBUG": "1"}, {"RSN_LZSS_DEC_SECTION_MIB": "2", "RSN_LZSS_DEC_JUMP": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l.split() for l in r.stdout.strip().splitlines()]
+        assert len(lines) == 5 and all(l[2] == "True" for l in lines), (env, lines)
+        if env.get("RSN_DEBUG"): assert r.stderr.count("lzss decode section") >= 10, r.stderr[-2000:]
+        res.append(lines)
+    assert res[0] == res[1] == res[2] == res[3]
+
+
 def test_a_storm_of_large_calls_queues_instead_of_failing(oracle):
     """every calling thread has a scratch arena of its own and a 1 GiB LZSS encode wants ~12 GiB of it; concurrent large
     calls are admitted while their needs fit the device (RSN_SCRATCH_GIB: here 1.5 GiB, so that 64 MiB calls -- ~1 GiB each -- run one
