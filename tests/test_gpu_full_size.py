@@ -360,3 +360,33 @@ def test_lzss_decode_beyond_4GiB_in_sections():
             assert torch.equal(back[a:a + GIB], src[a:a + GIB]), (name, a)
         del src, comp, back
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("w,mib", [(256, 64), (1000, 64), (4095, 64), (8192, 32), (20000, 16), (65536, 8)])
+def test_lzss_windows_other_than_the_engines_at_size(oracle, w, mib):
+    """windows other than 4096 -- the row walk below it, the sweep up to 8192 (k_match2), lzss_big.hip above --
+    were oracle-checked at KB-MB sizes only.  Tens of MiB of config 4's text and of mixed sections per window: the bytes are the
+    oracle's (segment induction with that window), and decode back to the input."""
+    import time
+    import torch
+    import workloads as W
+    from raisin_amd import lz
+    n = mib << 20
+    g = torch.Generator().manual_seed(w)
+    parts = [W.config_input("4", n)[: n // 2],
+             torch.randint(0, 256, (n // 8,), dtype=torch.uint8, generator=g),
+             W.config_input("3", n // 8),
+             torch.randint(97, 101, (n // 8 // 37 + 1,), dtype=torch.uint8, generator=g).repeat_interleave(37)[: n // 8],
+             W.config_input("4", n)[n // 2: n // 2 + n // 8]]
+    if w > 20000:                                                      # (periodic stretches under a window that large are outside the large-window search's work budget: RSN_ERR_LIMIT, tested in test_gpu_lzss.py)
+        parts = [parts[0], parts[1], parts[4]]
+    src = torch.cat(parts).cuda()
+    t0 = time.time()
+    got = lz.compress_tensor(src, window=w)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    ok, bad = oracle.lzss_check(bytes(src.cpu().numpy()), bytes(got.cpu().numpy()), window=w)
+    print("window %d, %d MiB: product %.2f s, oracle check %.1f s" % (w, src.numel() >> 20, t1 - t0, time.time() - t1))
+    assert ok, "window %d: differs from the oracle's CompressAsync output in the segment at compressed offset %d" % (w, bad)
+    back = lz.decompress_tensor(got)
+    assert back.numel() == src.numel() and torch.equal(back, src)
