@@ -1003,7 +1003,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const bool prebuilt = tree.n_leaves > 4096;
     std::thread table_builder;
     if (prebuilt) table_builder = std::thread([&] { build_tables(tree, k_env, lut, child); if (!no_lut2) build_second_level(child, k_env, false, lut, lut2); });
-    const bool codes_ok = assign_codes(tree, codes, msg);
+    const bool codes_ok = assign_codes(tree, codes, msg, false);
     if (prebuilt) table_builder.join();
     if (!codes_ok) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
     const auto t3 = now();

@@ -207,10 +207,34 @@ bool build_tree(std::vector<HuffSym> &syms, HuffTree &t, std::string &msg) {
     return true;
 }
 
-bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg) {
+bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg, bool want_dfs) {
     const size_t a = t.n_leaves;
-    c.code.assign(a, 0); c.len.assign(a, 0); c.dfs.clear(); c.dfs.reserve(a);
+    c.code.assign(a, 0); c.len.assign(a, 0); c.dfs.clear();
     c.min_len = ~0u; c.max_len = 0; c.total_bits = 0;
+    if (!want_dfs) {
+        // A node is created after both its children (run_heap), so ids fall from the root down: one pass in descending id order sees
+        // every parent before its children.  code = the path from the root, '0' to the left (huffman.go:118-119).
+        const size_t nn = t.freq.size();
+        if ((size_t)t.root + 1 != nn && !(a == 1 && t.root == 0)) { msg = "huffman: internal error (tree ids out of order)"; return false; }
+        std::vector<uint64_t> code(nn, 0);
+        std::vector<uint8_t> len(nn, 0);
+        for (size_t id = nn; id-- > a;) {
+            const uint32_t l = (uint32_t)len[id] + 1;
+            if (l > 64) { msg = "huffman: code longer than 64 bits"; return false; }
+            const uint64_t base = l <= 64 && len[id] < 64 ? code[id] << 1 : 0;
+            const int32_t le = t.left[id], ri = t.right[id];
+            code[le] = base; len[le] = (uint8_t)l;
+            code[ri] = base | 1; len[ri] = (uint8_t)l;
+        }
+        for (size_t i = 0; i < a; i++) {
+            const uint32_t l = len[i];
+            c.code[i] = code[i]; c.len[i] = (uint8_t)l;
+            c.min_len = std::min(c.min_len, l); c.max_len = std::max(c.max_len, l);
+            c.total_bits += t.freq[i] * l;
+        }
+        return true;
+    }
+    c.dfs.reserve(a);
     struct Item { int32_t node; uint64_t code; uint32_t len; };
     std::vector<Item> stack;
     stack.push_back({t.root, 0, 0});

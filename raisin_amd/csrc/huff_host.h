@@ -50,8 +50,10 @@ void huff_slice_cuts(const uint8_t *in, size_t n, int shards, std::vector<size_t
 // buildTree (huffman.go:58-103) incl. Go container/heap order.  syms: any order,
 // destroyed.  Returns false (with msg) for an empty table.
 bool build_tree(std::vector<HuffSym> &syms, HuffTree &t, std::string &msg);
-// printCodes (huffman.go:110-127).  Fails if a code exceeds 64 bits.
-bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg);
+// printCodes (huffman.go:110-127).  Fails if a code exceeds 64 bits.  want_dfs: also the leaves in the order printCodes visits them
+// (c.dfs: what rsn_huffman_table / rsn_huffman_plan hand out); without it the codes come from one pass over the internal nodes, parents
+// before children -- no stack, a third of the time on the 3 * 10^5 symbols of a rune alphabet.
+bool assign_codes(const HuffTree &t, HuffCodes &c, std::string &msg, bool want_dfs = true);
 // Header in this library's canonical order (ascending rune, '\\' never last), huffman.go:312-318.
 void emit_header(const std::vector<HuffSym> &by_rune_asc, std::string &out);
 // decodeTree's header scan (huffman.go:196-227).  Returns symbols ascending by rune.

@@ -721,7 +721,7 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
         std::vector<HuffSym> by_rune = syms;
         std::string msg;
         if (!build_tree(syms, tree, msg)) { sync.fail(RSN_ERR_EMPTY, msg.c_str()); return; }
-        if (!assign_codes(tree, codes, msg)) { sync.fail(RSN_ERR_LIMIT, msg.c_str()); return; }
+        if (!assign_codes(tree, codes, msg, false)) { sync.fail(RSN_ERR_LIMIT, msg.c_str()); return; }
         std::vector<std::pair<uint32_t, uint8_t>> len_of(tree.n_leaves);  // rune -> code length, ascending rune
         for (uint32_t i = 0; i < tree.n_leaves; i++) len_of[i] = {tree.rune[i], codes.len[i]};
         std::sort(len_of.begin(), len_of.end());
