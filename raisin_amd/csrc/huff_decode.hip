@@ -69,6 +69,7 @@ struct DecArgs {
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
     int *changed; int pass;
+    const uint32_t *fix_list, *fix_count;   // pass > 0: the blocks whose first entry is not their predecessor's exit (k_dec_fix_list); null: every block looks for itself
     const unsigned long long *blk_off; uint8_t *out;   // D3
     uint32_t child_n;           // entries of child[]
     const uint32_t *lut2; uint32_t lut2_n;   // second level: sub-tables for the K-bit prefixes that lead inside the tree
@@ -293,11 +294,16 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     const int tid = threadIdx.x;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
+    // a fixing pass works through a list (r04: 74 000 blocks of a 1 GiB `skewed` stream each staging the tables to find out that they have
+    // nothing to do was 0.07 ms of a 1.7 ms decode; the list holds a few dozen)
+    const uint32_t n_work = a.fix_list ? *a.fix_count : n_blk;
+    if (blockIdx.x >= n_work) return;
     stage_lut(a, s_lut);   // once per (persistent) block
     if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
     const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
     if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
-    for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t blk = a.fix_list ? a.fix_list[wi] : wi;
         const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
         const uint32_t g = blk * DB + tid;
         const bool live = g < a.n_sub;
@@ -393,6 +399,21 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
             a.blk_bytes[blk] = all;
         }
     }
+}
+
+// The blocks a fixing pass has to decode again: those whose first lane's entry is not the exit the block before has published (the
+// test k_dec_sync makes for itself when it has no list).  Block 0 starts from the exact entry.
+__global__ __launch_bounds__(256) void k_dec_fix_list(const uint16_t *__restrict__ exit_rel, const uint16_t *__restrict__ entry_rel, uint32_t n_blk,
+                                                      uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    const bool need = b >= 1 && b < n_blk && exit_rel[(size_t)b * DB - 1] != entry_rel[(size_t)b * DB];
+    const unsigned long long m = __ballot(need);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (need) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
 }
 
 // Per-lane byte sink for the direct (unstaged) path: aligned 8-byte stores, byte stores
@@ -1175,12 +1196,15 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
 
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;
-    rc = dev_buf(c, 7, ((size_t)n_blk * 2 + 4) * 8, &p); if (rc) return rc;
+    rc = dev_buf(c, 7, ((size_t)n_blk * 2 + 4) * 8 + (size_t)n_blk * 4 + 64, &p); if (rc) return rc;
     a.blk_bytes = (unsigned long long *)p;
     unsigned long long *d_blk_off = a.blk_bytes + n_blk;
     unsigned long long *d_total = d_blk_off + n_blk;
     int *d_changed = (int *)(d_total + 1);
+    uint32_t *d_fix_count = (uint32_t *)(d_changed + 1);                 // (zeroed together with `changed`)
+    uint32_t *d_fix_list = (uint32_t *)(d_total + 4);
     a.changed = d_changed;
+    static const bool no_fix_list = getenv("RSN_DEC_NO_FIX_LIST") != nullptr;   // A/B switch: every block of a fixing pass looks for itself
 
     static const uint32_t grid_env = [] { const char *e = getenv("RSN_DEC_GRID"); return e ? (uint32_t)std::max(atoi(e), 1) : 256u * 8u * 2u; }();   // tuning switch: persistent blocks
     const uint32_t grid_p = std::min<uint32_t>(n_blk, grid_env);          // persistent blocks: the LUT is staged once per block
@@ -1227,7 +1251,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     ht->changed = 0;
     if (n_blk > 1) {                                                  // (a single block starts from the exact entry and iterates to its fixed point in LDS)
         a.pass = 1;
-        RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
+        RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
+        if (!no_fix_list) {
+            RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
+            a.fix_list = d_fix_list; a.fix_count = d_fix_count;
+        }
         rc = launch_sync(); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
     }
@@ -1239,7 +1267,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         for (uint32_t pass = 2; ht->changed; pass++) {
             if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
             a.pass = (int)pass;
-            RSN_HIP(hipMemsetAsync(d_changed, 0, 4, s));
+            RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
+            if (!no_fix_list) RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
             rc = launch_sync(); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
