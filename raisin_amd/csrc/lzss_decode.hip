@@ -74,15 +74,27 @@ __device__ __forceinline__ size_t skip_open_token(const uint8_t *__restrict__ in
 // '>' among the 22 bytes before it.
 __device__ __forceinline__ uint32_t pack_bit7(uint32_t z) { return ((z >> 7) * 0x00204081u >> 21) & 0xFu; }   // bit 7 of each byte -> 4 bits
 
+// Sixteen flag bytes (0x80 or 0x00 each, four dwords) -> a 16-bit mask, bit j = byte j.  A flag byte times its weight 2^j summed over a
+// dword is one v_dot4_u32_u8; two dwords share an accumulator (weights 1..8, 16..128), the mask comes out times 0x80.  (r04: the
+// multiply-and-shift of pack_bit7 is a quarter-rate v_mul_lo_u32 per dword and mask -- sixteen per span in the parsers, a tenth of
+// k_lzd_count2's issue slots.)
+__device__ __forceinline__ uint32_t pack16_bit7(uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3) {
+    uint32_t lo = __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(z1, 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(z2, 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(z3, 0x80402010u, hi, false);
+    return ((hi << 8) | lo) >> 7;
+}
+
 __device__ __forceinline__ uint32_t mask_5c(const uint32_t w[4]) {                             // 16-bit mask of the 5C bytes
-    uint32_t m = 0;
+    uint32_t z[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t y = w[k] ^ 0x5C5C5C5Cu;
         const uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
-        m |= pack_bit7(~t & 0x80808080u) << (4 * k);
+        z[k] = ~t & 0x80808080u;
     }
-    return m;
+    return pack16_bit7(z[0], z[1], z[2], z[3]);
 }
 
 __device__ __forceinline__ void load_span(const uint32_t *sw, int sbyte, uint32_t w[4]) {      // 16 staged bytes from any offset
@@ -96,33 +108,32 @@ __device__ __forceinline__ void load_span(const uint32_t *sw, int sbyte, uint32_
 
 // '<' mask in the low half, '>' mask in the high half
 __device__ __forceinline__ uint32_t ltgt_masks(const uint32_t w[4]) {
-    uint32_t lt = 0, gt = 0;
+    uint32_t zl[4], zg[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t y = w[k] ^ 0x3C3C3C3Cu;                            // '<' -> 00, '>' -> 02
         const uint32_t y2 = y & 0xFDFDFDFDu;
         const uint32_t t = ((y2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y2;       // bit 7 clear iff the byte is '<' or '>'
         const uint32_t z = ~t & 0x80808080u;
-        const uint32_t g = z & (y << 6);                                  // bit 1 tells them apart
-        lt |= pack_bit7(z & ~g) << (4 * k);
-        gt |= pack_bit7(g) << (4 * k);
+        zg[k] = z & (y << 6);                                             // bit 1 tells them apart
+        zl[k] = z & ~zg[k];
     }
-    return lt | (gt << 16);
+    return pack16_bit7(zl[0], zl[1], zl[2], zl[3]) | (pack16_bit7(zg[0], zg[1], zg[2], zg[3]) << 16);
 }
 
 // ',' mask in the low half, digit mask in the high half (the span's share of what parse_tok_w works out per token: a token's
 // twelve bytes after its '<' are then a shift of two spans' masks)
 __device__ __forceinline__ uint32_t cd_masks(const uint32_t w[4]) {
-    uint32_t cm = 0, dm = 0;
+    uint32_t zc[4], zd[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t y = w[k] ^ 0x30303030u;                            // digits -> 00..09, ',' -> 1C
         const uint32_t td = ((y & 0x7F7F7F7Fu) + 0x76767676u) | y;        // bit 7 clear iff 00..09
         const uint32_t yc = y ^ 0x1C1C1C1Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
-        dm |= pack_bit7(~td & 0x80808080u) << (4 * k);
-        cm |= pack_bit7(~tc & 0x80808080u) << (4 * k);
+        zd[k] = ~td & 0x80808080u;
+        zc[k] = ~tc & 0x80808080u;
     }
-    return cm | (dm << 16);
+    return pack16_bit7(zc[0], zc[1], zc[2], zc[3]) | (pack16_bit7(zd[0], zd[1], zd[2], zd[3]) << 16);
 }
 
 // the token whose '<' is staged byte j; sw = dword view, zero past the data, readable 28 bytes past j
