@@ -2427,7 +2427,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
                 {
                     auto dec4 = [](uint32_t v, uint32_t &nd) {          // v < 10000: its digits, the first in byte 0, and how many
                         const uint32_t hi = (v * 5243u) >> 19, lo = v - hi * 100u;               // v / 100 (exact below 43699), v % 100
-                        const uint32_t d3 = (hi * 103u) >> 10, d1 = (lo * 103u) >> 10;           // x / 10 for x < 100
+                        const uint32_t d3 = (hi * 103u) >> 10, d1 = __umul24(lo, 103u) >> 10;    // x / 10 for x < 100  (__umul24: the compiler cannot see that lo < 100 and would take the quarter-rate 32-bit multiply)
                         const uint32_t w = (d3 | ((hi - d3 * 10u) << 8) | (d1 << 16) | ((lo - d1 * 10u) << 24)) + 0x30303030u;
                         nd = 1u + (v > 9u ? 1u : 0u) + (v > 99u ? 1u : 0u) + (v > 999u ? 1u : 0u);
                         return w >> (8u * (4u - nd));
