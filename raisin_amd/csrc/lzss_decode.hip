@@ -699,10 +699,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     __syncthreads();
     phase_done(0);
     const int TL = (int)a.TL;
-    auto token_desc = [&](int x, uint32_t ptr) -> uint32_t {              // source of output byte x of a token with this back-pointer
-        const int q = x - (int)ptr;
-        return q >= 0 ? (D_LOC | (uint32_t)q) : (D_EXT | (uint32_t)(TL + q));
-    };
     // ---- A: every item marks the output position it starts at -- a literal with its byte, a token with D_LOC | (ptr - 1).
     // every token here has 1 <= len <= ptr <= DT (k_lzd_tiles checked it), so 32-bit offsets cannot overflow
     int run = (int)((long long)info.y - (long long)ts);                   // output offset (relative to the tile) of the first staged item: <= 0
@@ -759,15 +755,22 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     // ---- B: a lane owns 16 consecutive output positions.  The item a position belongs to is the last mark at or before it
     // (fill forward: a scan with "rightmost mark" inside the lane, across the wavefront, across the block), and a token's
     // bytes get their descriptor from the position and the token's back-pointer alone.
+    // (r04) Marks, positions and descriptors are 16-bit: the arithmetic runs on PAIRS of positions in packed halves (v_pk_add_u16 /
+    // v_pk_sub_u16 / v_pk_ashrrev_i16 and bit selects), branch-free -- it had been sixteen copies of a two-way branch per lane,
+    // ~530 vector and ~340 scalar instructions; a position's flags live at bit (j >> 1) + 16 (j & 1) of the lane's masks.
     const int xb = 16 * tid;
     uint32_t pk[8];
     {
         const uint4 v0 = reinterpret_cast<const uint4 *>(sd + xb)[0], v1 = reinterpret_cast<const uint4 *>(sd + xb)[1];
         pk[0] = v0.x; pk[1] = v0.y; pk[2] = v0.z; pk[3] = v0.w; pk[4] = v1.x; pk[5] = v1.y; pk[6] = v1.z; pk[7] = v1.w;
     }
-    uint32_t mylast = NONE;
+    uint32_t mylast = NONE;                                               // the lane's last mark: the last nonzero dword's high half, else its low half
+    {
+        uint32_t lastw = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { const uint32_t val = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; mylast = val != NONE ? val : mylast; }
+        for (int k = 0; k < 8; k++) lastw = pk[k] ? pk[k] : lastw;
+        mylast = (lastw >> 16) ? (lastw >> 16) : lastw;
+    }
     uint32_t incl = mylast;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d && incl == NONE) incl = y; }
     if (lane == 63) s_wlast[wv] = incl;
@@ -780,29 +783,52 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         const uint32_t carry = wv ? (uint32_t)__builtin_amdgcn_readlane((int)wl, wv - 1) : NONE;
         if (cur == NONE) cur = carry;
     }
-    uint32_t dsc[16];
+    auto fbit = [](int j) { return (j >> 1) + 16 * (j & 1); };          // where position j's flag sits in litm / unres
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    auto pk_add = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); };
+    auto pk_sub = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); };
+    auto pk_sign = [](uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, a) >> (i16x2)15); };   // 0xFFFF in a half whose bit 15 is set
+    auto bsel = [](uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); };                                   // v_bfi_b32
+    uint32_t dp[8], lm[8];                                                // descriptors and "is a literal" masks, two positions a word
     uint32_t unres = 0, litm = 0;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
+    {
+        const uint32_t c_ext = ((uint32_t)TL + D_EXT) & 0xFFFFu, sel_ext = c_ext | (c_ext << 16), sel_loc = D_LOC | (D_LOC << 16);
+        const uint32_t xp0 = (uint32_t)xb | ((uint32_t)(xb + 1) << 16);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t val = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-        cur = val != NONE ? val : cur;
-        const int x = xb + j;
-        const bool is_lit = (cur & M_LIT) && x < tlen;
-        uint32_t d = 0;                                                   // (a position no item covers cannot occur in a validated stream)
-        if (is_lit) d = ((uint32_t)x + cur) & 0x7FFFu;                    // for now: the staged index of the literal's byte
-        else if ((cur & M_TOK) && x < tlen) d = token_desc(x, (cur & D_PAY) + 1u);
-        dsc[j] = d;
-        litm |= (is_lit ? 1u : 0u) << j;
-        unres |= (!is_lit && (d >> 14) == 1u ? 1u : 0u) << j;
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lo = pk[k] & 0xFFFFu, hi = pk[k] >> 16;
+            const uint32_t c0 = lo != NONE ? lo : cur, c1 = hi != NONE ? hi : c0;   // the marks that cover positions 2k and 2k + 1
+            cur = c1;
+            const uint32_t C = c0 | (c1 << 16);
+            const uint32_t xp = xp0 + (uint32_t)k * 0x00020002u;          // the two positions (below 16384: no carry between the halves)
+            const uint32_t L = pk_sign(C);                                // M_LIT is bit 15
+            const uint32_t d_lit = pk_add(xp, C) & 0x7FFF7FFFu;           // for now: the staged index of the literal's byte
+            const uint32_t ptr = (C & (D_PAY | (D_PAY << 16))) + 0x00010001u;
+            const uint32_t q = pk_sub(xp, ptr);                           // position of the source inside the tile, or negative: before it
+            const uint32_t S = pk_sign(q);
+            const uint32_t d_tok = pk_add(q, bsel(S, sel_ext, sel_loc));  // D_LOC | q, or D_EXT | (TL + q)
+            dp[k] = bsel(L, d_lit, d_tok);                                // (a position no item covers cannot occur in a validated stream)
+            lm[k] = L;
+            litm |= (L & 0x00010001u) << k;
+            unres |= (~(L | S) & 0x00010001u) << k;                       // a token's byte whose source lies inside the tile
+        }
+        // the positions behind the tile's end take no part (the last tile of a stream)
+        const uint32_t nv = (uint32_t)min(max(tlen - xb, 0), 16);
+        const uint32_t vm = ((1u << ((nv + 1) >> 1)) - 1u) | (((1u << (nv >> 1)) - 1u) << 16);
+        litm &= vm; unres &= vm;
     }
-    if (__ballot(litm != 0)) {   // the literals' bytes out of the stage, all reads issued together (a slot that holds no literal reads byte 0 with everybody else)
+    if (__ballot(litm != 0)) {   // the literals' bytes out of the stage, all reads issued together (a slot that holds no literal reads some byte of the block's LDS with everybody else)
         uint32_t by[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) by[j] = sb[(litm >> j) & 1 ? dsc[j] : 0u];
+        for (int j = 0; j < 16; j++) { const uint32_t a2 = dp[j >> 1] & lm[j >> 1] & 0x7FFF7FFFu; by[j] = sb[(j & 1) ? a2 >> 16 : a2 & 0xFFFFu]; }   // (not a literal: byte 0)
 #pragma unroll
-        for (int j = 0; j < 16; j++) if ((litm >> j) & 1) dsc[j] = by[j];
+        for (int k = 0; k < 8; k++) dp[k] = bsel(lm[k], by[2 * k] | (by[2 * k + 1] << 16), dp[k]);
     }
+    uint32_t dsc[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) dsc[j] = (j & 1) ? dp[j >> 1] >> 16 : dp[j >> 1] & 0xFFFFu;
     auto write_back = [&]() {
         uint32_t o[8];
 #pragma unroll
@@ -811,7 +837,8 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(o[4], o[5], o[6], o[7]);
     };
     __syncthreads();                                                      // every lane has read its marks
-    write_back();
+    reinterpret_cast<uint4 *>(sd + xb)[0] = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+    reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(dp[4], dp[5], dp[6], dp[7]);
     __syncthreads();
     phase_done(2);
     // ---- C: in-tile pointer jumping, the lane's 16 descriptors in registers; only the unresolved ones read LDS, two hops a round.
@@ -826,10 +853,10 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
                 if (hop && !__ballot(unres != 0)) break;
                 uint32_t w[16];                                           // (a resolved slot reads sd[0] with everybody else: a broadcast)
 #pragma unroll
-                for (int j = 0; j < 16; j++) w[j] = sd[(unres >> j) & 1 ? (dsc[j] & D_PAY) : 0u];
+                for (int j = 0; j < 16; j++) w[j] = sd[(unres >> fbit(j)) & 1 ? (dsc[j] & D_PAY) : 0u];
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    if ((unres >> j) & 1) { dsc[j] = w[j]; if ((w[j] >> 14) != 1u) unres &= ~(1u << j); }
+                    if ((unres >> fbit(j)) & 1) { dsc[j] = w[j]; if ((w[j] >> 14) != 1u) unres &= ~(1u << fbit(j)); }
                 }
             }
             write_back();
