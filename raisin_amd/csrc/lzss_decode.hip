@@ -757,7 +757,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     // bytes get their descriptor from the position and the token's back-pointer alone.
     // (r04) Marks, positions and descriptors are 16-bit: the arithmetic runs on PAIRS of positions in packed halves (v_pk_add_u16 /
     // v_pk_sub_u16 / v_pk_ashrrev_i16 and bit selects), branch-free -- it had been sixteen copies of a two-way branch per lane,
-    // ~530 vector and ~340 scalar instructions; a position's flags live at bit (j >> 1) + 16 (j & 1) of the lane's masks.
+    // ~530 vector and ~340 scalar instructions; position j's literal flag lives at bit (j >> 1) + 16 (j & 1) of litm.
     const int xb = 16 * tid;
     uint32_t pk[8];
     {
@@ -783,7 +783,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         const uint32_t carry = wv ? (uint32_t)__builtin_amdgcn_readlane((int)wl, wv - 1) : NONE;
         if (cur == NONE) cur = carry;
     }
-    auto fbit = [](int j) { return (j >> 1) + 16 * (j & 1); };          // where position j's flag sits in litm / unres
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     typedef short i16x2 __attribute__((ext_vector_type(2)));
     auto pk_add = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); };
@@ -791,7 +790,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     auto pk_sign = [](uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, a) >> (i16x2)15); };   // 0xFFFF in a half whose bit 15 is set
     auto bsel = [](uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); };                                   // v_bfi_b32
     uint32_t dp[8], lm[8];                                                // descriptors and "is a literal" masks, two positions a word
-    uint32_t unres = 0, litm = 0;
+    uint32_t litm = 0;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
     {
         const uint32_t c_ext = ((uint32_t)TL + D_EXT) & 0xFFFFu, sel_ext = c_ext | (c_ext << 16), sel_loc = D_LOC | (D_LOC << 16);
@@ -812,12 +811,11 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             dp[k] = bsel(L, d_lit, d_tok);                                // (a position no item covers cannot occur in a validated stream)
             lm[k] = L;
             litm |= (L & 0x00010001u) << k;
-            unres |= (~(L | S) & 0x00010001u) << k;                       // a token's byte whose source lies inside the tile
         }
         // the positions behind the tile's end take no part (the last tile of a stream)
         const uint32_t nv = (uint32_t)min(max(tlen - xb, 0), 16);
         const uint32_t vm = ((1u << ((nv + 1) >> 1)) - 1u) | (((1u << (nv >> 1)) - 1u) << 16);
-        litm &= vm; unres &= vm;
+        litm &= vm;
     }
     if (__ballot(litm != 0)) {   // the literals' bytes out of the stage, all reads issued together (a slot that holds no literal reads some byte of the block's LDS with everybody else)
         uint32_t by[16];
@@ -826,42 +824,52 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
 #pragma unroll
         for (int k = 0; k < 8; k++) dp[k] = bsel(lm[k], by[2 * k] | (by[2 * k + 1] << 16), dp[k]);
     }
-    uint32_t dsc[16];
+    if (tlen != DT) {   // the stream's last tile: what lies behind its end is nobody's -- a resolved zero, or it would chase pointers for nothing
+        const uint32_t nv = (uint32_t)min(max(tlen - xb, 0), 16);
 #pragma unroll
-    for (int j = 0; j < 16; j++) dsc[j] = (j & 1) ? dp[j >> 1] >> 16 : dp[j >> 1] & 0xFFFFu;
+        for (int k = 0; k < 8; k++) dp[k] &= (nv > 2u * k ? 0xFFFFu : 0u) | (nv > 2u * k + 1u ? 0xFFFF0000u : 0u);
+    }
     auto write_back = [&]() {
-        uint32_t o[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = dsc[2 * j] | (dsc[2 * j + 1] << 16);
-        reinterpret_cast<uint4 *>(sd + xb)[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        reinterpret_cast<uint4 *>(sd + xb)[0] = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+        reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(dp[4], dp[5], dp[6], dp[7]);
     };
     __syncthreads();                                                      // every lane has read its marks
-    reinterpret_cast<uint4 *>(sd + xb)[0] = make_uint4(dp[0], dp[1], dp[2], dp[3]);
-    reinterpret_cast<uint4 *>(sd + xb)[1] = make_uint4(dp[4], dp[5], dp[6], dp[7]);
+    write_back();
     __syncthreads();
     phase_done(2);
-    // ---- C: in-tile pointer jumping, the lane's 16 descriptors in registers; only the unresolved ones read LDS, two hops a round.
+    // ---- C: in-tile pointer jumping, the lane's 16 descriptors in registers (packed in pairs, as B left them); only the unresolved
+    // ones -- bits 15:14 == 01: D_LOC -- read LDS, two hops a round.
     // (A reader may see another lane's descriptor before or after that lane's update of the same round: both name the same byte.
     //  Giving lane t the positions t, t + DTH, ... instead -- consecutive lanes on consecutive addresses -- measured slower.)
+    auto loc_halves = [&](uint32_t d) { return pk_sign((d << 1) & ~d); }; // 0xFFFF in a half that holds a D_LOC descriptor
+    const uint8_t *sdb = reinterpret_cast<const uint8_t *>(sd);
     uint32_t rounds = 0;
     for (;;) {
         rounds++;
-        if (unres) {
+        uint32_t um[8], any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { um[k] = loc_halves(dp[k]); any |= um[k]; }
+        if (any) {
 #pragma unroll
             for (int hop = 0; hop < 2; hop++) {                           // all 16 reads of a hop are issued together
-                if (hop && !__ballot(unres != 0)) break;
+                if (hop && !__ballot(any != 0)) break;
                 uint32_t w[16];                                           // (a resolved slot reads sd[0] with everybody else: a broadcast)
 #pragma unroll
-                for (int j = 0; j < 16; j++) w[j] = sd[(unres >> fbit(j)) & 1 ? (dsc[j] & D_PAY) : 0u];
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t a2 = (dp[k] & um[k] & (D_PAY | (D_PAY << 16))) << 1;   // byte offsets of the two sources
+                    w[2 * k] = *reinterpret_cast<const uint16_t *>(sdb + (a2 & 0xFFFFu));
+                    w[2 * k + 1] = *reinterpret_cast<const uint16_t *>(sdb + (a2 >> 16));
+                }
+                any = 0;
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if ((unres >> fbit(j)) & 1) { dsc[j] = w[j]; if ((w[j] >> 14) != 1u) unres &= ~(1u << fbit(j)); }
+                for (int k = 0; k < 8; k++) {
+                    dp[k] = bsel(um[k], w[2 * k] | (w[2 * k + 1] << 16), dp[k]);
+                    um[k] = loc_halves(dp[k]); any |= um[k];
                 }
             }
             write_back();
         }
-        if (!__syncthreads_or(unres != 0)) break;
+        if (!__syncthreads_or(any != 0)) break;
     }
     phase_done(3);
     for (int v = tid; v * 8 < tlen; v += DTH) st16<(RSN_NT_MASK & 32) != 0>(reinterpret_cast<uint4 *>(a.desc + ts) + v, reinterpret_cast<const uint4 *>(sd)[v]);
