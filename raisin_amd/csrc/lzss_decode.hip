@@ -726,8 +726,13 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (lane == 63) s_part[wv] = incl;
         __syncthreads();
         int o = run + (int)(incl - mine);
-        uint32_t tot = 0;
-        for (int w = 0; w < DTH / 64; w++) { if (w < wv) o += (int)s_part[w]; tot += s_part[w]; }
+        uint32_t tot;
+        {   // the sixteen wavefront sums: one scan by shuffles instead of sixteen LDS reads and adds per lane
+            uint32_t ws = lane < DTH / 64 ? s_part[lane] : 0u;
+            for (int d = 1; d < DTH / 64; d <<= 1) { const uint32_t y = __shfl_up(ws, d); if (lane >= d) ws += y; }
+            tot = (uint32_t)__builtin_amdgcn_readlane((int)ws, DTH / 64 - 1);
+            if (wv) o += (int)(uint32_t)__builtin_amdgcn_readlane((int)ws, wv - 1);
+        }
         if (valid && o < tlen) {
             for (uint32_t st = r.lit & ~(r.lit << 1); st; st &= st - 1) {   // the first literal of every run of literals in the span
                 const int j = __builtin_ctz(st);
@@ -899,10 +904,38 @@ __global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict_
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) cur[j] = (uint16_t)tail_entry(k0, nr, j);
     __syncthreads();
+    // (r04) A step used to wait twice for memory -- the tile's kind, then its tail descriptors -- 2.7 us of which the composition is a
+    // fraction: the kinds of the whole group are fetched up front, and the NEXT tile's tail (windows up to 4096: four entries a lane) is
+    // asked for before this tile's is composed -- unless that tile is a run tile, which has no descriptors (config 3 is nothing else:
+    // fetching them regardless cost it 0.3 ms, r04 section 8).
+    __shared__ uint8_t s_kind[DGRP];                                     // the number of runs of every tile of the group (0: descriptors)
+    static_assert(RT_RUNS <= 255, "a tile's run count fits a byte");
+    constexpr uint32_t PF = 4;
+    const bool pf_on = TL <= PF * DTH;
+    for (uint32_t t = threadIdx.x; t < dgrp; t += DTH) s_kind[t] = (uint8_t)min(rt_cnt ? rt_cnt[k0 + t] : 0u, 255u);
+    __syncthreads();
+    uint32_t pf[PF] = {0, 0, 0, 0};
+    auto fetch = [&](size_t k) {
+#pragma unroll
+        for (uint32_t q = 0; q < PF; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) pf[q] = desc[k * DT + DT - TL + j]; }
+    };
+    uint32_t rt_pf = 0;                                                   // ... and a run tile's runs come a step ahead in the same way
+    if (pf_on && dgrp > 1 && s_kind[1] == 0) fetch(k0 + 1);
+    if (dgrp > 1 && threadIdx.x < s_kind[1]) rt_pf = rt_runs[(k0 + 1) * RT_RUNS + threadIdx.x];
     for (uint32_t t = 1; t < dgrp; t++) {
-        nr = rt_cnt ? rt_cnt[k0 + t] : 0u;
-        if (threadIdx.x < nr) s_rt[threadIdx.x] = rt_runs[(k0 + t) * RT_RUNS + threadIdx.x];
+        nr = s_kind[t];                                                   // (a run tile has at most RT_RUNS = 64 runs: the byte IS the count)
+        if (threadIdx.x < nr) s_rt[threadIdx.x] = rt_pf;
+        uint32_t mine_v[PF];
+#pragma unroll
+        for (uint32_t q = 0; q < PF; q++) mine_v[q] = pf[q];
+        const bool have = pf_on && nr == 0;                               // this tile's entries came with the step before
+        if (pf_on && t + 1 < dgrp && s_kind[t + 1] == 0) fetch(k0 + t + 1);
+        if (t + 1 < dgrp && threadIdx.x < s_kind[t + 1]) rt_pf = rt_runs[(k0 + t + 1) * RT_RUNS + threadIdx.x];
         __syncthreads();
+        if (have) {
+#pragma unroll
+            for (uint32_t q = 0; q < PF; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) { const uint32_t v = mine_v[q]; nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; } }
+        } else
         for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = tail_entry(k0 + t, nr, j); nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
         __syncthreads();
         uint16_t *sw = cur; cur = nxt; nxt = sw;
