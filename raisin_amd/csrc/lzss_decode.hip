@@ -679,11 +679,12 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         if (a.stats) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&a.stats[q], now - t_prev); t_prev = now; }
     };
     const uint32_t k = blockIdx.x, ts = k * DT;
-    const uint32_t is_run_tile = a.rt_cnt ? a.rt_cnt[k] : 0u;             // (asked for here, looked at after the staging loads have been issued)
+    const uint32_t is_run_tile = a.rt_cnt ? a.rt_cnt[k] : 0u;             // (arrives together with the tile's record below)
     const int tlen = (int)min((uint32_t)DT, a.E - ts);
     const uint2 info = a.tile_info[k];
     const size_t in0 = info.x;
     const size_t in1 = k + 1 < a.n_tiles ? min(a.n, (size_t)a.tile_info[k + 1].x + MAXTOK) : a.n;
+    if (__builtin_amdgcn_readfirstlane((int)is_run_tile)) return;         // k_lzd_runs has resolved it (block-uniform: a scalar branch; before the staging loads: config 3 is nothing but such tiles)
     if (in1 - in0 > (size_t)(DT + 64)) { if (tid == 0) *a.fallback = 1; return; }   // zero-length tokens can stretch a tile's input without bound
     const size_t inA = in0 & ~(size_t)15;
     const int lo = (int)(in0 - inA), hi = lo + (int)(in1 - in0);
@@ -695,7 +696,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
     for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(0u, 0u, 0u, 0u);
-    if (__builtin_amdgcn_readfirstlane((int)is_run_tile)) return;         // k_lzd_runs has resolved it (block-uniform: a scalar branch)
     __syncthreads();
     phase_done(0);
     const int TL = (int)a.TL;
