@@ -1011,20 +1011,30 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
     if (threadIdx.x < 2 * DT / ZTILE) (&s_last[0][0])[threadIdx.x] = 0;
     for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = g ? gtail[(size_t)(g - 1) * TL + j] : 0;
     const uint32_t x0 = threadIdx.x * 16;
-    auto load = [&](uint32_t k, uint4 &a0, uint4 &a1) {                   // (a run tile has no descriptors in memory: nothing is loaded for it)
-        if (k < n_tiles && k * DT + x0 < E && !(rt_cnt && rt_cnt[k])) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = ld16<(RSN_NT_MASK & 64) != 0>(p); a1 = ld16<(RSN_NT_MASK & 64) != 0>(p + 1); }
+    // (r04) the kinds of the group's tiles up front -- the number of runs, 0 for a tile with descriptors -- and a run tile's runs a step
+    // ahead, like the next tile's descriptors: a step waited for them in turn
+    __shared__ uint8_t s_kind[DGRP + 1];
+    for (uint32_t t = threadIdx.x; t <= dgrp && t <= (uint32_t)DGRP; t += DTH) { const uint32_t k = g * dgrp + t; s_kind[t] = (uint8_t)(rt_cnt && t < dgrp && k < n_tiles ? rt_cnt[k] : 0u); }
+    __syncthreads();
+    auto load = [&](uint32_t t, uint4 &a0, uint4 &a1, uint32_t &rp) {     // (a run tile has no descriptors in memory: its runs are loaded instead)
+        const uint32_t k = g * dgrp + t;
+        if (t >= dgrp || k >= n_tiles) return;
+        const uint32_t kind = s_kind[t];
+        if (kind) { if (threadIdx.x < kind) rp = rt_runs[(size_t)k * RT_RUNS + threadIdx.x]; }
+        else if (k * DT + x0 < E) { const uint4 *p = reinterpret_cast<const uint4 *>(desc + (size_t)k * DT + x0); a0 = ld16<(RSN_NT_MASK & 64) != 0>(p); a1 = ld16<(RSN_NT_MASK & 64) != 0>(p + 1); }
     };
     uint4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, e0 = d0, e1 = d1;
-    load(g * dgrp, d0, d1);
+    uint32_t rp0 = 0, rp1 = 0;
+    load(0, d0, d1, rp0);
     __syncthreads();
     for (uint32_t t = 0; t < dgrp; t++) {
         const uint32_t k = g * dgrp + t;
         if (k >= n_tiles) break;
-        load(k + 1 < (g + 1) * dgrp ? k + 1 : n_tiles, e0, e1);            // next tile's descriptors in flight during this one
+        load(t + 1, e0, e1, rp1);                                          // next tile's descriptors (or runs) in flight during this one
         const uint32_t ts = k * DT, len = min((uint32_t)DT, E - ts);
-        const uint32_t nr = rt_cnt ? rt_cnt[k] : 0u;                      // a run tile: its descriptors are nr runs (block-uniform)
+        const uint32_t nr = s_kind[t];                                    // a run tile: its descriptors are nr runs (block-uniform)
         if (nr) {
-            if (threadIdx.x < nr) s_rt[t & 1][threadIdx.x] = rt_runs[(size_t)k * RT_RUNS + threadIdx.x];
+            if (threadIdx.x < nr) s_rt[t & 1][threadIdx.x] = rp0;
             __syncthreads();
         }
         if (x0 < len) {
@@ -1079,7 +1089,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
             s_last[t & 1][threadIdx.x] = 0;                               // two tiles (and two barriers) later it is used again
         }
         uint8_t *sw = prev; prev = nxt; nxt = sw;
-        d0 = e0; d1 = e1;
+        d0 = e0; d1 = e1; rp0 = rp1;
     }
 }
 
