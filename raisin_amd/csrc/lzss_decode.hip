@@ -1075,12 +1075,12 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_emit(const uint16_t *__restrict_
             }
             if (x0 + 16 <= len) *reinterpret_cast<uint4 *>(esc + ts + x0) = make_uint4(so[0], so[1], so[2], so[3]);
             else for (uint32_t q = 0; x0 + q < len; q++) esc[ts + x0 + q] = (uint8_t)(so[q >> 2] >> (8 * (q & 3)));
-            if (x0 + 16 > DT - TL) {                                      // this span overlaps the tile's tail
-                for (uint32_t q = 0; q < 16; q++) { const uint32_t x = x0 + q; if (x >= DT - TL) nxt[x - (DT - TL)] = (uint8_t)(o[q >> 2] >> (8 * (q & 3))); }
+            if (x0 >= DT - TL) *reinterpret_cast<uint4 *>(nxt + (x0 - (DT - TL))) = make_uint4(o[0], o[1], o[2], o[3]);   // the span lies in the tile's tail (TL and x0 are multiples of 16: whole spans)
+            if (!map_ff) {                                                // (the unescape pass's block summaries: nobody reads them when the stream holds no 5C)
+                const uint32_t nv = min(16u, len - x0);
+                const uint32_t non = ~mask_5c(o) & (nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u));
+                if (non) atomicMax(&s_last[t & 1][x0 / ZTILE], (x0 % ZTILE) + 32u - (uint32_t)__builtin_clz(non));
             }
-            const uint32_t nv = min(16u, len - x0);
-            const uint32_t non = ~mask_5c(o) & (nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u));
-            if (non) atomicMax(&s_last[t & 1][x0 / ZTILE], (x0 % ZTILE) + 32u - (uint32_t)__builtin_clz(non));
         }
         __syncthreads();
         if (!map_ff && threadIdx.x < DT / ZTILE && threadIdx.x * ZTILE < len) {
