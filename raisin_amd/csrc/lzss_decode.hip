@@ -910,33 +910,51 @@ __global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict_
     // fetching them regardless cost it 0.3 ms, r04 section 8).
     __shared__ uint8_t s_kind[DGRP];                                     // the number of runs of every tile of the group (0: descriptors)
     static_assert(RT_RUNS <= 255, "a tile's run count fits a byte");
-    constexpr uint32_t PF = 4;
-    const bool pf_on = TL <= PF * DTH;
+    // A lane composes FOUR CONSECUTIVE entries (windows up to 4096; larger ones go round again): a descriptor tile's come as one
+    // 8-byte load, a run tile's usually lie in one run -- one bisection, and the four entries of the map in hand are consecutive
+    // too: three dwords and a funnel shift instead of four bisections and four 2-byte gathers (the step is bound by the LDS).
+    const bool pf_on = TL <= 4 * DTH;
     for (uint32_t t = threadIdx.x; t < dgrp; t += DTH) s_kind[t] = (uint8_t)min(rt_cnt ? rt_cnt[k0 + t] : 0u, 255u);
     __syncthreads();
-    uint32_t pf[PF] = {0, 0, 0, 0};
-    auto fetch = [&](size_t k) {
-#pragma unroll
-        for (uint32_t q = 0; q < PF; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) pf[q] = desc[k * DT + DT - TL + j]; }
-    };
+    const uint32_t j4 = 4 * threadIdx.x;
+    uint2 pf = {0, 0};
+    auto fetch = [&](size_t k) { if (j4 < TL) pf = *reinterpret_cast<const uint2 *>(desc + k * DT + DT - TL + j4); };   // (TL, DT multiples of 256: 8-byte aligned)
     uint32_t rt_pf = 0;                                                   // ... and a run tile's runs come a step ahead in the same way
     if (pf_on && dgrp > 1 && s_kind[1] == 0) fetch(k0 + 1);
     if (dgrp > 1 && threadIdx.x < s_kind[1]) rt_pf = rt_runs[(k0 + 1) * RT_RUNS + threadIdx.x];
+    auto through = [&](uint32_t v) -> uint32_t { return (v & D_EXT) ? cur[v & D_PAY] : (v & 0xFFFFu); };   // one entry through the map in hand
     for (uint32_t t = 1; t < dgrp; t++) {
         nr = s_kind[t];                                                   // (a run tile has at most RT_RUNS = 64 runs: the byte IS the count)
         if (threadIdx.x < nr) s_rt[threadIdx.x] = rt_pf;
-        uint32_t mine_v[PF];
-#pragma unroll
-        for (uint32_t q = 0; q < PF; q++) mine_v[q] = pf[q];
-        const bool have = pf_on && nr == 0;                               // this tile's entries came with the step before
+        const uint2 mine_v = pf;
         if (pf_on && t + 1 < dgrp && s_kind[t + 1] == 0) fetch(k0 + t + 1);
         if (t + 1 < dgrp && threadIdx.x < s_kind[t + 1]) rt_pf = rt_runs[(k0 + t + 1) * RT_RUNS + threadIdx.x];
         __syncthreads();
-        if (have) {
-#pragma unroll
-            for (uint32_t q = 0; q < PF; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) { const uint32_t v = mine_v[q]; nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; } }
-        } else
-        for (uint32_t j = threadIdx.x; j < TL; j += DTH) { const uint32_t v = tail_entry(k0 + t, nr, j); nxt[j] = (v & D_EXT) ? cur[v & D_PAY] : (uint16_t)v; }
+        for (uint32_t j0 = j4; j0 < TL; j0 += 4 * DTH) {
+            uint32_t o0, o1;                                              // entries j0, j0 + 1 | j0 + 2, j0 + 3
+            if (nr) {
+                const uint32_t x = DT - TL + j0;
+                uint32_t lo = 0, hi = nr;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((s_rt[mid] & 0xFFFFu) <= x) lo = mid; else hi = mid; }
+                const uint32_t r = ((s_rt[lo] >> 16) + (x - (s_rt[lo] & 0xFFFFu))) & D_PAY;
+                const uint32_t nxt_x = lo + 1 < nr ? (s_rt[lo + 1] & 0xFFFFu) : 0xFFFFFFFFu;
+                if (nxt_x >= x + 4 && r + 4 <= TL) {                      // one run: the map's entries r .. r + 3
+                    const uint32_t *c32 = reinterpret_cast<const uint32_t *>(cur) + (r >> 1);
+                    const uint32_t d0 = c32[0], d1 = c32[1], d2 = (r & 1) ? c32[2] : 0u, sh = 16u * (r & 1u);
+                    o0 = __builtin_amdgcn_alignbit(d1, d0, sh); o1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+                } else {
+                    const uint32_t e0 = through(run_desc(s_rt, nr, x)), e1 = through(run_desc(s_rt, nr, x + 1));
+                    const uint32_t e2 = through(run_desc(s_rt, nr, x + 2)), e3 = through(run_desc(s_rt, nr, x + 3));
+                    o0 = e0 | (e1 << 16); o1 = e2 | (e3 << 16);
+                }
+            } else {
+                uint2 v = mine_v;
+                if (!pf_on || j0 != j4) v = *reinterpret_cast<const uint2 *>(desc + (k0 + t) * DT + DT - TL + j0);
+                o0 = through(v.x & 0xFFFFu) | (through(v.x >> 16) << 16);
+                o1 = through(v.y & 0xFFFFu) | (through(v.y >> 16) << 16);
+            }
+            *reinterpret_cast<uint2 *>(nxt + j0) = make_uint2(o0, o1);
+        }
         __syncthreads();
         uint16_t *sw = cur; cur = nxt; nxt = sw;
     }
