@@ -595,7 +595,8 @@ struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32
 
 __global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in, size_t n, const uint2 *__restrict__ tile_info, uint32_t n_tiles, uint32_t E, uint32_t TL,
                                                  uint32_t *__restrict__ rt_cnt, uint32_t *__restrict__ rt_runs) {
-    __shared__ uint8_t s_in[RT_BYTES + MAXTOK + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_in32[(RT_BYTES + MAXTOK + 8 + 32) / 4];   // (a dword view for parse_tok_w: zero past the data, readable 28 bytes past a token's '<')
+    uint8_t *s_in = reinterpret_cast<uint8_t *>(s_in32);
     __shared__ uint32_t s_tok[RT_ITEMS + 1];                              // x | (ptr - 1) << 16 in stream order; then the end of the last token
     __shared__ uint32_t s_runs[RT_RUNS];
     __shared__ uint32_t s_nr;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in,
     const size_t in0 = info.x, in1 = k + 1 < n_tiles ? (size_t)tile_info[k + 1].x : n;   // the tile's items begin in [in0, in1)
     if (in1 <= in0 || in1 - in0 > (size_t)RT_BYTES) { if (lane == 0) rt_cnt[k] = 0; return; }
     const uint32_t nb = (uint32_t)(in1 - in0), stage = min((uint32_t)(n - in0), nb + (uint32_t)MAXTOK);
-    for (uint32_t i = lane; i < RT_BYTES + MAXTOK + 8; i += 64) s_in[i] = i < stage ? in[in0 + i] : 0;
+    for (uint32_t i = lane; i < RT_BYTES + MAXTOK + 8 + 32; i += 64) s_in[i] = i < stage ? in[in0 + i] : 0;
     if (lane == 0) s_nr = 0;
     __syncthreads();
     // every '<' among the first nb bytes starts a token (a literal '<' is escaped); the tile is a run tile iff those tokens follow each
@@ -618,8 +619,8 @@ __global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in,
         uint32_t pos = 0;
         while (x < tlen && ok) {                                            // (the token that reaches the tile's end may begin at byte nb: it is staged too)
             if (pos >= stage || s_in[pos] != '<' || ntok >= (uint32_t)RT_ITEMS) { ok = false; break; }
-            const Tok t = parse_tok(s_in, stage, pos);
-            if (!t.ok || t.ptr == 0 || t.ptr > TL || t.len > t.ptr) { ok = false; break; }   // (validated already; a run tile needs ptr <= TL like every tile of the tile path)
+            const Tok t = parse_tok_w(s_in32, (int)pos);                  // (the dword parser: the byte loop's dependent LDS reads were most of this kernel on periodic data, 0.15 ms per GiB)
+            if (!t.ok || pos + t.tl > stage || t.ptr == 0 || t.ptr > TL || t.len > t.ptr) { ok = false; break; }   // (validated already; a run tile needs ptr <= TL like every tile of the tile path)
             if (t.len) {                                                    // (a zero-length token produces nothing)
                 const int xs = max(x, 0);
                 if (x + (int)t.len > 0 && xs < tlen) s_tok[ntok++] = (uint32_t)xs | ((t.ptr - 1u) << 16);
