@@ -136,6 +136,17 @@ __device__ __forceinline__ uint32_t cd_masks(const uint32_t w[4]) {
     return pack16_bit7(zc[0], zc[1], zc[2], zc[3]) | (pack16_bit7(zd[0], zd[1], zd[2], zd[3]) << 16);
 }
 
+// the ',' mask alone (k_lzd_resolve: its tokens were validated by the counting pass, the digits need no second look)
+__device__ __forceinline__ uint32_t c_mask(const uint32_t w[4]) {
+    uint32_t zc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t yc = w[k] ^ 0x2C2C2C2Cu, tc = ((yc & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | yc;
+        zc[k] = ~tc & 0x80808080u;
+    }
+    return pack16_bit7(zc[0], zc[1], zc[2], zc[3]);
+}
+
 // the token whose '<' is staged byte j; sw = dword view, zero past the data, readable 28 bytes past j
 __device__ __forceinline__ Tok parse_tok_w(const uint32_t *sw, int j) {
     const int q = (j + 1) >> 2; const uint32_t sh = (uint32_t)((j + 1) & 3) * 8;
@@ -205,6 +216,8 @@ struct Span {
 
 // masks[] holds ltgt_masks of every span, two spans of lead-in and one span beyond included: masks[sp + 2] is span sp;
 // cdm[] the same for cd_masks (spans sp and sp + 1 are read)
+// TRUSTED: every token of the stream is known to be well-formed (the counting pass has said so): cdm holds the ',' masks alone
+template <bool TRUSTED = false>
 __device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *masks, const uint32_t *cdm, int sp, int sbyte, int valid, Span &r) {
     const uint32_t m0 = masks[sp + 2], m1 = masks[sp + 1], m2 = masks[sp];
     const uint32_t mn = masks[sp + 3], cd0 = cdm[sp + 2], cd1 = cdm[sp + 3];
@@ -234,7 +247,7 @@ __device__ __forceinline__ void span_parse(const uint32_t *sw, const uint32_t *m
                 const uint32_t g12 = (gt32 >> sh) & 0xFFFu, c12 = (cm32 >> sh) & 0xFFFu, d12 = (dm32 >> sh) & 0xFFFu;
                 const uint32_t pc = (uint32_t)__builtin_ctz(c12 | 0x1000u), pg = (uint32_t)__builtin_ctz(g12 | 0x1000u);
                 const uint32_t need = ((1u << pg) - 1u) & ~(1u << pc);
-                if (pc >= 1 && pc <= 4 && pg >= pc + 2 && pg <= pc + 5 && (d12 & need) == need) {
+                if (pc >= 1 && pc <= 4 && pg >= pc + 2 && pg <= pc + 5 && (TRUSTED || (d12 & need) == need)) {
                     const int b = sbyte + j + 1, q = b >> 2;
                     const uint32_t d0 = sw[q], d1 = sw[q + 1], d2 = sw[q + 2], d3 = sw[q + 3];
                     const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)b), a1 = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)b),
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         const int valid = hi - sbyte >= 16 ? 16 : hi - sbyte > 0 ? hi - sbyte : 0;
         Span r;
         uint32_t m = 0, cd = 0, lead = 0, lead_cd = 0;
-        if (valid) { load_span(sw, sbyte, r.w); m = ltgt_masks(r.w); cd = cd_masks(r.w); }
+        if (valid) { load_span(sw, sbyte, r.w); m = ltgt_masks(r.w); cd = c_mask(r.w); }
         if (tid < 2 && base) { lead = masks[DTH + tid]; lead_cd = cdm[DTH + tid]; }   // the last two spans of the previous round
         __syncthreads();
         masks[tid + 2] = m; cdm[tid + 2] = cd;
@@ -717,11 +730,11 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             uint32_t w[4] = {0, 0, 0, 0};
             const int nb = lo + 16 * (base + DTH);
             if (nb < hi + 16) load_span(sw, nb, w);
-            masks[DTH + 2] = ltgt_masks(w); cdm[DTH + 2] = cd_masks(w);
+            masks[DTH + 2] = ltgt_masks(w); cdm[DTH + 2] = c_mask(w);
         }
         __syncthreads();
         uint32_t mine = 0;
-        if (valid) { span_parse(sw, masks, cdm, tid, sbyte, valid, r); mine = r.out; }
+        if (valid) { span_parse<true>(sw, masks, cdm, tid, sbyte, valid, r); mine = r.out; }
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_part[wv] = incl;
