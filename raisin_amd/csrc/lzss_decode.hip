@@ -733,8 +733,10 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             masks[DTH + 2] = ltgt_masks(w); cdm[DTH + 2] = c_mask(w);
         }
         __syncthreads();
+        phase_done(6);
         uint32_t mine = 0;
         if (valid) { span_parse<true>(sw, masks, cdm, tid, sbyte, valid, r); mine = r.out; }
+        phase_done(7);
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_part[wv] = incl;
@@ -747,6 +749,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             tot = (uint32_t)__builtin_amdgcn_readlane((int)ws, DTH / 64 - 1);
             if (wv) o += (int)(uint32_t)__builtin_amdgcn_readlane((int)ws, wv - 1);
         }
+        phase_done(8);
         if (valid && o < tlen) {
             for (uint32_t st = r.lit & ~(r.lit << 1); st; st &= st - 1) {   // the first literal of every run of literals in the span
                 const int j = __builtin_ctz(st);
@@ -1422,15 +1425,16 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         }
         ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr, d_rt_cnt, d_rt_runs};
         static const bool lzd_stats = getenv("RSN_LZD_STATS") != nullptr;
-        if (lzd_stats) { void *sp; rc = dev_buf(c, 25, 64, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 64, s)); ra.stats = (unsigned long long *)sp; }
+        if (lzd_stats) { void *sp; rc = dev_buf(c, 25, 128, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 128, s)); ra.stats = (unsigned long long *)sp; }
         if (d_rt_cnt) RSN_LAUNCH("lzss_dec_runs", k_lzd_runs, dim3(n_tiles), dim3(64), 0, s, d_in, n, (const uint2 *)d_tinfo, n_tiles, E, TL, d_rt_cnt, d_rt_runs);
         RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
         if (lzd_stats) {
-            unsigned long long hs[8];
-            RSN_HIP(hipMemcpyAsync(hs, ra.stats, 64, hipMemcpyDeviceToHost, s));
+            unsigned long long hs[16];
+            RSN_HIP(hipMemcpyAsync(hs, ra.stats, 128, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
             fprintf(stderr, "lzss_dec_resolve, cycles per tile: staging %.0f, parse + item marks %.0f, fill forward %.0f, pointer jumping %.0f (%.2f rounds), store %.0f\n",
                     (double)hs[0] / n_tiles, (double)hs[1] / n_tiles, (double)hs[2] / n_tiles, (double)hs[3] / n_tiles, (double)hs[5] / n_tiles, (double)hs[4] / n_tiles);
+            fprintf(stderr, "  parse + item marks in parts: masks + exchange %.0f, span parse %.0f, scan %.0f, marks %.0f\n", (double)hs[6] / n_tiles, (double)hs[7] / n_tiles, (double)hs[8] / n_tiles, (double)hs[1] / n_tiles);
         }
         static thread_local size_t attr_tl = 0;
         if ((size_t)TL * 4 > attr_tl) {
