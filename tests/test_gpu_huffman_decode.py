@@ -205,7 +205,7 @@ def test_second_level_tables_and_switches(oracle):
             ) % (root, os.path.join(root, "tests"))
     outs = []
     for env in ({}, {"RSN_DEC_NO_LUT2": "1"}, {"RSN_DEC_K": "8"}, {"RSN_DEC_KWIDE": "0"}, {"RSN_DEC_FUSED": "1"}, {"RSN_NO_MULTI": "1"},
-                {"RSN_DEC_WARM": "0"}, {"RSN_DEC_WARM": "0", "RSN_DEC_FUSED": "1"}):   # no warm-up: most blocks' guessed entries are wrong -- the fixing passes (and the one-pass decoder's fallback) do the work
+                {"RSN_DEC_WARM": "0"}, {"RSN_DEC_WARM": "0", "RSN_DEC_NO_FIX_LIST": "1"}, {"RSN_DEC_WARM": "0", "RSN_DEC_FUSED": "1"}):   # no warm-up: most blocks' guessed entries are wrong -- the fixing passes (and the one-pass decoder's fallback) do the work
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
