@@ -254,7 +254,9 @@ __device__ __forceinline__ uint32_t advance(const DecArgs &a, const uint32_t *s_
         while (sp <= safe && lim >= K) {
             const uint32_t win = window32_sp(s_data, sp);
             const uint32_t e = lut_at(a, s_lut, win, lane_r);
-            if (!SHORT && (e & 0x80000000u)) { uint32_t q = sp - spo; (void)decode_long(a, s_data, win, e, q, l2); sp = q + spo; nb++; continue; }   // first code longer than K bits
+            if (!SHORT && __ballot((e & 0x80000000u) != 0)) {             // first code longer than K bits, somewhere in the wavefront (rare: a scalar branch around it)
+                if (e & 0x80000000u) { uint32_t q = sp - spo; (void)decode_long(a, s_data, win, e, q, l2); sp = q + spo; nb++; continue; }
+            }
             const uint32_t u1 = u_used(e);
             sp += u1; nb += u_n(e);
             if (sp <= safe) {
@@ -511,20 +513,20 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
                 while (remaining) {
                     const uint32_t win = window32_sp(s_data, pos);
                     const uint32_t e = lut_at(a, s_lut, win, lane_r);
-                    uint32_t bytes, take, used;
-                    if (!SHORT && (e & 0x80000000u)) { uint32_t q = pos - spo; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q + spo - pos; }
-                    else {
-                        bytes = u_bytes(e);
-                        take = min(u_n(e), remaining);                    // (the last lookup may list more codewords than the lane owes:
-                        used = u_used(e);                                 //  whatever lies above `cnt` bytes is masked off at the end, pos is dead by then)
+                    uint32_t bytes = u_bytes(e);
+                    uint32_t take = min(u_n(e), remaining);               // (the last lookup may list more codewords than the lane owes:
+                    uint32_t used = u_used(e);                            //  whatever lies above `cnt` bytes is masked off at the end, pos is dead by then)
+                    if (!SHORT && __ballot((e & 0x80000000u) != 0)) {     // a code longer than K bits somewhere in the wavefront (rare: a scalar branch around it, no exec masks on the common path)
+                        if (e & 0x80000000u) { uint32_t q = pos - spo; bytes = decode_long(a, s_data, win, e, q, l2); take = 1; used = q + spo - pos; }
                     }
                     acc |= (unsigned long long)bytes << (8 * cnt);
                     cnt += take; remaining -= take; pos += used;
                     if (cnt >= 4) { RSN_EMIT_WORD(o, (uint32_t)acc); o++; acc >>= 32; cnt -= 4; }
                     // the second lookup out of the same window (r04): `used` <= 11 bits are gone, >= 21 are left
                     if (used <= (uint32_t)LUT_BITS_MAX && remaining) {
-                        const uint32_t e2 = lut_at(a, s_lut, win >> used, lane_r);
-                        if (SHORT || !(e2 & 0x80000000u)) {
+                        uint32_t e2 = lut_at(a, s_lut, win >> used, lane_r);
+                        if (!SHORT) e2 = (int32_t)e2 < 0 ? 0u : e2;       // (a long code waits for the next turn's fresh window: an entry of no symbols and no bits)
+                        {
                             const uint32_t b2 = u_bytes(e2);
                             const uint32_t t2 = min(u_n(e2), remaining);
                             acc |= (unsigned long long)b2 << (8 * cnt);   // (remaining != 0: the first lookup was taken whole, acc holds nothing above cnt)
