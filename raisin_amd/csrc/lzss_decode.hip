@@ -1311,6 +1311,16 @@ __global__ __launch_bounds__(ZB) void k_une_write(const uint8_t *__restrict__ es
 // ======================================================================= host side
 namespace {
 
+// The decoder's large scratch -- 2 bytes of descriptors per escaped byte, the escaped stream itself, the tail maps -- goes through the
+// same admission gate as the encoder's (rsn_api.hip: a goroutine storm of gigabyte calls queues instead of running the device out of
+// memory); released, with the buffers when others wait, on every way out.  Slots 13 .. 16, 19, 22, 23, 25, 27, 36.
+struct DecGate {
+    Ctx &c; size_t need = 0;
+    explicit DecGate(Ctx &cc) : c(cc) {}
+    void admit(size_t escaped) { if (!need && escaped >= ((size_t)64 << 20)) { need = 4 * escaped; (void)scratch_admit(c, need); } }
+    ~DecGate() { if (need) scratch_release(c, need, (0xFull << 13) | (1ull << 19) | (3ull << 22) | (1ull << 25) | (1ull << 27) | (1ull << 36)); }
+};
+
 // L4 over an escaped stream of any length: d_esc[0, E) -> d_out.  have_summ: the per-block summaries are in place already (the tile
 // path's emit kernel writes them on its way out).  Scratch slot 16.
 int lzss_unescape(Ctx &c, hipStream_t s, const uint8_t *d_esc, size_t E, bool have_summ, uint8_t *d_out, size_t out_cap, size_t *out_n) {
@@ -1377,6 +1387,8 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
     const bool one_pass = !three_pass && hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
+    DecGate gate(c);
+    if (!esc_dst && d_out) gate.admit(E);                               // (a section is admitted by lzss_decode_sections; the size query allocates nothing)
     if (!d_out && !esc_dst) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens
         *out_n = round_up((size_t)E, 16) + 16;
         return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %u bytes", E);
@@ -1540,6 +1552,8 @@ int lzss_decode_sections(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, u
     if (E == 0) return RSN_OK;
     if (!d_out) { *out_n = round_up(E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %zu bytes", E); }
     if (hmax + 16 > SEC && hmax + 16 > ((size_t)1 << 30)) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 4 GiB and more with back-pointers beyond 1 GiB");
+    DecGate gate(c);
+    gate.admit(E / 4 + std::min(E, SEC + ((size_t)1 << 28)));          // (admit() charges four times its argument: the whole escaped stream + four bytes per escaped byte of a section)
     rc = dev_buf(c, 15, E + 64, &p); if (rc) return rc;
     uint8_t *d_esc = (uint8_t *)p;
     // the first item that STARTS at or after compressed position q (a block start): the tokens are known to be well-formed

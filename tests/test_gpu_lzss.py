@@ -732,11 +732,14 @@ def test_a_storm_of_large_calls_queues_instead_of_failing(oracle):
             "datas = [bytes(W.config_input('4', (64 << 20) + k * 4099).numpy()) for k in range(3)]\n"
             "want = [hashlib.sha256(lz.CompressAsync(d)).hexdigest() for d in datas]\n"
             "got = [None] * 6\n"
+            "back = [None] * 6\n"
             "def run(i):\n"
-            "    got[i] = hashlib.sha256(lz.CompressAsync(datas[i %% 3])).hexdigest()\n"
+            "    c = lz.CompressAsync(datas[i %% 3])\n"
+            "    got[i] = hashlib.sha256(c).hexdigest()\n"
+            "    back[i] = lz.Decompress(c) == datas[i %% 3]\n"                # (the decoder's scratch goes through the same gate)
             "ts = [threading.Thread(target=run, args=(i,)) for i in range(6)]\n"
             "[t.start() for t in ts]; [t.join() for t in ts]\n"
-            "print('OK' if got == want + want else 'MISMATCH', got, want)\n" % root)
+            "print('OK' if got == want + want and all(back) else 'MISMATCH', got, want, back)\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, RSN_SCRATCH_GIB="1.5", RSN_SCRATCH_DEBUG="1"))
     assert r.returncode == 0, r.stderr[-3000:]
