@@ -189,7 +189,7 @@ def BenchmarkFile(algorithms, fileString, PrintStats=False):
     lossless = decompressed == data
     ratio = len(compressed) / len(data) * 100 if data else float("nan")
     actual = _entropy(_byte_counts(decompressed), len(compressed)) if compressed else 0.0
-    res = Result(name, "%.2fms" % (dur * 1e3), ratio, actual, entropy, lossless, False)
+    res = Result(name, _time_taken(dur), ratio, actual, entropy, lossless, False)
     if PrintStats:
         print("Lossless: %s" % str(lossless).lower())
         print("Original bytes: %d" % len(data))
@@ -217,12 +217,51 @@ def _suite_order(results):
 BenchmarkTimeout = 60.0   # engine.go:216 `timeout := 1 * time.Minute`
 
 
+def _go_duration_ns(ns):
+    """time.Duration.String() (Go's published format: the largest unit that leaves a non-zero integer part below a
+    second -- "190µs", "1.23ms" --, "XhYmZ.ZZZs" from a second up, fractions without trailing zeros, "0s" for zero)."""
+    if ns == 0:
+        return "0s"
+    sign, u = ("-", -ns) if ns < 0 else ("", ns)
+
+    def frac(v, prec):                       # fmtFrac: v / 10^prec, and the fraction's digits without trailing zeros
+        q, r = divmod(v, 10 ** prec)
+        digits = ("%0*d" % (prec, r)).rstrip("0") if prec else ""
+        return q, ("." + digits) if digits else ""
+
+    if u < 1000000000:
+        if u < 1000:
+            return "%s%dns" % (sign, u)
+        prec, unit = (3, "\u00b5s") if u < 1000000 else (6, "ms")
+        q, f = frac(u, prec)
+        return "%s%d%s%s" % (sign, q, f, unit)
+    sec, f = frac(u, 9)
+    out = "%d%ss" % (sec % 60, f)
+    mins = sec // 60
+    if mins > 0:
+        out = "%dm" % (mins % 60) + out
+        if mins // 60 > 0:
+            out = "%dh" % (mins // 60) + out
+    return sign + out
+
+
+def _go_round_ns(ns, m):
+    """time.Duration.Round(m): to the nearest multiple of m, halfway values away from zero."""
+    if m <= 0:
+        return ns
+    r = abs(ns) % m
+    v = abs(ns) - r if r + r < m else abs(ns) + m - r
+    return -v if ns < 0 else v
+
+
 def _go_duration(seconds):
-    """time.Duration.String() for the timeout row (engine.go:258: ">1m0s")."""
-    if seconds >= 60:
-        m, sec = divmod(seconds, 60)
-        return "%dm%gs" % (m, sec)
-    return "%gs" % seconds if seconds >= 1 else "%gms" % (seconds * 1e3)
+    """time.Duration.String() of a duration given in seconds (the timeout row, engine.go:258: ">1m0s")."""
+    return _go_duration_ns(int(round(seconds * 1e9)))
+
+
+def _time_taken(seconds):
+    """engine.go:425: duration.Round(10*time.Microsecond).String() -- "190µs", "4.61s"."""
+    return _go_duration_ns(_go_round_ns(int(round(seconds * 1e9)), 10000))
 
 
 def BenchmarkSuite(files, algorithms, out=None, timeout=None):

@@ -55,6 +55,41 @@ static std::string trim_ext(const std::string &f) {
     return f.substr(0, dot);
 }
 
+// time.Duration.String() (Go's published format: "190µs", "1.23ms" below a second, "XhYmZ.ZZZs" from a second up, fractions
+// without trailing zeros, "0s" for zero) -- the timeout row (engine.go:258: ">1m0s") and the "time taken" column (engine.go:425)
+static std::string go_duration_ns(long long ns) {
+    if (ns == 0) return "0s";
+    const bool neg = ns < 0;
+    unsigned long long u = neg ? (unsigned long long)(-ns) : (unsigned long long)ns;
+    auto frac = [](unsigned long long v, int prec, std::string &f) {     // fmtFrac: v / 10^prec; f = "." + the fraction's digits without trailing zeros
+        unsigned long long p = 1;
+        for (int k = 0; k < prec; k++) p *= 10;
+        char buf[24]; snprintf(buf, sizeof buf, "%0*llu", prec, v % p);
+        f = prec ? buf : "";
+        while (!f.empty() && f.back() == '0') f.pop_back();
+        if (!f.empty()) f = "." + f;
+        return v / p;
+    };
+    std::string out, f;
+    if (u < 1000000000ull) {
+        if (u < 1000ull) out = std::to_string(u) + "ns";
+        else if (u < 1000000ull) { const unsigned long long q = frac(u, 3, f); out = std::to_string(q) + f + "\xC2\xB5s"; }
+        else { const unsigned long long q = frac(u, 6, f); out = std::to_string(q) + f + "ms"; }
+    } else {
+        const unsigned long long sec = frac(u, 9, f), mins = sec / 60;
+        out = std::to_string(sec % 60) + f + "s";
+        if (mins > 0) { out = std::to_string(mins % 60) + "m" + out; if (mins / 60 > 0) out = std::to_string(mins / 60) + "h" + out; }
+    }
+    return neg ? "-" + out : out;
+}
+// time.Duration.Round(m): to the nearest multiple of m, halfway values away from zero
+static long long go_round_ns(long long ns, long long m) {
+    const unsigned long long a = ns < 0 ? (unsigned long long)(-ns) : (unsigned long long)ns, r = a % (unsigned long long)m;
+    const unsigned long long v = r + r < (unsigned long long)m ? a - r : a + (unsigned long long)m - r;
+    return ns < 0 ? -(long long)v : (long long)v;
+}
+static std::string go_duration(long long ms) { return go_duration_ns(ms * 1000000ll); }
+
 // check(e) -> panic in the reference; an exception here (caught per row in -benchmark, engine.go:315-328)
 template <class Call>
 static Bytes take(Call call) {
@@ -107,8 +142,8 @@ static Result BenchmarkFile(const std::vector<std::string> &algorithms, const st
     const auto t0 = std::chrono::steady_clock::now();
     const Bytes c = compress(data, algorithms);
     const Bytes d = decompress(c, algorithms);
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    char tt[32]; snprintf(tt, sizeof tt, "%.2fms", ms);
+    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    const std::string tt = go_duration_ns(go_round_ns(ns, 10000));     // engine.go:425: duration.Round(10*time.Microsecond).String()
     return {name, tt, (float)c.size() / (float)data.size() * 100.f, (float)entropy(d, c.size()), entropy(data, data.size()), d == data, false};
 }
 }  // namespace engine
@@ -120,15 +155,6 @@ static std::string ByteCountSI(long long b) {
     long long div = unit; int exp = 0;
     for (long long n = b / unit; n >= unit; n /= unit) { div *= unit; exp++; }
     char buf[32]; snprintf(buf, sizeof buf, "%.1f %cB", (double)b / (double)div, "kMGTPE"[exp]);
-    return buf;
-}
-
-// time.Duration.String() for the timeout row (engine.go:258: ">1m0s")
-static std::string go_duration(long long ms) {
-    char buf[48];
-    if (ms >= 60000) snprintf(buf, sizeof buf, "%lldm%gs", ms / 60000, (double)(ms % 60000) / 1e3);
-    else if (ms >= 1000) snprintf(buf, sizeof buf, "%gs", (double)ms / 1e3);
-    else snprintf(buf, sizeof buf, "%lldms", ms);
     return buf;
 }
 
@@ -164,6 +190,7 @@ int main(int argc, char **argv) {
         else if (const char *v = val("-outext")) outext = v;
         else if (a == "-delete") { has_delete = true; del = true; }
         else if (const char *v = val("-delete")) { has_delete = true; del = strcmp(v, "false") != 0; }
+        else if (const char *v = val("-fmtduration")) { printf("%s\n", go_duration_ns(go_round_ns(atoll(v), 10000)).c_str()); return 0; }   // (tests: engine.go:425's column for a given number of nanoseconds)
         else if (a[0] != '-' && file.empty()) file = a;
     }
     if (cmd.empty()) cmd = app.size() >= 5 && app.compare(app.size() - 5, 5, "grape") == 0 ? "decompress" : "compress";   // cli.go:54-58

@@ -19,6 +19,7 @@ int main() {
     printf("%s: %d CUs, sharedMemPerBlock %zu, maxSharedMemoryPerMultiProcessor %zu, regsPerBlock %d, maxThreadsPerMultiProcessor %d\n", p.name, p.multiProcessorCount,
            p.sharedMemPerBlock, p.maxSharedMemoryPerMultiProcessor, p.regsPerBlock, p.maxThreadsPerMultiProcessor);
     probe<38016, 256>(); probe<50856, 384>(); probe<62400, 512>(); probe<69000, 576>(); probe<76488, 640>(); probe<53808, 1024>(); probe<57096, 1024>();
+    probe<72976, 1024>(); probe<74000, 1024>(); probe<75816, 1024>(); probe<78000, 1024>(); probe<80000, 1024>(); probe<81920, 1024>();
     probe<22000, 256>(); probe<32768, 256>(); probe<40960, 256>(); probe<65536, 256>(); probe<81920, 256>(); probe<16384, 64>();
     return 0;
 }

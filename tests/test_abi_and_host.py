@@ -167,6 +167,22 @@ def test_engine_mirror_host_side(built):
     assert lz.DefaultWindowSize == 4096
 
 
+def test_time_taken_column_is_gos_duration_string(built):
+    """engine.go:425: duration.Round(10*time.Microsecond).String() -- README.md:153-167 shows "190µs", ai/data.json "4.61328s";
+    the same nanoseconds through the Python mirror and the C++ host."""
+    import subprocess
+    from raisin_amd import engine
+    want = {0: "0s", 4999: "0s", 5000: "10\u00b5s", 190000: "190\u00b5s", 194999: "190\u00b5s", 195000: "200\u00b5s", 1234567: "1.23ms",
+            999995000: "1s", 1500000000: "1.5s", 4613280000: "4.61328s", 60000000000: "1m0s", 61230000000: "1m1.23s",
+            3600000000000: "1h0m0s", 3723500000000: "1h2m3.5s"}
+    exe = os.path.join(ROOT, "raisin_amd", "host", "rsn")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    for ns, text in want.items():
+        assert engine._go_duration_ns(engine._go_round_ns(ns, 10000)) == text, ns
+        assert subprocess.check_output([exe, "-fmtduration=%d" % ns]).decode("utf-8").strip() == text, ns
+    assert engine._go_duration(60.0) == "1m0s" and engine._time_taken(0.00019) == "190\u00b5s"   # README.md:157
+
+
 def test_legacy_lz_compress_host_only(built, oracle, samiam, known):
     """(f)#4: lz.Compress (lzss.go:224) lives in librsn as host code of its own -- README's 21-byte answer
     (README.md:165), the ai/data.json sizes, and the oracle's independent restatement; needs no device."""
