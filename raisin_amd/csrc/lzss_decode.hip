@@ -1315,10 +1315,10 @@ namespace {
 // same admission gate as the encoder's (rsn_api.hip: a goroutine storm of gigabyte calls queues instead of running the device out of
 // memory); released, with the buffers when others wait, on every way out.  Slots 13 .. 16, 19, 22, 23, 25, 27, 36.
 struct DecGate {
-    Ctx &c; size_t need = 0;
+    Ctx &c; size_t held = 0; bool asked = false;
     explicit DecGate(Ctx &cc) : c(cc) {}
-    void admit(size_t escaped) { if (!need && escaped >= ((size_t)64 << 20)) { need = 4 * escaped; (void)scratch_admit(c, need); } }
-    ~DecGate() { if (need) scratch_release(c, need, (0xFull << 13) | (1ull << 19) | (3ull << 22) | (1ull << 25) | (1ull << 27) | (1ull << 36)); }
+    void admit(size_t escaped) { if (!asked && escaped >= ((size_t)64 << 20)) { asked = true; held = scratch_admit(c, 4 * escaped); } }   // (0 inside a host-buffer call: covered there)
+    ~DecGate() { scratch_release(c, held, (0xFull << 13) | (1ull << 19) | (3ull << 22) | (1ull << 25) | (1ull << 27) | (1ull << 36)); }
 };
 
 // L4 over an escaped stream of any length: d_esc[0, E) -> d_out.  have_summ: the per-block summaries are in place already (the tile

@@ -1637,615 +1637,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     }
 }
 
-// ------------------------------------------------------------------ E2'''' (r05): the chain walk, block-synchronous
-// The same contract as k_match_chain (exact keys wherever a greedy chain of the tile lands, the claim bitmap, the records), another
-// search structure.  What the format gives (lzss.go:141-147): a token is written only if len("<d,L>") < L, never for L <= 5, so for a
-// short match only L steers the chain, and L <= 2 can be answered by PRESENCE -- does this bigram / this byte occur in the window at
-// all? -- without a single candidate compare.  r04's counters say what that is worth on text: 51 % of a chain's visits have L <= 2,
-// and a visit's candidates under a bigram key are twice those under a trigram key.
-//   1. buckets keyed by the TRIGRAM (five bits of the first two bytes, three of the third; two more bits of the third as the entry's
-//      tag -- exact on lower-case text): a visit meets the candidates that can give L >= 3 and no others.  The eight buckets of a
-//      bigram lie side by side: the exact fall-back for "is the bigram in the window" scans them (rare, see 2.).
-//   2. a table of two bits per position, filled by all threads before any chain moves: L = 0 / 1 / 2 proven, or HARD (L >= 3, or not
-//      proven).  Bigram presence comes from a table of 4096 slots that rides on the scatter's rounds of 1024 positions -- a slot holds
-//      (round, earliest position of that round), one atomicMax; a position looks before its round's inserts (an earlier round's
-//      occurrence, checked against the staged bytes; or "the last round with this slot lies before the window") and after them (the
-//      earliest of its own round); a slot shared with another bigram proves nothing and the position is HARD.  Trigram presence comes
-//      from the sorted buckets: an entry looks at its neighbours in the list.  Byte presence: the block masks.
-//   3. the walk: 128 chains (a home row of 8 lanes each, as before), but the BLOCK moves in step: (S1) every row steps through cheap
-//      positions -- claim, two bits, add -- until it stands on a HARD one, and publishes that visit's bucket slice; (S2) the candidates
-//      of all visits are dealt over all sixteen wavefronts in rows of eight (the owner of a row by an 8-ary search of the prefix sums,
-//      its parameters from LDS), row maxima go to the chain by an LDS atomic; (S3) the home rows commit.  The row map, the bucketful
-//      path and the per-wavefront dealing of k_match_chain are gone: a visit with 3 candidates and one with 300 are 39 rows of the
-//      same round.
-// A HARD visit whose candidates give nothing of three bytes falls back to the exact answers for L <= 2 (the bigram's eight buckets, the
-// byte masks): that is what keeps "not proven" safe.
-#ifndef RSN_WALK_MAXSTEP
-#define RSN_WALK_MAXSTEP 8                                                // cheap steps a row takes per round of the block before it lets the others deal
-#endif
-#ifndef RSN_WALK_NARROW
-#define RSN_WALK_NARROW 16                                                // a bucket slice longer than this is trimmed to the window's blocks
-#endif
-#ifndef RSN_WALK_SCAN_CAP
-#define RSN_WALK_SCAN_CAP 6                                               // list neighbours an entry examines before it calls itself HARD
-#endif
-__device__ __forceinline__ uint32_t lds_load4(const uint32_t *sw, uint32_t rel) {
-    const uint32_t q = rel >> 2;
-    return __builtin_amdgcn_alignbyte(sw[q + 1], sw[q], rel);
-}
-__device__ __forceinline__ uint32_t tri_key(uint32_t w) { return ((w & 31u) << 8) | ((w >> 5) & 0xF8u) | ((w >> 16) & 7u); }   // w = b0 | b1 << 8 | b2 << 16
-__device__ __forceinline__ uint32_t tri_tag(uint32_t w) { return (w >> 19) & 3u; }
-__device__ __forceinline__ uint32_t bi_slot(uint32_t w) { return ((w & 127u) << 5) | ((w >> 8) & 31u); }
-
-template <class C>
-__global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_walk(ChainArgs a) {
-#ifdef RSN_WALK_STATS
-#define WS_T(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wst[i] += now_ - wst_last; wst_last = now_; } } while (0)
-#define WS_C(i, v) do { wsc[i] += (v); } while (0)
-    unsigned long long wst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wst_last = __builtin_amdgcn_s_memtime();
-    uint32_t wsc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#else
-#define WS_T(i) do { } while (0)
-#define WS_C(i, v) do { } while (0)
-#endif
-    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = RSN_CHAIN_ROW_CS, CH = C::CH, NS = C::NS;
-    constexpr int LW = 8, K = 8, NWV = CTH / 64, NCH = NWV * K;             // lanes per home row, rows per wavefront, wavefronts, chains
-    constexpr uint32_t LCAP = 4, NONE = 0xFFFFFFFFu;
-    static_assert(CTH == 1024 && C::TAGB == 2 && NCH == 128 && (CH + CT) % 16 == 0, "rounds of 1024 positions, two tag bits, 128 chains");
-    auto cand_q = [](uint32_t irel, uint32_t tag) { return ((irel - 1u) << C::TAGB) | tag; };
-    auto cand_rot = [](uint32_t q, uint32_t e) { const uint32_t d = q - e; return (uint32_t)__builtin_amdgcn_alignbit(d, d, (uint32_t)C::TAGB); };   // < W: a candidate at distance rot + 1
-    __shared__ __attribute__((aligned(1024))) uint32_t sw[C::STAGE / 4];   // fc[r0, r0 + STAGE), zero outside the stream
-    __shared__ __attribute__((aligned(16))) uint8_t s_pool[(HNB / 2) * 4 + NS * 2];
-    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_pool);
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_pool + (HNB / 2) * 4);
-    __shared__ __attribute__((aligned(16))) uint32_t s_claim[C::DUMP_BYTES / 4];
-    __shared__ unsigned long long s_present[256];
-    __shared__ uint32_t s_capl[(CH + CT) / 16];                           // two bits per position: 0 HARD, 1 L = 2, 2 L = 1, 3 L = 0
-    struct WalkScratch {
-        uint32_t par[NCH][8];                                             // a visit's parameters for the lanes its candidates are dealt to
-        uint32_t best[NCH], nrows[NCH], lcnt[NCH], lfar[NCH];
-        uint32_t pre[NCH + 4];                                            // rows of the chains up to and including this one
-        uint32_t next[NCH];                                               // where a chain goes on (NONE: a new start; DEAD: it has ended for good)
-        uint32_t llist[NCH][LCAP][2];
-    };
-    __shared__ __attribute__((aligned(16))) uint32_t s_un[4096];          // the set-up's bigram table; then the walk's scratch
-    static_assert(sizeof(WalkScratch) <= sizeof(uint32_t) * 4096, "the walk's scratch lives where the bigram table was");
-    uint32_t *s_bt = s_un;
-    WalkScratch &ws = *reinterpret_cast<WalkScratch *>(s_un);
-    __shared__ uint32_t s_part[CTH / 64];
-    __shared__ uint32_t s_heavy, s_next, s_dense;
-    __shared__ uint32_t s_nstep, s_stepmin, s_stepmax;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t E = a.E, W = a.W;
-    const uint32_t list_entry = (a.redo & 2u) ? chain_tail().redo_list[blockIdx.x] : blockIdx.x;
-    const uint32_t bx = list_entry & 0x3FFFFFFFu;
-    const long long t0 = (long long)bx * CT;
-    const long long r0 = t0 - CH - HWMAX;
-    if ((a.redo & 4u) && bx < HALO_TILES) return;
-    if (chain_tail().tchain[bx].walked == 2) return;
-    for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
-        const long long P = r0 + 16ll * v;
-        uint4 x = {0, 0, 0, 0};
-        if (P >= 0 && P + 16 <= (long long)E) x = *reinterpret_cast<const uint4 *>(a.fc + P);
-        else if (P + 16 > 0 && P < (long long)E) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)E) w[k >> 2] |= (uint32_t)a.fc[q] << (8 * (k & 3)); }
-            x = {w[0], w[1], w[2], w[3]};
-        }
-        reinterpret_cast<uint4 *>(sw)[v] = x;
-    }
-    for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
-    for (int i = tid; i < C::DUMP_BYTES / 4; i += CTH) s_claim[i] = 0;
-    for (int i = tid; i < 256; i += CTH) s_present[i] = 0;
-    for (int i = tid; i < (CH + CT) / 16; i += CTH) s_capl[i] = 0;
-    for (int i = tid; i < 4096; i += CTH) s_bt[i] = 0;
-    if (tid == 0) { s_heavy = 0; s_next = 0; s_dense = 0; s_nstep = 0; s_stepmin = 0xFFFFFFFFu; s_stepmax = 0; }
-    __syncthreads();
-    WS_T(0);
-
-    // ---- the staged positions that count: [rlo, rhi1) hold a byte of the stream, [rlo, rhi2) a bigram, [rlo, rhi3) a trigram
-    const long long q0 = max(0ll, t0 - CH);
-    const uint32_t zrel = (uint32_t)max(0ll, -r0);
-    const uint32_t rlo = (uint32_t)(max(0ll, q0 - (long long)W) - r0);
-    const uint32_t rhi1 = (uint32_t)(min((long long)E, t0 + (long long)CT) - r0);
-    const uint32_t rhi2 = max(rlo, rhi1 - (t0 + (long long)CT >= (long long)E ? 1u : 0u));       // (the stream's last position starts no bigram)
-    const uint32_t rhi3 = (uint32_t)max((long long)rlo, min((long long)E - 2, t0 + (long long)CT) - r0);
-    const uint32_t npos = (uint32_t)min((long long)CT, (long long)E - t0);
-    const uint32_t kp_end = CH + npos;
-    const uint32_t tp_lo = max((uint32_t)HWMAX, zrel), tp_hi = HWMAX + kp_end;   // staged offsets of the positions a chain can stand on
-    for (uint32_t rel = tid; rel < (uint32_t)NS; rel += CTH) {
-        if (rel < rlo || rel >= rhi1) continue;
-        const uint32_t w = lds_load4(sw, rel);
-        if (rel < rhi3) { const uint32_t h = tri_key(w); atomicAdd(&s_cur[h >> 1], 1u << (16 * (h & 1))); }
-        const unsigned long long bit = 1ull << (rel >> CSH);
-        if (!(s_present[w & 0xFFu] & bit)) atomicOr(&s_present[w & 0xFFu], bit);
-    }
-    __syncthreads();
-    {
-        constexpr int PER = HNB / 2 / CTH;
-        uint32_t sum = 0;
-        for (int k = 0; k < PER; k++) { const uint32_t x = s_cur[tid * PER + k]; sum += (x & 0xFFFF) + (x >> 16); }
-        uint32_t incl = sum;
-        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
-        if (lane == 63) s_part[wv] = incl;
-        __syncthreads();
-        uint32_t run = incl - sum;
-        for (int k = 0; k < wv; k++) run += s_part[k];
-        for (int k = 0; k < PER; k++) {
-            const uint32_t x = s_cur[tid * PER + k], c0 = x & 0xFFFF, c1 = x >> 16;
-            s_cur[tid * PER + k] = run | ((run + c0) << 16);
-            run += c0 + c1;
-        }
-    }
-    __syncthreads();
-    WS_T(1);
-    // ---- scatter (rounds of 2^CSH offsets: a bucket's entries end up ordered by block) + the bigram table (rounds of 1024)
-    {
-        // before its round's inserts: 1 = no occurrence in an earlier round can lie in the window, 2 = one does, 3 = not proven
-        auto bt_before = [&](uint32_t rel, uint32_t w) -> uint32_t {
-            const uint32_t v = s_bt[bi_slot(w)];
-            if (v == 0) return 1u;
-            const uint32_t rr = (v >> 10) - 1u, p = (rr << 10) + (1023u - (v & 1023u)), dn = rel - p;
-            if (dn >= 2u && dn <= W) return ((lds_load4(sw, p) ^ w) & 0xFFFFu) == 0 ? 2u : 3u;
-            if (((rr + 1u) << 10) + W <= rel) return 1u;                    // that whole round lies before the window
-            return 3u;
-        };
-        // after them: the slot holds the earliest position of this round
-        auto bt_after = [&](uint32_t rel, uint32_t w, uint32_t st) {
-            if (st != 2u) {
-                const uint32_t v = s_bt[bi_slot(w)];
-                const uint32_t p = (rel & ~1023u) + (1023u - (v & 1023u));
-                if (p + 2u <= rel) st = (((lds_load4(sw, p) ^ w) & 0xFFFFu) == 0 && rel - p <= W) ? 2u : 3u;
-            }
-            uint32_t code = 0;                                              // HARD
-            if (st == 2u) code = 1u;                                        // L = 2, unless its trigram occurs too (below)
-            else if (st == 1u) {                                            // no bigram: L = 1 iff the byte occurs in the window -- proven only by a whole block
-                const uint32_t wst = max(rel - min(W, rel), zrel);
-                const uint32_t fb_lo = (wst + (1u << CSH) - 1) >> CSH, fb_hi = rel >> CSH;
-                if (fb_lo < fb_hi) {
-                    const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
-                    if (s_present[w & 0xFFu] & m) code = 2u;
-                }
-            }
-            const uint32_t kp = rel - HWMAX;
-            if (code) atomicOr(&s_capl[kp >> 4], code << (2u * (kp & 15u)));
-        };
-        uint32_t p_rel = NONE, p_w = 0, p_st = 0;                          // the position of the round before, waiting for its second look
-        for (uint32_t base = 0; base < (uint32_t)NS; base += CTH) {
-            const uint32_t rel = base + tid;
-            const bool in3 = rel >= rlo && rel < rhi3, in2 = rel >= rlo && rel < rhi2;
-            const uint32_t w = lds_load4(sw, min(rel, (uint32_t)NS));
-            if (p_rel != NONE) bt_after(p_rel, p_w, p_st);
-            p_rel = NONE;
-            if (in2 && rel >= tp_lo && rel < tp_hi) { p_rel = rel; p_w = w; p_st = bt_before(rel, w); }
-            const uint32_t h = tri_key(w), ent = (rel << C::TAGB) | tri_tag(w), sh = 16 * (h & 1);
-#pragma unroll
-            for (int g = 0; g < (CTH >> CSH); g++) {
-                if ((tid >> CSH) == g && in3) {
-                    const uint32_t slot = (atomicAdd(&s_cur[h >> 1], 1u << sh) >> sh) & 0xFFFF;
-                    s_list[slot] = (uint16_t)ent;
-                }
-                if (g == (CTH >> CSH) - 1 && in2) atomicMax(&s_bt[bi_slot(w)], (((base >> 10) + 1u) << 10) | (1023u - (uint32_t)tid));
-                __syncthreads();
-            }
-        }
-        if (p_rel != NONE) bt_after(p_rel, p_w, p_st);
-    }
-    const uint16_t *ends = reinterpret_cast<const uint16_t *>(s_cur);
-    __syncthreads();
-    WS_T(2);
-    // ---- trigram presence: every entry of a position a chain can stand on looks at its neighbours in the list -- the entries before it
-    //      (its own block's first, in no order; then the earlier blocks, nearest first) and the rest of its own block behind it
-    {
-        const uint32_t n_ent = ends[HNB - 1];
-        for (uint32_t j0 = 0; j0 < n_ent; j0 += CTH) {
-            const uint32_t j = j0 + tid;
-            uint32_t rel = 0, w = 0, lo = 0, hi = 0, q = 0, res = 2;       // res: 0 looking, 1 HARD, 2 no trigram of the window matches
-            if (j < n_ent) {
-                rel = (uint32_t)s_list[j] >> C::TAGB;
-                if (rel >= tp_lo && rel < tp_hi) {
-                    w = lds_load4(sw, rel) & 0xFFFFFFu;
-                    const uint32_t key = tri_key(w);
-                    lo = key ? (uint32_t)ends[key - 1] : 0u; hi = ends[key];
-                    q = cand_q(rel, tri_tag(w));
-                    res = 0;
-                }
-            }
-            const bool act = res == 0;
-            const uint32_t blk_i = rel >> CSH, blk_lo = (rel - min(W, rel)) >> CSH;
-            uint32_t idx = j, steps = 0;
-            while (__ballot(res == 0)) {
-                if (res == 0) {
-                    if (idx <= lo) res = 2;
-                    else {
-                        idx--;
-                        const uint32_t e2 = s_list[idx], rel2 = e2 >> C::TAGB;
-                        if ((rel2 >> CSH) < blk_lo) res = 2;
-                        else {
-                            const uint32_t rot = cand_rot(q, e2);
-                            if (rot < W && rot >= 2u && (lds_load4(sw, rel2) & 0xFFFFFFu) == w) res = 1;
-                            else if (++steps >= (uint32_t)RSN_WALK_SCAN_CAP) res = 1;
-                        }
-                    }
-                }
-            }
-            bool fwd = act && res == 2;
-            idx = j;
-            while (__ballot(fwd)) {
-                if (fwd) {
-                    idx++;
-                    if (idx >= hi) fwd = false;
-                    else {
-                        const uint32_t e2 = s_list[idx], rel2 = e2 >> C::TAGB;
-                        if ((rel2 >> CSH) != blk_i) fwd = false;
-                        else {
-                            const uint32_t rot = cand_rot(q, e2);
-                            if (rot < W && rot >= 2u && (lds_load4(sw, rel2) & 0xFFFFFFu) == w) { res = 1; fwd = false; }
-                            else if (++steps >= (uint32_t)RSN_WALK_SCAN_CAP) { res = 1; fwd = false; }
-                        }
-                    }
-                }
-            }
-            if (act && res == 1) { const uint32_t kp = rel - HWMAX; atomicAnd(&s_capl[kp >> 4], ~(3u << (2u * (kp & 15u)))); }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < (int)(sizeof(WalkScratch) / 4); i += CTH) s_un[i] = 0;
-    __syncthreads();
-    WS_T(3);
-
-    // ---- the walk.  Positions are counted from t0 - CH (kp); staged offset = HWMAX + kp.
-    uint32_t kp_first = (uint32_t)(q0 - (t0 - CH));
-    if ((a.redo & 4u) && bx == HALO_TILES) kp_first = CH;
-    if (list_entry >> 31) kp_first = chain_tail().redo_start[blockIdx.x] - (uint32_t)(t0 - CH);
-    // (starts every CS positions from the warm-up start on, the warm-up zone included: the warm-up chain is the longest of the tile, and
-    //  the rounds of the block are as many as its longest chain has HARD visits)
-    const uint32_t nitems = (list_entry & 0x40000000u) ? 1u : (kp_end - kp_first + CS - 1) / CS;
-    constexpr uint32_t GIVE_UP = 0x40000000u, DEAD = 0xFFFFFFFEu;
-    const int rl = lane & (LW - 1), slot = lane / LW;
-    const bool leader = rl == 0;
-    const uint32_t ch = (uint32_t)wv * K + (uint32_t)slot;               // the chain whose home row this is (S3)
-    if (tid < NCH) ws.next[tid] = NONE;
-    __syncthreads();
-    for (;;) {
-        // ---- S1. ONE LANE per chain, the first two wavefronts (the other fourteen wait: a row of eight lanes per chain on all sixteen
-        //      was sixteen times the instructions, and instruction issue is what a CU's two blocks share): through the cheap positions
-        //      to a HARD one; its bucket slice, trimmed to the window by bisection
-        bool alive = false;
-        if (tid < NCH) {
-            uint32_t kp = ws.next[tid];
-            alive = kp != DEAD;
-            bool mine = false;
-            for (uint32_t steps = 0; alive && !mine && steps < (uint32_t)RSN_WALK_MAXSTEP; steps++) {
-                if (kp >= kp_end) {
-                    const uint32_t kq = atomicAdd(&s_next, 1u);
-                    alive = kq < nitems;
-                    kp = kp_first + kq * CS;
-                }
-                if (alive) {
-                    const uint32_t old = atomicOr(&s_claim[kp >> 5], 1u << (kp & 31));
-                    if ((old >> (kp & 31)) & 1) kp = NONE;                  // somebody else's already: that chain walks the rest
-                    else {
-                        const uint32_t c2 = (s_capl[kp >> 4] >> (2u * (kp & 15u))) & 3u;
-                        if (c2 == 0) mine = true;
-                        else {
-                            const uint32_t L = 3u - c2;
-                            WS_C(1, 1);
-                            a.keys[(uint32_t)(t0 - CH) + kp] = L << 16;     // (no distance: nothing of five bytes or fewer becomes a token, lzss.go:143)
-                            kp += max(1u, L);                               // lzss.go:139-142
-                        }
-                    }
-                }
-            }
-            uint32_t nrows = 0;
-            if (mine) {
-                const uint32_t irel = HWMAX + kp, capE = E - ((uint32_t)(t0 - CH) + kp);
-                const uint32_t w = lds_load4(sw, irel), key = tri_key(w);
-                uint32_t lo = key ? (uint32_t)ends[key - 1] : 0u, hi = ends[key];
-                const unsigned long long pat0 = lds_load8(sw, irel);
-                if (hi - lo > (uint32_t)RSN_WALK_NARROW) {                  // the bucket's entries are ordered by block: the first of the window's first block, the first behind the position's own
-                    const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
-                    uint32_t a1 = lo, b1 = hi, a2 = lo, b2 = hi;
-                    while (a1 < b1 || a2 < b2) {
-                        const uint32_t m1 = (a1 + b1) >> 1, m2 = (a2 + b2) >> 1;
-                        const uint32_t k1 = (uint32_t)s_list[min(m1, hi - 1)] >> (C::TAGB + CSH), k2 = (uint32_t)s_list[min(m2, hi - 1)] >> (C::TAGB + CSH);
-                        if (a1 < b1) { if (k1 < blk_lo) a1 = m1 + 1; else b1 = m1; }
-                        if (a2 < b2) { if (k2 <= blk_i) a2 = m2 + 1; else b2 = m2; }
-                    }
-                    lo = a1; hi = max(a2, a1);
-                }
-                nrows = (hi - lo + LW - 1) / LW;
-                WS_C(2, 1); WS_C(3, nrows);
-                *reinterpret_cast<uint4 *>(&ws.par[tid][0]) = uint4{irel, cand_q(irel, tri_tag(w)), (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
-                *reinterpret_cast<uint4 *>(&ws.par[tid][4]) = uint4{lo, hi, capE, kp};
-            } else ws.par[tid][7] = NONE;
-            ws.next[tid] = alive ? kp : DEAD;                               // (a HARD visit: S3 replaces it)
-            ws.nrows[tid] = nrows;
-        }
-        WS_T(4);
-        if (!__syncthreads_or(alive)) break;
-        WS_T(5);
-        if (tid == 0) WS_C(0, 1);
-        // ---- S2. all candidates of all visits, dealt in rows of LW entries over the block
-        {
-            const uint32_t n0 = ws.nrows[2 * lane], n1 = ws.nrows[2 * lane + 1];
-            uint32_t pre = n0 + n1;
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x111, 0xF, 0xF, true);
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x112, 0xF, 0xF, true);
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x114, 0xF, 0xF, true);
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, 0x118, 0xF, 0xF, true);
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false);
-            pre += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pre, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false);
-            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
-            // (every wavefront works the sums out for itself and writes the same values: no barrier for them)
-            ws.pre[2 * lane] = pre - n1; ws.pre[2 * lane + 1] = pre;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t g0 = 0; g0 < n_all; g0 += NCH) {
-                const uint32_t g = g0 + ch;
-                const bool row_ok = g < n_all;
-                // whose row: the first chain whose inclusive sum exceeds g -- sixteenths, then pairs, then one compare
-                uint32_t m = row_ballot<LW>(g < ws.pre[16 * rl + 15], lane);
-                const uint32_t seg = m ? (uint32_t)__builtin_ctz(m) : 7u;
-                m = row_ballot<LW>(g < ws.pre[16 * seg + 2 * rl + 1], lane);
-                const uint32_t c0 = 16 * seg + 2 * (m ? (uint32_t)__builtin_ctz(m) : 7u);
-                const uint32_t v0 = ws.pre[c0];
-                const uint32_t cc = g < v0 ? c0 : c0 + 1u;
-                const uint32_t before = g < v0 ? (c0 ? ws.pre[c0 - 1] : 0u) : v0;
-                const uint4 p0 = *reinterpret_cast<const uint4 *>(&ws.par[cc][0]), p1 = *reinterpret_cast<const uint4 *>(&ws.par[cc][4]);
-                const uint32_t idx = p1.x + (g - before) * LW + (uint32_t)rl;
-                const bool valid = row_ok && idx < p1.y;
-                const uint32_t e = s_list[valid ? idx : 0u];
-                const uint32_t rel = e >> C::TAGB, rot = cand_rot(p0.y, e), dn = rot + 1u;
-                const bool ok = valid && rot < W;
-                uint32_t lim = 0, off = 0;
-                unsigned long long x = 1;
-                if (ok) {
-                    lim = min(dn, p1.z);                                    // entirely inside the window, and inside the stream
-                    x = lds_load8(sw, rel) ^ ((unsigned long long)p0.z | ((unsigned long long)p0.w << 32));
-                    uint32_t room = x == 0 ? lim : 0u;
-                    while (off + 8 < room) {
-                        off += 8;
-                        x = lds_load8(sw, rel + off) ^ lds_load8(sw, p0.x + off);
-                        if (x != 0 || off + 8 >= HLMAX) room = 0;
-                    }
-                }
-                const bool fl = x == 0 && off + 8 >= HLMAX;                 // agrees further than the stage reaches: the home row follows it through memory
-                if (__ballot(fl)) {
-                    const uint32_t rm = row_ballot<LW>(fl, lane);
-                    if (rm) {
-                        const uint32_t far = row_max_u32<LW>(fl ? dn : 0u), first = (uint32_t)__builtin_ctz(rm);
-                        uint32_t k0 = 0;
-                        if ((uint32_t)rl == first) { k0 = atomicAdd(&ws.lcnt[cc], (uint32_t)__builtin_popcount(rm)); atomicMax(&ws.lfar[cc], far); }
-                        k0 = row_read<LW>(k0, first, lane);
-                        const uint32_t k = k0 + (uint32_t)__builtin_popcount(rm & ((1u << rl) - 1u));
-                        if (fl && k < LCAP) { ws.llist[cc][k][0] = dn | (lim << 16); ws.llist[cc][k][1] = off + 8; }
-                    }
-                }
-                const uint32_t nb = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                const uint32_t len = min(off + nb, lim);
-                const uint32_t rbest = row_max_u32<LW>(len >= 3u ? (len << 16) | dn : 0u);   // longest, then farthest back (bytes.Index, lzss.go:419); below three bytes: see S3
-                if (leader && rbest) atomicMax(&ws.best[cc], rbest);
-            }
-        }
-        WS_T(6);
-        __syncthreads();
-        WS_T(7);
-        // ---- S3. home rows (eight lanes per chain, all wavefronts): commit
-        const uint32_t kp = ws.par[ch][7];
-        if (kp != NONE) {
-            const uint32_t ipos = (uint32_t)(t0 - CH) + kp, irel = HWMAX + kp, capE = E - ipos;
-            uint32_t best = ws.best[ch];
-            const uint32_t lcnt = ws.lcnt[ch], long_far = ws.lfar[ch];
-            const bool longm = lcnt != 0;
-            if (leader) { ws.best[ch] = 0; if (longm) { ws.lcnt[ch] = 0; ws.lfar[ch] = 0; } }
-            auto first_diff = [&](uint32_t d, uint32_t from, uint32_t lim) -> uint32_t {
-                const uint8_t *pa = a.fc + (size_t)ipos, *pb = pa - d;
-                uint32_t mm = lim;
-                for (uint32_t q = from + 8u * (uint32_t)rl; q < lim && mm == lim; q += 8u * LW) {
-                    if (q + 8 <= lim) {
-                        unsigned long long u, v;
-                        __builtin_memcpy(&u, pa + q, 8); __builtin_memcpy(&v, pb + q, 8);
-                        if (u != v) mm = q + ((uint32_t)__builtin_ctzll(u ^ v) >> 3);
-                    } else for (uint32_t k = q; k < lim && mm == lim; k++) if (pa[k] != pb[k]) mm = k;
-                }
-                return ~row_max_u32<LW>(~mm);
-            };
-            bool giveup_heavy = false;
-            if (longm) {
-                if (lcnt <= LCAP) {                                       // every long candidate is followed to its end, farthest first
-                    uint32_t done = 0;
-                    for (uint32_t t = 0; t < lcnt; t++) {
-                        uint32_t pick = 0, dj = 0;
-                        for (uint32_t k = 0; k < lcnt; k++) {
-                            const uint32_t d = ws.llist[ch][k][0] & 0xFFFFu;
-                            if (!((done >> k) & 1u) && d > dj) { dj = d; pick = k; }
-                        }
-                        done |= 1u << pick;
-                        if ((best >> 16) > dj) break;
-                        best = max(best, (first_diff(dj, ws.llist[ch][pick][1], ws.llist[ch][pick][0] >> 16) << 16) | dj);
-                    }
-                } else {                                                  // runs, short periods: the farthest long candidate decides (see k_match_chain)
-                    const uint32_t Lp = min(long_far, capE);
-                    const uint32_t mm = first_diff(long_far, 0, Lp);
-                    if (mm == Lp) best = max(best, (Lp << 16) | long_far);
-                    else {
-                        const uint32_t want = a.fc[(size_t)ipos + mm];
-                        const uint32_t w = lds_load4(sw, irel), key = tri_key(w);
-                        const uint32_t blo = key ? (uint32_t)ends[key - 1] : 0u, bhi = ends[key];
-                        bool other = false;
-                        for (uint32_t idx = blo + rl; idx < bhi; idx += LW) {
-                            const uint32_t e = s_list[idx], rot = cand_rot(cand_q(irel, tri_tag(w)), e), dn = rot + 1u;
-                            if (rot < W && dn > mm && dn <= ipos && a.fc[(size_t)ipos - dn + mm] == want) other = true;
-                        }
-                        if (row_ballot<LW>(other, lane)) giveup_heavy = true;
-                        else best = max(best, (mm << 16) | long_far);
-                    }
-                }
-            }
-            if (best == 0 && !giveup_heavy) {
-                // nothing of three bytes: the exact answers for L <= 2 (a HARD position that was "not proven", or a bucket of strangers)
-                const uint32_t w = lds_load4(sw, irel), b0 = w & 0xFFu;
-                bool hit2 = false;
-                if (leader) WS_C(4, 1);
-                if (capE >= 2) {                                            // the bigram's eight buckets, a lane each: any entry in [i - W, i - 2] with these two bytes
-                    const uint32_t kb = (tri_key(w) & ~7u) + (uint32_t)rl;
-                    const uint32_t blo = kb ? (uint32_t)ends[kb - 1] : 0u, bhi = ends[kb];
-                    bool f = false;
-                    for (uint32_t idx = blo; __builtin_expect(row_ballot<LW>(idx < bhi && !f, lane) != 0, 0); idx++) {
-                        if (idx < bhi && !f) {
-                            const uint32_t rel2 = (uint32_t)s_list[idx] >> C::TAGB, dn = irel - rel2;
-                            if (dn >= 2u && dn <= W && ((lds_load4(sw, rel2) ^ w) & 0xFFFFu) == 0) f = true;
-                        }
-                        if (leader) WS_C(5, 1);
-                        if (row_ballot<LW>(f, lane)) break;
-                    }
-                    hit2 = row_ballot<LW>(f, lane) != 0;
-                }
-                if (hit2) best = 2u << 16;
-                else {
-                    const uint32_t wst = max(irel - min(W, irel), zrel);
-                    const uint32_t fb_lo = (wst + (1u << CSH) - 1) >> CSH, fb_hi = irel >> CSH;
-                    bool hit = false;
-                    if (fb_lo < fb_hi) {
-                        const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
-                        hit = (s_present[b0] & m) != 0;
-                    }
-                    if (!hit) {                                           // the two ragged ends, four bytes per lane and trip
-                        const uint32_t e1r = min(fb_lo << CSH, irel), s2 = max(min(fb_hi << CSH, irel), fb_lo < fb_hi ? wst : e1r);
-                        auto any_eq = [&](uint32_t q0_, uint32_t q1_) {
-                            bool f = false;
-                            for (uint32_t wq = (q0_ >> 2) + (uint32_t)rl; 4u * wq < q1_; wq += LW) {
-                                uint32_t m = bytes_equal(sw[wq], b0);
-                                const uint32_t p0 = 4u * wq;
-                                if (p0 < q0_) m &= 0xFFFFFFFFu << (8u * (q0_ - p0));
-                                if (p0 + 4u > q1_) m &= 0xFFFFFFFFu >> (8u * (p0 + 4u - q1_));
-                                f = f || m != 0;
-                            }
-                            return f;
-                        };
-                        const bool f = any_eq(wst, e1r) || any_eq(s2, irel);
-                        hit = row_ballot<LW>(f, lane) != 0;
-                    }
-                    best = hit ? (1u << 16) : 0u;
-                }
-            }
-            if (longm && !giveup_heavy && (best >> 16) == (best & 0xFFFFu) && leader) {
-                atomicAdd(&s_nstep, 1u); atomicMin(&s_stepmin, best & 0xFFFFu); atomicMax(&s_stepmax, best & 0xFFFFu);
-            }
-            if (giveup_heavy) {
-                if (leader) { atomicOr(&s_next, GIVE_UP); s_heavy = 1; ws.next[ch] = DEAD; }
-            } else if (leader) {
-                a.keys[ipos] = best;
-                ws.next[ch] = kp + max(1u, best >> 16);                   // lzss.go:139-142: a reference skips size-1 positions
-            }
-        }
-        WS_T(8);
-        __syncthreads();
-    }
-    __syncthreads();
-#ifdef RSN_WALK_STATS
-    if (a.stats) {
-        if (threadIdx.x == 0) { for (int i = 0; i < 9; i++) atomicAdd(&a.stats[i], wst[i]); atomicAdd(&a.stats[9], 1ull); }
-        for (int i = 0; i < 6; i++) if (wsc[i]) atomicAdd(&a.stats[10 + i], (unsigned long long)wsc[i]);
-    }
-#endif
-    // (the thread's index once more, opaque to the compiler: or what the prologue derived from it is kept for the epilogue's loops and,
-    //  the walk needing every register, spilled across it)
-    const int etid = (int)vec((uint32_t)threadIdx.x), elane = etid & 63, ewv = etid >> 6;
-    const ChainTail T = chain_tail();
-    if (etid == 0 && s_heavy) T.heavy[bx / (MATCH_STRIP / CT)] = 1;
-    if (etid == 0 && s_dense && !s_heavy) { T.dense[bx / (MATCH_STRIP / CT)] = 1; if (T.n_dense) atomicAdd(T.n_dense, 1u); }
-    if (s_heavy || s_dense) { if (etid == 0) { T.tchain[bx] = TileChain{0, 0, 0, 0}; T.step[bx] = 0; } return; }
-    {   // Every visit of this tile a match over its whole distance, and the same distance d: the stretch repeats with a period that d is
-        // the largest multiple of inside the window, every chain in it steps by d and keeps its phase -- the chains of neighbouring tiles
-        // never join.  The tile says so (step = d): k_stretch_pred then places the true chain by arithmetic and the next look walks it.
-        if (s_nstep == 0 || s_stepmin != s_stepmax) { if (etid == 0) T.step[bx] = 0; }   // (text: no such visit at all -- nothing to count)
-        else {
-            uint32_t cl = 0;
-            for (int i = etid; i < C::DUMP_BYTES / 4; i += CTH) cl += (uint32_t)__builtin_popcount(s_claim[i]);
-            for (int dd = 32; dd; dd >>= 1) cl += __shfl_down(cl, dd);
-            if (elane == 0) s_part[ewv] = cl;
-            __syncthreads();
-            if (etid == 0) {
-                uint32_t all = 0;
-                for (int k = 0; k < CTH / 64; k++) all += s_part[k];
-                T.step[bx] = s_nstep == all ? s_stepmin : 0u;
-            }
-        }
-    }
-
-    // ---- hand the claim bitmap to k_chain_tail (1 KB per tile): together with the keys it is all the in-tile parse needs
-    {
-        uint4 *dst = reinterpret_cast<uint4 *>(T.dump + (size_t)bx * C::DUMP_BYTES);
-        for (int i = etid; i < C::DUMP_BYTES / 16; i += CTH) dst[i] = reinterpret_cast<const uint4 *>(s_claim)[i];
-        if (etid == 0) T.tchain[bx] = TileChain{0, 0, 1u, kp_first};   // walked; entry and exit are k_chain_tail's to fill in
-    }
-    // ---- and for k_chain_serial, which follows the chain with one elane per tile: one record per claimed position, side by side in
-    //      position order -- its key, where it is, and WHICH RECORD the chain goes on with (the rank of the landing position among
-    //      the claims: a prefix popcount of the bitmap, here in LDS).  Through the position-indexed key array the elane would fetch
-    //      every line of it, 4 GB per GiB, for a fifth of their contents, and each step would wait for its load; the records it can
-    //      read a window ahead.  (The keys this block has just written come back from the L2.)
-    if (T.ckeys) {
-        constexpr int NWORDS = C::DUMP_BYTES / 4;
-        uint32_t *s_pre = s_cur;                                          // (the bucket index has served)
-        __syncthreads();
-        // (the keys first -- a thread takes every CTH-th position, its loads are all asked for before anything else: one round trip to the
-        //  L2 for the block, under the scan; a tile that turns out to have too many claims has read them for nothing)
-        constexpr int PER = (NWORDS * 32 + CTH - 1) / CTH;
-        const uint32_t *kb = a.keys + (t0 - CH);                              // (wave-uniform: a scalar base, 32-bit offsets)
-        uint32_t kv[PER];
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t kp = (uint32_t)etid + (uint32_t)j * CTH;
-            const bool on = kp < (uint32_t)NWORDS * 32u && ((s_claim[kp >> 5] >> (kp & 31)) & 1u);
-            kv[j] = on ? kb[kp] : 0xFFFFFFFFu;                                // (no key has a length of 65535)
-        }
-        {   // claims before every word of the bitmap: the first NWORDS / 64 wavefronts scan 64 words each, then add what lies before them
-            constexpr int NSW = (NWORDS + 63) / 64;
-            const int w = etid;
-            const uint32_t c = w < NWORDS ? (uint32_t)__builtin_popcount(s_claim[w]) : 0u;
-            uint32_t incl = c;
-            if (ewv < NSW) {
-                for (int dd = 1; dd < 64; dd <<= 1) {                         // (bpermute addresses from the opaque lane index: see above)
-                    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((elane - dd) << 2, (int)incl);
-                    if (elane >= dd) incl += y;
-                }
-                if (elane == 63) s_part[ewv] = incl;
-            }
-            lds_barrier();
-            if (ewv < NSW) {
-                uint32_t before = 0;
-                for (int k = 0; k < ewv; k++) before += s_part[k];
-                if (w < NWORDS) s_pre[w] = before + incl - c;
-                if (w == NWORDS - 1) s_pre[NWORDS] = before + incl;
-            }
-        }
-        lds_barrier();
-        const uint32_t total = s_pre[NWORDS];
-        const bool fits = total <= (uint32_t)CT / 2 && (s_claim[kp_first >> 5] >> (kp_first & 31)) & 1u;   // (8 bytes a record in a region of 4 CT)
-        if (fits) {
-            uint2 *ck = reinterpret_cast<uint2 *>(T.ckeys + (size_t)bx * CT);
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const uint32_t kp = (uint32_t)etid + (uint32_t)j * CTH, key = kv[j];
-                if (key != 0xFFFFFFFFu) {
-                    const uint32_t at = s_pre[kp >> 5] + (uint32_t)__builtin_popcount(s_claim[kp >> 5] & ((1u << (kp & 31)) - 1u));
-                    const uint32_t kp2 = kp + max(1u, key >> 16);
-                    uint32_t nr = CK_EXIT;                                // the chain leaves the tile
-                    if (kp2 < kp_end) {
-                        const uint32_t cw = s_claim[kp2 >> 5];
-                        nr = (cw >> (kp2 & 31)) & 1u ? s_pre[kp2 >> 5] + (uint32_t)__builtin_popcount(cw & ((1u << (kp2 & 31)) - 1u)) : CK_BROKEN;
-                    }
-                    ck[at] = uint2{key, nr | (kp << 14)};
-                }
-            }
-        }
-        if (etid == 0)   // the number of records, and the record of the warm-up start
-            T.ckn[bx] = fits ? total | ((s_pre[kp_first >> 5] + (uint32_t)__builtin_popcount(s_claim[kp_first >> 5] & ((1u << (kp_first & 31)) - 1u))) << 16) : NO_LIST;
-    }
-}
-
 // The chain inside a tile, resolved from k_match_chain's claim bitmap and the keys instead of by the general parse
 // (k_parse_exit .. k_parse_mark).  Every landing position of a walked chain was claimed and evaluated, so following
 // i -> i + max(1, L) from the warm-up start never leaves the claimed set: the claimed positions (about one in five)
@@ -3236,9 +2627,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     using CC = ChainCfg<8192, RSN_CHAIN_CTH, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
     // lanes per chain in k_match_chain: 8 or 16 = eight or four chains per wavefront, 64 = a wavefront per chain (RSN_LZSS_CHAIN_LANES, A/B)
     static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 || v == 4 ? v : 8; }();
-    static const bool old_walk = getenv("RSN_LZSS_OLD_WALK") != nullptr;   // A/B switch (r05): k_match_chain instead of k_match_walk
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
-        if (!old_walk) { RSN_LAUNCH(name, (k_match_walk<CC>), dim3(blocks), dim3(CC::CTH), 0, s, ca); return RSN_OK; }
         if (chain_lanes == 64) RSN_LAUNCH(name, (k_match_chain<CC, 64>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         else if (chain_lanes == 8) RSN_LAUNCH(name, (k_match_chain<CC, 8>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         else if (chain_lanes == 4) RSN_LAUNCH(name, (k_match_chain<CC, 4>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
@@ -3300,29 +2689,12 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             if (!no_ckeys && !tail_doubling && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
         }
         ChainArgs ha{d_fc, E, W, d_keys, halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
-#ifdef RSN_WALK_STATS
-        void *wstp; rc = dev_buf(c, 23, 128, &wstp); if (rc) return rc;
-        RSN_HIP(hipMemsetAsync(wstp, 0, 128, s));
-        ha.stats = (unsigned long long *)wstp;
-#endif
 #ifdef RSN_CHAIN_STATS
         void *stp; rc = dev_buf(c, 23, 128, &stp); if (rc) return rc;
         RSN_HIP(hipMemsetAsync(stp, 0, 128, s));
         ha.stats = (unsigned long long *)stp;
 #endif
         rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
-#ifdef RSN_WALK_STATS
-        {
-            unsigned long long hs[16];
-            RSN_HIP(hipMemcpyAsync(hs, wstp, 128, hipMemcpyDeviceToHost, s));
-            RSN_HIP(hipStreamSynchronize(s));
-            const double nb = (double)(hs[9] ? hs[9] : 1);
-            fprintf(stderr, "walk stats: %llu blocks; cycles per block as thread 0 sees them: stage %.0f, count+scan %.0f, scatter+bigrams %.0f, trigrams %.0f | walk: S1 %.0f, barrier %.0f, S2 %.0f, barrier %.0f, S3 %.0f\n",
-                    hs[9], hs[0] / nb, hs[1] / nb, hs[2] / nb, hs[3] / nb, hs[4] / nb, hs[5] / nb, hs[6] / nb, hs[7] / nb, hs[8] / nb);
-            fprintf(stderr, "walk stats: per block: rounds %.1f, cheap steps %.0f, hard visits %.0f, rows dealt %.0f (%.1f per visit), fall-backs %.1f with %.1f scan trips\n",
-                    hs[10] / nb, hs[11] / nb, hs[12] / nb, hs[13] / nb, (double)hs[13] / (double)(hs[12] ? hs[12] : 1), hs[14] / nb, hs[15] / nb);
-        }
-#endif
 #ifdef RSN_CHAIN_STATS
         {
             unsigned long long hs[16];
@@ -3507,10 +2879,10 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
     // ~12 bytes of scratch per position of a pass (keys 4, compact lists 4, chain records, the escaped stream, a section's copy) + the
     // escaped stream itself: small calls pass straight through, large ones are admitted one device-full at a time (rsn_api.hip)
     const size_t need = n < ((size_t)32 << 20) ? 0 : 13 * std::min(n, (size_t)3 << 29) + 2 * n;
-    if (need) (void)scratch_admit(c, need);
+    const size_t held = scratch_admit(c, need);                        // (0 inside a host-buffer call: that one's admission covers this need)
     const int rc = lzss_encode_admitted(c, s, d_in, n, window, d_out, out_cap, out_n);
     // (the encoder's scratch: slots 8..19, 22..27, 35, 36 -- not 20 / 21, the host-buffer entry points' staging, still in use by the caller)
-    if (need) scratch_release(c, need, (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35));
+    scratch_release(c, held, (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35));
     return rc;
 }
 

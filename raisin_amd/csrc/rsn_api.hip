@@ -141,6 +141,7 @@ ScratchGate g_gate[64];
 }  // namespace
 
 size_t scratch_admit(Ctx &c, size_t need) {
+    if (c.gate_held || need == 0) return 0;                               // inside a host-buffer call that stated staging + codec scratch up front (host_call)
     ScratchGate &g = g_gate[c.device & 63];
     std::unique_lock<std::mutex> lk(g.mu);
     if (g.cap == 0) {
@@ -158,10 +159,13 @@ size_t scratch_admit(Ctx &c, size_t need) {
         g.waiting--;
     }
     g.calls++; g.in_flight += need;
+    c.gate_held = need;
     return need;
 }
 
 void scratch_release(Ctx &c, size_t need, unsigned long long slots) {
+    if (need == 0) return;
+    c.gate_held = 0;
     ScratchGate &g = g_gate[c.device & 63];
     bool give_back;
     {
@@ -286,13 +290,22 @@ void result_free(void *p) {
 }
 
 // Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a library-owned result.
+// codec_need: what the codec itself will ask the gate for (its scratch besides the two staging buffers): stated HERE, before the
+// staging is allocated -- a call that waited behind the gate inside the codec already held n + 1.125 x bound bytes of staging, uncounted
+// (64 goroutines with 1 GiB each: 218 GiB next to the admitted 85 %), and the codec's own admission is covered by this one.
 template <class Fn>
-int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t bound, Fn fn) {
+int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t bound, size_t codec_need, Fn fn) {
     Ctx &c = ctx();
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
     int rc = ctx_init(c); if (rc) return rc;
     hipStream_t s = c.own_stream;
+    struct Admitted {                                                  // released, with the large buffers when others wait, on every way out
+        Ctx &c; size_t held;
+        ~Admitted() { scratch_release(c, held, (3ull << 20) | (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35)); }   // staging + the codecs' slots (8..19, 22..27, 35, 36)
+    };
+    const size_t total_need = round_up(n, 16) + 64 + bound + bound / 8 + codec_need;
+    Admitted gate{c, total_need >= ((size_t)64 << 20) ? scratch_admit(c, total_need) : 0};
     static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
     auto stamp = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_in = timing ? stamp() : 0;
@@ -436,7 +449,7 @@ int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_
 
 static int huffman_compress_single(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     // typical outputs are < n; the exact need is reported back on RSN_ERR_CAPACITY
-    return host_call(in, n, out, out_n, n + n / 8 + (1 << 16),
+    return host_call(in, n, out, out_n, n + n / 8 + (1 << 16), n / 32,
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return huff_encode_dev(c, s, di, n, dout, cap, got, nullptr, nullptr);
                      });
@@ -451,14 +464,15 @@ int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out
 }
 
 int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
-    return host_call(in, n, out, out_n, 4 * n + (1 << 16),
+    return host_call(in, n, out, out_n, 4 * n + (1 << 16), n / 8,
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return huff_decode_dev(c, s, di, n, dout, cap, got);
                      });
 }
 
 int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
-    return host_call(in, n, out, out_n, lzss_compress_bound(n),
+    // (the encoder's own statement of need, lzss_encode_dev: ~13 bytes of scratch per position of a pass + the escaped stream)
+    return host_call(in, n, out, out_n, lzss_compress_bound(n), n < ((size_t)32 << 20) ? 0 : 13 * std::min(n, (size_t)3 << 29) + 2 * n,
                      [n, window](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return lzss_encode_dev(c, s, di, n, window, dout, cap, got);
                      });
@@ -485,7 +499,9 @@ int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_
 }
 
 int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
-    return host_call(in, n, out, out_n, 8 * n + (1 << 16),
+    // (the decoder asks for 4 bytes per escaped byte from 64 MiB of them up, lzss_decode.hip: stated for an expansion of two -- text is 1.5;
+    //  a stream that expands further decodes inside this admission all the same)
+    return host_call(in, n, out, out_n, 8 * n + (1 << 16), n < ((size_t)32 << 20) ? 0 : 8 * n,
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return lzss_decode_dev(c, s, di, n, dout, cap, got);
                      });

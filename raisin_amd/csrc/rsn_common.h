@@ -39,6 +39,7 @@ struct Ctx {
     enum { N_BUFS = 38 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words; 35: k_esc_try's block flags; 36: an LZSS section's stream (encoder: the aligned copy; decoder: the escaped bytes in front + the section's tokens)
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
+    size_t gate_held = 0;           // scratch this thread's call in progress has been admitted with (rsn_api.hip: a nested admission is covered by it)
 
     ~Ctx();     // parks the device resources for the next thread (rsn_api.hip); makes no HIP call
 
@@ -55,8 +56,8 @@ int ctx_init(Ctx &c);                       // lazy: picks device, creates strea
 int dev_buf(Ctx &c, int slot, size_t bytes, void **out);   // grow-only scratch
 int pinned_buf(Ctx &c, size_t bytes, void **out);
 // admission of calls with gigabytes of scratch (rsn_api.hip): waits while the device's calls in flight need more than it holds
-size_t scratch_admit(Ctx &c, size_t need);
-void scratch_release(Ctx &c, size_t need, unsigned long long slots);         // ... and gives those slots' large buffers back when others wait (bit k = slot k)
+size_t scratch_admit(Ctx &c, size_t need);                                   // returns what to hand to scratch_release: `need`, or 0 inside a call that has been admitted already
+void scratch_release(Ctx &c, size_t held, unsigned long long slots);         // ... and gives those slots' large buffers back when others wait (bit k = slot k); held == 0: nothing to do
 void scratch_forget(Ctx &c, size_t bytes);
 unsigned long long scratch_queued(int device);                               // calls that have had to wait so far (tests)
 void prof_collect(Ctx &c);

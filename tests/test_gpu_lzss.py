@@ -745,3 +745,8 @@ def test_a_storm_of_large_calls_queues_instead_of_failing(oracle):
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.strip().startswith("OK"), r.stdout[-2000:]
     assert "waits" in r.stderr, r.stderr[-2000:]
+    # (the admission covers the host-buffer call's STAGING too -- n + 1.125 x bound next to the encoder's 15 n: a 64 MiB call
+    #  states 1.14 GiB, not the 0.94 of the codec alone)
+    import re
+    needs = [float(x) for x in re.findall(r"needs ([0-9.]+) GiB of scratch", r.stderr)]
+    assert needs and max(needs) >= 1.10, needs
