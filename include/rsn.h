@@ -118,8 +118,9 @@ RSN_API int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, si
  * string, and stores in *out_n a capacity that WOULD suffice (the exact size rounded up to 16, plus
  * 16: not the exact size); call again with a buffer of at least that many bytes, the second call
  * returns RSN_OK and the exact size.  rsn_lzss_decompress_dev and the two compress_dev calls follow
- * the same contract.  On RSN_ERR_FORMAT the contents of d_out are unspecified (the decoders write while
- * they validate; nothing is ever written outside [d_out, d_out + out_cap)).  (The Huffman query with d_out NULL is answered from the header's counts alone,
+ * the same contract.  On RSN_ERR_FORMAT and on RSN_ERR_CAPACITY the contents of d_out are unspecified (the decoders
+ * write while they validate, and what fits a too-small buffer may have been written before the total is known; nothing
+ * is ever written outside [d_out, d_out + out_cap)).  (The Huffman query with d_out NULL is answered from the header's counts alone,
  * without touching the payload: a foreign stream whose payload decodes to more than its header
  * announces reports the larger need on the call that follows.)                                  */
 RSN_API int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream);

@@ -713,6 +713,9 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
     const char *bd = getenv("RSN_BATCH_DEVICES");
     const int n_dev = std::max(1, std::min(visible, !bd || !*bd ? 1 : (!strcmp(bd, "all") ? visible : atoi(bd))));
     if (G <= 0) G = n_dev;
+    // (every slice is a thread with a stream and an arena of its own that meets the others at a barrier -- a few per device
+    //  is all that can overlap anything; 64 or 255 of them only left that many parked contexts behind)
+    G = std::min(G, std::max(16, 4 * n_dev));
     std::vector<size_t> cut;
     huff_slice_cuts(in, n, G, cut);                                       // on rune starts (huff_host.cpp: host logic, tested without a device)
     const size_t S = cut.size() - 1;                                      // slices
@@ -802,10 +805,15 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
     };
 
     std::vector<std::thread> threads;
-    for (size_t w = 1; w < S; w++) threads.emplace_back(worker, w);
+    try {
+        for (size_t w = 1; w < S; w++) threads.emplace_back(worker, w);
+    } catch (const std::exception &ex) {                                  // std::system_error must not leave an extern "C" entry point: the workers that did start stop at the barrier
+        sync.fail(RSN_ERR_NOMEM, (std::string("huffman: starting a slice's thread failed: ") + ex.what()).c_str());
+    }
     worker(0);                                                            // the caller is worker 0, on its own context
     for (auto &t : threads) t.join();
     (void)hipSetDevice(c.device);
+    trim_parked_excess(c.device);                                         // the workers have parked their contexts: no more of them than the limit stay
     if (sync.rc != RSN_OK) { if (res) result_free(res); return c.fail(sync.rc, "%s", sync.msg.c_str()); }
     for (auto &x : sl) if (x.has) { res[x.first] = 0; res[x.last] = 0; }
     for (auto &x : sl) if (x.has) { res[x.first] |= x.edge[0]; if (x.last != x.first) res[x.last] |= x.edge[1]; }

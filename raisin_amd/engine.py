@@ -100,10 +100,17 @@ def CompressFiles(algorithms, files, extension):
         i = 0
         while i < len(files):
             group, datas, size = [], [], 0
-            while i < len(files) and (not group or size + os.path.getsize(files[i]) <= BATCH_BYTES):
-                if os.path.getsize(files[i]) == 0:
-                    break                                        # an empty file ends the group: the loop below meets it in order
-                d = open(files[i], "rb").read()
+            bad = False                                          # files[i] is empty, missing or unreadable: the per-file call below meets it in order
+            while i < len(files):
+                try:
+                    fsize = os.path.getsize(files[i])
+                    if fsize == 0 or (group and size + fsize > BATCH_BYTES):
+                        bad = fsize == 0
+                        break
+                    d = open(files[i], "rb").read()
+                except OSError:                                  # (a file that cannot be read ends the group -- the ones before it are
+                    bad = True                                   #  compressed and written first, as the reference's loop would have, engine.go:150-154)
+                    break
                 group.append(files[i]); datas.append(d); size += len(d); i += 1
             outs = None
             if len(group) > 1:
@@ -121,7 +128,7 @@ def CompressFiles(algorithms, files, extension):
                     print("Original bytes: %d" % len(data))
                     print("Compressed bytes: %d" % len(out))
                     print("Compression ratio: %.2f%%" % (len(out) / len(data) * 100 if data else float("nan")))
-            if i < len(files) and os.path.getsize(files[i]) == 0:
+            if bad:
                 CompressFile(algorithms, files[i], files[i] + extension)   # raises like the reference panics; the earlier files are written
                 i += 1
         return

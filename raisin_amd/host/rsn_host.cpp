@@ -204,14 +204,14 @@ int main(int argc, char **argv) {
             if (algorithm.empty()) algorithm = "lzss,huffman";   // reference default "lzss,arithmetic" (cli.go:99); arithmetic is not on this path
             const auto algs = split(algorithm, ',');
             auto out_name = [&](const std::string &f) { return files.size() == 1 ? (out.empty() ? f + ".rsn" : out) : f + "." + (outext.empty() ? "rsn" : outext); };   // cli.go:108-112
-            auto one_file = [&](const std::string &f) {            // engine.CompressFile, engine.go:157-172
+            auto one_data = [&](const std::string &f, const Bytes &data) {   // engine.CompressFile, engine.go:157-172, the file's bytes in hand
                 const std::string o = out_name(f);
-                const Bytes data = read_file(f);
                 printf("Compressing...\n");
                 const Bytes c = engine::compress(data, algs);
                 write_file(o, c);
                 printf("Original bytes: %zu\nCompressed bytes: %zu\nCompression ratio: %.2f%%\n", data.size(), c.size(), (float)c.size() / (float)data.size() * 100.f);   // engine.go:166-169
             };
+            auto one_file = [&](const std::string &f) { one_data(f, read_file(f)); };
             if (files.size() > 1 && algs.size() == 1 && algs[0] == "huffman") {
                 // engine.CompressFiles loops over the files, one .rsn each (engine.go:150-154).  Independent inputs of one Huffman layer go
                 // through the batch entry point -- upload, encode and download overlapped on the device (and dealt over devices with
@@ -220,11 +220,19 @@ int main(int argc, char **argv) {
                 // is done again by the loop, which stops at the failing file with everything before it on disk.
                 constexpr size_t BATCH_BYTES = (size_t)4 << 30;
                 size_t i = 0;
+                Bytes held; bool have_held = false;                 // a file that overflowed the group before: read once, kept for this group
                 while (i < files.size()) {
                     std::vector<std::string> group; std::vector<Bytes> datas; size_t size = 0;
+                    bool bad = false;                               // files[i] is empty or cannot be read: the loop's turn below, in order
                     while (i < files.size()) {
-                        Bytes d = read_file(files[i]);
-                        if (d.empty() || (!group.empty() && size + d.size() > BATCH_BYTES)) break;
+                        Bytes d;
+                        if (have_held) { d = std::move(held); have_held = false; }
+                        else {
+                            try { d = read_file(files[i]); }
+                            catch (const std::exception &) { bad = true; break; }   // (the group read so far is compressed and written first, engine.go:150-154)
+                        }
+                        if (d.empty()) { bad = true; break; }
+                        if (!group.empty() && size + d.size() > BATCH_BYTES) { held = std::move(d); have_held = true; break; }
                         size += d.size(); group.push_back(files[i]); datas.push_back(std::move(d)); i++;
                     }
                     bool done = false;
@@ -242,8 +250,8 @@ int main(int argc, char **argv) {
                             done = true;
                         }
                     }
-                    if (!done) for (auto &f : group) one_file(f);
-                    if (group.empty() && i < files.size()) one_file(files[i++]);   // an empty (or alone oversized) file: the loop's turn, in order
+                    if (!done) for (size_t k = 0; k < group.size(); k++) one_data(group[k], datas[k]);   // (what was read is not read again)
+                    if (bad) one_file(files[i++]);                  // throws where the reference panics; everything before it is on disk
                 }
             } else
             for (auto &f : files) one_file(f);

@@ -1,4 +1,6 @@
-cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+#!/bin/bash
+# GPU box: the Huffman decoder's warm-up length (RSN_DEC_WARM) on `skewed` and config 4
+cd "${GRAFT_REPO_ROOT:-$(pwd)}" || exit 1
 run() {
   python bench.py --profile-only skewed,4 2>/dev/null | python -c "
 import json,sys

@@ -105,6 +105,18 @@ def test_list_of_files_keeps_the_loops_semantics_when_one_fails(tmp_path, oracle
     for k in (0, 1):
         assert open(paths[k] + ".huf", "rb").read() == oracle.huffman_compress(datas[k])
     assert not os.path.exists(paths[3] + ".huf")
+    # the same for a file that cannot be READ -- a missing third file ends the group, the two before it are compressed and written
+    missing = [paths[0], paths[1], str(tmp_path / "not_there.txt"), paths[3]]
+    with pytest.raises(OSError):
+        engine.CompressFiles(["huffman"], missing, ".mis")
+    for k in (0, 1):
+        assert open(paths[k] + ".mis", "rb").read() == oracle.huffman_compress(datas[k])
+    assert not os.path.exists(paths[3] + ".mis")
+    r = subprocess.run([exe, "-compress", ",".join(missing), "-algorithm=huffman", "-outext=mi2"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout.count("Compressing...") >= 2
+    for k in (0, 1):
+        assert open(paths[k] + ".mi2", "rb").read() == oracle.huffman_compress(datas[k])
+    assert not os.path.exists(paths[3] + ".mi2")
     old = engine.BATCH_BYTES                                  # groups: three files of which no two fit one group -> three single calls, same bytes
     engine.BATCH_BYTES = len(samiam) * 2
     try:

@@ -166,6 +166,37 @@ def test_size_query_checks_the_stream_and_cannot_overflow(huff):
     assert huff.Decompress(huge) == bytes(b"ab"[(b >> (7 - k)) & 1] for b in range(100) for k in range(8))
 
 
+def test_a_buffer_that_is_too_small_is_never_overrun(huff):
+    """the emit pass is queued before the host has seen the total (one sync per call), so a too-small buffer may be partly
+    written before RSN_ERR_CAPACITY comes back (rsn.h says so) -- but never past out_cap: a canary behind the buffer stays, for the
+    general decoder (skewed codes, multi-block), the flat one, and a stream whose payload ends inside a codeword (RSN_ERR_FORMAT)."""
+    import torch
+    from raisin_amd import _lib
+    rng = np.random.default_rng(7)
+    skew = bytes((rng.geometric(0.25, size=1 << 20).clip(max=60) + 32).astype(np.uint8))
+    flat = bytes(rng.integers(0, 128, size=1 << 20, dtype=np.uint8))
+    for data in (skew, flat):
+        comp = huff.Compress(data)
+        src = torch.frombuffer(bytearray(comp + b"\0" * 64), dtype=torch.uint8).cuda()
+        for cap in (16, 4096, 65536 + 16, len(data) // 2 // 16 * 16, len(data) - 16 - len(data) % 16):
+            buf = torch.full((cap + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+            got = ctypes.c_size_t(0)
+            rc = _lib.lib().rsn_huffman_decompress_dev(src.data_ptr(), len(comp), buf.data_ptr(), cap, ctypes.byref(got), None)
+            torch.cuda.synchronize()
+            assert rc == _lib.RSN_ERR_CAPACITY and got.value >= len(data), (rc, cap)
+            assert bool((buf[cap:] == 0xA5).all()), cap
+        # a payload cut inside a codeword: FORMAT or a shorter output, never a write past the buffer
+        cut = comp[:len(comp) - len(comp) // 3]
+        src2 = torch.frombuffer(bytearray(cut + b"\0" * 64), dtype=torch.uint8).cuda()
+        cap = len(data) // 2 // 16 * 16
+        buf = torch.full((cap + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        got = ctypes.c_size_t(0)
+        rc = _lib.lib().rsn_huffman_decompress_dev(src2.data_ptr(), len(cut), buf.data_ptr(), cap, ctypes.byref(got), None)
+        torch.cuda.synchronize()
+        assert rc in (_lib.RSN_ERR_CAPACITY, -3), rc
+        assert bool((buf[cap:] == 0xA5).all())
+
+
 def test_device_resident_round_trip_256MiB(huff):
     import torch
     n = 1 << 28
