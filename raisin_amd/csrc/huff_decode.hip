@@ -34,20 +34,14 @@
 namespace rsn {
 
 
-#ifndef RSN_DEC_DB
-#define RSN_DEC_DB 256
-#endif
-constexpr int DB = RSN_DEC_DB;      // lanes per block
+constexpr int DB = 256;             // lanes per block (r04: 384 / 640 lanes load the SIMDs unevenly and lose a third, 512 ties)
 constexpr int FDB = 256;            // lanes per block of k_dec_flat
 constexpr int SW = 8;               // 32-bit words per subsequence (S = 256 bits; 128: emit 5 % faster, sync 40 % slower -- its warm-up is per subsequence)
 constexpr int SBITS = SW * 32;
 constexpr int ORG_WORDS = 8;              // words staged in front of the block: warm-up room for the entry guess
 constexpr int ORG = ORG_WORDS * 32;       // block-relative bit positions are offset by this
 constexpr int DATA_WORDS = ORG_WORDS + DB * SW + 8;   // + overrun for a code that starts inside and ends outside
-#ifndef RSN_LUT_BITS
-#define RSN_LUT_BITS 11
-#endif
-constexpr int LUT_BITS_MAX = RSN_LUT_BITS;
+constexpr int LUT_BITS_MAX = 11;    // index bits of the first-level table (r04: 10 bits lose 9 % on `skewed`)
 constexpr int LUT_WORDS = 1 << LUT_BITS_MAX;
 constexpr int OUT_STAGE = DB * 64;  // bytes of block output staged in LDS (larger blocks store directly)
 constexpr int OUT_STAGE_RUNE = 40960; // the same for rune alphabets: a rune is up to four bytes (two blocks per CU instead of four, but coalesced stores)
@@ -73,11 +67,7 @@ struct DecArgs {
     const unsigned long long *blk_off; uint8_t *out;   // D3
     uint32_t child_n;           // entries of child[]
     const uint32_t *lut2; uint32_t lut2_n;   // second level: sub-tables for the K-bit prefixes that lead inside the tree
-    // the one-pass decoder (k_dec_fused)
-    unsigned long long *status;      // per tile: flag << 62 | bytes (decoupled look-back)
-    uint32_t *ticket; uint32_t n_tiles; uint32_t slotw;   // tiles are handed out in order; words per lane slot
-    unsigned long long *tile_entry, *tile_exit;           // absolute bit positions, for the joint check
-    unsigned long long out_cap; unsigned long long *total_out; int *flags;   // flags[0] joint mismatch, [1] payload ends inside a code, [2] capacity
+    unsigned long long out_cap;
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t j) { return j + (j >> 5); }
@@ -287,10 +277,6 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_exit[DB];
     __shared__ unsigned long long s_part[DB / 64];
     __shared__ int s_skip;
-#ifdef RSN_DEC_LDS_PAD
-    __shared__ uint32_t s_padding[RSN_DEC_LDS_PAD / 4];
-    if (a.n_sub == 0xFFFFFFFFu) s_padding[threadIdx.x] = 1;   // (occupancy probe: keeps the array alive)
-#endif
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
     const int tid = threadIdx.x;
@@ -452,12 +438,7 @@ __device__ __forceinline__ void emit_walk(const DecArgs &a, const uint32_t *s_da
     }
 }
 
-// TIMING PROBE (-DRSN_EMIT_PROBE_PLAIN, wrong output): plain stores instead of the ORs -- what the LDS atomics cost the walk
-#ifdef RSN_EMIT_PROBE_PLAIN
-#define RSN_EMIT_WORD(p, v) (*(p) = (v))
-#else
 #define RSN_EMIT_WORD(p, v) atomicOr((p), (v))
-#endif
 template <bool ASCII, bool SHORT, bool MULTI>
 __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
@@ -467,10 +448,6 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
     __shared__ uint32_t s_wsum[DB / 64];
     __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
     __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
-#ifdef RSN_DEC_LDS_PAD
-    __shared__ uint32_t s_padding[RSN_DEC_LDS_PAD / 4];
-    if (a.n_sub == 0xFFFFFFFFu) s_padding[threadIdx.x] = 1;
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
     const uint32_t my0 = ORG + tid * SBITS;
@@ -560,219 +537,6 @@ __global__ __launch_bounds__(DB) void k_dec_emit(DecArgs a, uint32_t n_blk) {
             if (ASCII) *reinterpret_cast<uint4 *>(s_out + b0) = make_uint4(0, 0, 0, 0);   // the ORs of the next block need a zeroed image
         }
     }
-}
-
-// ---------------------------------------------------------------- one pass: k_dec_fused
-// D1 + D2 + D3 above decode every symbol twice -- once to count (k_dec_sync), once to write (k_dec_emit) -- and both walks are
-// bound by vector issue (~23 lane-instructions per symbol each, profiles/r03h_valu_skewed.txt).  This kernel decodes once:
-//   * a TILE is 256 lanes x 256 bits like a k_dec_sync block, but only the last OWN = 254 subsequences are its own: the first
-//     OV = 2 lanes decode the previous tile's last subsequences again, so the first own lane's entry comes out of 128 bits of
-//     warm-up + 512 bits of walk and the in-block fixed point -- a guess that self-synchronisation makes right except with
-//     negligible probability; nothing is exchanged between tiles to get it.  It is CHECKED afterwards (k_dec_joints: every
-//     tile's entry == its predecessor's exit; by induction from tile 0's exact entry the parse is then the true one) and the
-//     three-kernel path runs instead when a joint fails: the result never rests on the guess.
-//   * the walk that finds the exits also WRITES the symbols, into a slot of the lane's own in LDS (a lane cannot know its
-//     output offset before every lane has counted); lanes whose entry is corrected walk again, as in k_dec_sync;
-//   * the tile's byte count is published (one 8-byte word: flag | count) and its output offset comes from a decoupled
-//     look-back over the predecessors' words -- tiles are handed out through a ticket counter, so a tile's predecessors
-//     always belong to running blocks and the wait cannot deadlock whatever the residency;
-//   * the slots are compacted in place (registers -> zeroed image -> ORs at the byte offset) and leave as 16-byte stores.
-// Byte alphabets with a shortest code of >= 3 bits (a slot holds the <= 86 symbols of 256 bits).
-constexpr int OV = 2, OWN = DB - OV;
-constexpr int SLOTW_MAX = 22;
-constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1;
-
-__device__ __forceinline__ unsigned long long st_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// advance() that keeps what it decodes: the symbols of [pos, lim) go to `slot` as bytes, four at a time
-template <bool SHORT>
-__device__ __forceinline__ uint32_t slot_walk(const DecArgs &a, const uint32_t *s_data, const uint32_t *s_lut, uint32_t lane_r, const Lut2 &l2,
-                                              uint32_t &pos, uint32_t lim, uint32_t *slot) {
-    unsigned long long acc = 0;
-    uint32_t cnt = 0, nb = 0;
-    const uint32_t K = (uint32_t)a.K, safe = lim >= K ? lim - K : 0;
-    while (pos <= safe && lim >= K) {                             // a whole K-bit window inside the subsequence: up to three codewords
-        const uint32_t win = window32(s_data, pos);
-        const uint32_t e = lut_at(a, s_lut, win, lane_r);
-        uint32_t bytes, take;
-        if (!SHORT && (e & 0x80000000u)) { bytes = decode_long(a, s_data, win, e, pos, l2); take = 1; }
-        else { bytes = u_bytes(e); take = u_n(e); pos += u_used(e); }
-        acc |= (unsigned long long)bytes << (8 * cnt);
-        cnt += take; nb += take;
-        if (cnt >= 4) { *slot++ = (uint32_t)acc; acc >>= 32; cnt -= 4; }
-    }
-    while (pos < lim) {                                           // the last codewords one by one: the next one may start past lim
-        const uint32_t r = decode_one<true, SHORT>(a, s_data, s_lut, lane_r, pos, l2);
-        acc |= (unsigned long long)r << (8 * cnt);
-        cnt++; nb++;
-        if (cnt >= 4) { *slot++ = (uint32_t)acc; acc >>= 32; cnt -= 4; }
-    }
-    if (cnt) *slot = (uint32_t)acc;                               // (bytes above cnt are zero: acc holds nothing else)
-    return nb;
-}
-
-template <bool SHORT>
-__global__ __launch_bounds__(DB) void k_dec_fused(DecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_slots[];   // DB * slotw words (+ 8): the lanes' slots, then the output image
-    __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];   // (the alignment puts it first in the LDS: its address is an instruction offset, not an add)
-    __shared__ uint32_t s_lut[LUT_WORDS];
-    __shared__ uint32_t s_exit[DB];
-    __shared__ uint32_t s_wsum[DB / 64];
-    __shared__ uint32_t s_tile;
-    __shared__ unsigned long long s_lb[DB / 64];
-    __shared__ uint32_t s_lbp[DB / 64];
-    __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
-    __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
-    const uint32_t my0 = ORG + tid * SBITS;
-    const uint32_t slotw = a.slotw;
-    uint32_t *slot = s_slots + tid * slotw;
-    stage_lut(a, s_lut);
-    if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
-    const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
-    if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
-    if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
-    __syncthreads();
-    uint32_t tile = s_tile;
-    while (tile < a.n_tiles) {
-        uint32_t next = 0;
-        if (tid == 0) next = atomicAdd(a.ticket, 1u);               // the next tile's ticket is on its way while this one is decoded
-        const long long sub0 = (long long)tile * OWN - OV;          // lane 0's subsequence (negative in tile 0: those lanes idle)
-        const long long g = sub0 + tid;
-        const bool live = g >= 0 && g < (long long)a.n_sub;
-        const bool own = live && tid >= OV;
-        const long long blk_bit0 = sub0 * SBITS;
-        const long long p0_rel = (long long)a.p0 - blk_bit0 + ORG;
-        const uint32_t end_rel = (uint32_t)min((long long)a.end - blk_bit0 + ORG, (long long)(ORG + DB * SBITS + 4096));
-        const uint32_t lim = min(my0 + SBITS, end_rel);
-        stage_words(a, sub0 * SW - ORG_WORDS, s_data);
-        __syncthreads();
-        uint32_t e;
-        const bool fixed = g == 0;                                  // the stream's first code: exact
-        if (!live) e = BAD_POS;
-        else if (fixed) e = (uint32_t)p0_rel;
-        else {
-            const uint32_t start = (uint32_t)max(p0_rel, (long long)my0 - a.warm);
-            uint32_t q = start;
-            (void)advance<true, SHORT, true>(a, s_data, s_lut, lane_r, l2, q, my0, (uint32_t)tid);
-            e = q;
-        }
-        bool have = false;
-        uint32_t x = 0, nb = 0;
-        for (int round = 0; round <= DB; round++) {
-            if (live && !have) {
-                if (e == BAD_POS) { x = BAD_POS; nb = 0; }
-                else { uint32_t pos = e; nb = slot_walk<SHORT>(a, s_data, s_lut, lane_r, l2, pos, lim, slot); x = pos > end_rel ? BAD_POS : pos; }
-                have = true;
-            }
-            s_exit[tid] = x;
-            __syncthreads();
-            bool changed = false;
-            if (live && tid > 0 && !fixed) {
-                const uint32_t en = s_exit[tid - 1];
-                if (en != e) { e = en; have = false; changed = true; }       // (g >= 1 here: the lane before is live too)
-            }
-            if (!__syncthreads_or(changed)) break;
-        }
-        // what the joint check needs: where the first own lane entered, where the last one left (absolute bit positions)
-        auto abs_pos = [&](uint32_t rel) -> unsigned long long { return rel == BAD_POS ? ~0ull : (unsigned long long)(blk_bit0 + (long long)rel - ORG); };
-        if (tid == OV) a.tile_entry[tile] = abs_pos(e);
-        if (live && (tid == DB - 1 || g == (long long)a.n_sub - 1)) {
-            a.tile_exit[tile] = abs_pos(x);
-            if (g == (long long)a.n_sub - 1 && x != lim) a.flags[1] = 1;                 // the payload ends inside a codeword
-        }
-        const uint32_t nbo = own ? nb : 0;
-        uint32_t incl = nbo;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        uint32_t wpre = 0, total = 0;
-        for (int k = 0; k < DB / 64; k++) { if (k < wv) wpre += s_wsum[k]; total += s_wsum[k]; }
-        const uint32_t my_off = wpre + incl - nbo;
-        unsigned long long base_bytes;
-        // ---- the tile's offset: publish the count, then look back over the predecessors' words, 256 at a time (one per lane: a
-        //      step costs a round trip to the memory side, ~2 us, whatever its width, and the nearest inclusive prefix lies as far
-        //      back as tiles finish during one look-back -- a 64-wide window needed a dozen steps, 4.5 ms per GiB instead of 1)
-        if (tid == 0 && tile > 0) st_store(&a.status[tile], ST_AGG | total);
-        {
-            unsigned long long excl = 0;
-            long long idx = (long long)tile - 1;
-#ifdef RSN_DEC_PROBE
-            if (a.pass == 99) { excl = (unsigned long long)tile * 12288; idx = -1; }   // timing probe: no look-back (output misplaced)
-#endif
-            while (idx >= 0) {
-                const long long j = idx - tid;
-                unsigned long long v = ST_PREFIX;                   // before tile 0: an inclusive prefix of zero
-                if (j >= 0) { v = st_load(&a.status[j]); while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(4); v = st_load(&a.status[j]); } }
-                const unsigned long long has_prefix = __ballot((v >> 62) == 2);
-                const int first = has_prefix ? __builtin_ctzll(has_prefix) : 64;
-                unsigned long long part = lane <= first ? (v & ST_MASK) : 0;
-                for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d);
-                if (lane == 0) { s_lb[wv] = part; s_lbp[wv] = has_prefix != 0; }
-                __syncthreads();
-                bool found = false;
-                for (int k = 0; k < DB / 64 && !found; k++) { excl += s_lb[k]; found = s_lbp[k] != 0; }
-                __syncthreads();                                    // s_lb is read; the next window may overwrite it
-                if (found) break;
-                idx -= DB;
-            }
-            if (tid == 0) {
-                st_store(&a.status[tile], ST_PREFIX | (excl + total));
-                if (tile == a.n_tiles - 1) *a.total_out = excl + total;
-            }
-            base_bytes = excl;
-        }
-        // ---- compaction: own slot -> registers, zero, OR at the byte offset
-        uint32_t w[SLOTW_MAX + 1];
-#pragma unroll
-        for (int j = 0; j < SLOTW_MAX; j++) {
-            uint32_t v = 0;
-            if (j < (int)slotw && 4u * j < nbo) v = slot[j];
-            if (4u * j + 4 > nbo && 4u * j < nbo) v &= 0xFFFFFFFFu >> (32 - 8 * (nbo - 4u * j));
-            w[j] = v;
-        }
-        w[SLOTW_MAX] = 0;
-        __syncthreads();                                            // every slot is in registers
-        for (uint32_t i = tid; i < (DB * slotw + 8) / 4; i += DB) reinterpret_cast<uint4 *>(s_slots)[i] = make_uint4(0, 0, 0, 0);
-        const unsigned long long base = base_bytes;
-        uint8_t *dst = a.out + base;
-        const uint32_t al = (uint32_t)((uintptr_t)dst & 15);
-        __syncthreads();
-        if (nbo) {
-            const uint32_t D = al + my_off, sh = 32 - 8 * (D & 3), nw = ((D & 3) + nbo + 3) >> 2;
-            uint32_t *o = s_slots + (D >> 2);
-            uint32_t prev = 0;
-#pragma unroll
-            for (int j = 0; j <= SLOTW_MAX; j++) {
-                if (j < (int)nw) atomicOr(o + j, (uint32_t)((((unsigned long long)w[j] << 32) | prev) >> sh));
-                prev = w[j];
-            }
-        }
-        __syncthreads();
-        const bool fits = base + total <= a.out_cap;
-        if (!fits && tid == 0) a.flags[2] = 1;
-        if (fits) {
-            const uint32_t span = al + total;
-            uint8_t *gbase = dst - al;
-            const uint8_t *img = reinterpret_cast<const uint8_t *>(s_slots);
-            for (uint32_t u = tid; u * 16 < span; u += DB) {
-                const uint32_t b0 = u * 16;
-                if (b0 >= al && b0 + 16 <= span) *reinterpret_cast<uint4 *>(gbase + b0) = *reinterpret_cast<const uint4 *>(img + b0);
-                else for (uint32_t k = max(b0, al); k < min(b0 + 16, span); k++) gbase[k] = img[k];
-            }
-        }
-        if (tid == 0) s_tile = next;
-        __syncthreads();                                            // the image is drained; the next tile is known
-        tile = s_tile;
-    }
-}
-
-// every tile's first own lane must have entered where the previous tile's last own lane left
-__global__ void k_dec_joints(const unsigned long long *tile_entry, const unsigned long long *tile_exit, uint32_t n_tiles, int *flags) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (t < n_tiles && tile_entry[t] != tile_exit[t - 1]) flags[0] = 1;
 }
 
 // ---------------------------------------------------------------- F: flat codes
@@ -1020,12 +784,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // A large alphabet (config 2b: 3*10^5 runes) spends milliseconds both on the code lengths and on the lookup tables; neither needs
     // the other -- more than 2^11 leaves means codes longer than any first-level table, so K is known -- so a second host thread
     // builds the tables meanwhile.
-    static const int k_env = [] { const char *e = getenv("RSN_DEC_K"); return e ? std::min(std::max(atoi(e), 4), LUT_BITS_MAX) : LUT_BITS_MAX; }();   // tuning switch: index bits of the first-level table
-    static const bool no_lut2 = getenv("RSN_DEC_NO_LUT2") != nullptr;   // A/B switch: codes longer than K bits walk the tree bit by bit
+    constexpr int k_env = LUT_BITS_MAX;                                 // index bits of the first-level table, at most
     std::vector<uint32_t> lut, lut2; std::vector<int32_t> child;
     const bool prebuilt = tree.n_leaves > 4096;
     std::thread table_builder;
-    if (prebuilt) table_builder = std::thread([&] { build_tables(tree, k_env, lut, child); if (!no_lut2) build_second_level(child, k_env, false, lut, lut2); });
+    if (prebuilt) table_builder = std::thread([&] { build_tables(tree, k_env, lut, child); build_second_level(child, k_env, false, lut, lut2); });
     const bool codes_ok = assign_codes(tree, codes, msg, false);
     if (prebuilt) table_builder.join();
     if (!codes_ok) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
@@ -1077,9 +840,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // ---- tables
     // First-level index bits.  Rune alphabets: the longest code, capped.  Byte alphabets (r04): room for THREE codewords -- an entry
     // lists up to three, and with K = the longest code a text alphabet (longest code 7, mean 4.4 bits) got 1.6 symbols out of a
-    // lookup where 11 bits hold 2.4; smaller tables are replicated across the LDS banks as before.  RSN_DEC_KWIDE=0: the old rule.
-    static const bool k_wide = !(getenv("RSN_DEC_KWIDE") && atoi(getenv("RSN_DEC_KWIDE")) == 0);
-    const int K = (int)std::min<unsigned>(ascii && k_wide ? std::max(codes.max_len, 3u * codes.min_len + 2u) : codes.max_len, (unsigned)k_env);
+    // lookup where 11 bits hold 2.4; smaller tables are replicated across the LDS banks as before.
+    const int K = (int)std::min<unsigned>(ascii ? std::max(codes.max_len, 3u * codes.min_len + 2u) : codes.max_len, (unsigned)k_env);
     const bool short_codes = codes.max_len <= (unsigned)K;
     if (!prebuilt) build_tables(tree, K, lut, child);
     const auto t4 = now();
@@ -1106,7 +868,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             lut[v] = u_entry(syms, used, nsym, len1);                             // nsym >= 1 here: the first codeword fits
         }
     }
-    if (!prebuilt && !short_codes && !no_lut2) build_second_level(child, K, ascii, lut, lut2);
+    if (!prebuilt && !short_codes) build_second_level(child, K, ascii, lut, lut2);
     const auto t5 = now();
     {   // the device reads the stream LSB-first: first-level entry v moves to the index with v's K bits reversed
         //     (the second level is built in that order, see build_second_level)
@@ -1115,7 +877,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         lut.swap(t);
     }
     if (host_timing) fprintf(stderr, "huffman decode host: first level + child array %.2f ms, second level %.2f ms (%zu entries), bit-reversal %.2f ms\n", ms(t3, t4), ms(t4, t5), lut2.size(), ms(t5, now()));
-    static const bool dbg = getenv("RSN_DEC_DEBUG") != nullptr;
+    static const bool dbg = getenv("RSN_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "huffman decode tables: K %d, longest code %u, %zu tree nodes, second level %zu entries (%s)\n", K, codes.max_len, child.size() / 2, lut2.size(), lut2.size() <= (size_t)LUT2_LDS ? "LDS" : "L2");
     rc = dev_buf(c, 5, (lut.size() + child.size() + lut2.size()) * 4 + 64, &p); if (rc) return rc;
     uint32_t *d_lut = (uint32_t *)p;
@@ -1149,53 +911,6 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
 
-    // ---- one pass (k_dec_fused): byte alphabets whose shortest code is >= 3 bits; checked afterwards, the three kernels below
-    //      run instead if a tile's guessed entry was not its predecessor's exit
-    //      MEASURED AND LEFT OFF (r04, 1 GiB `skewed`): 4.1 ms against 1.84 for the three kernels.  Without the look-back (offsets
-    //      faked: RSN_DEC_PROBE build) the kernel takes 1.79 ms -- its slots cost a block 22 KB of LDS, three blocks share a CU
-    //      instead of four / seven, and the walks are as latency-bound as they are issue-bound -- and the in-order look-back adds
-    //      2.3 ms: every tile waits for its predecessor's count, so a tile that needs another round holds up all 768 resident
-    //      blocks behind it, and they hold their LDS while they wait.  RSN_DEC_FUSED=1 turns it on (bit-identical, tested).
-    static const bool use_fused = getenv("RSN_DEC_FUSED") != nullptr && atoi(getenv("RSN_DEC_FUSED")) != 0;
-    if (ascii && codes.min_len >= 3 && use_fused) {
-        const uint32_t cap_syms = (uint32_t)ceil_div(SBITS, codes.min_len);
-        uint32_t slotw = (uint32_t)ceil_div(cap_syms, 4);
-        if (!(slotw & 1) && slotw + 1 <= (uint32_t)SLOTW_MAX) slotw++;       // an odd lane stride spreads the slots over the banks
-        a.n_tiles = (uint32_t)ceil_div(a.n_sub, OWN);
-        a.slotw = slotw;
-        const size_t head_bytes = (size_t)a.n_tiles * 8 + 64;                // status words, then total / ticket / flags: zeroed per call
-        rc = dev_buf(c, 34, head_bytes + (size_t)a.n_tiles * 16 + 64, &p); if (rc) return rc;
-        a.status = (unsigned long long *)p;
-        a.total_out = a.status + a.n_tiles;
-        a.ticket = (uint32_t *)(a.total_out + 1);
-        a.flags = (int *)(a.ticket + 1);
-        a.tile_entry = (unsigned long long *)((uint8_t *)p + head_bytes);
-        a.tile_exit = a.tile_entry + a.n_tiles;
-        a.out = d_out; a.out_cap = out_cap;
-        RSN_HIP(hipMemsetAsync(p, 0, head_bytes, s));
-        const size_t dyn = ((size_t)DB * slotw + 8) * 4;
-#ifdef RSN_DEC_PROBE
-        if (getenv("RSN_DEC_FUSED_NOLB")) a.pass = 99;
-#endif
-        static const uint32_t fgrid_env = [] { const char *e = getenv("RSN_DEC_FUSED_GRID"); return e ? (uint32_t)std::max(atoi(e), 1) : 256u * 4u; }();
-        const uint32_t fgrid = std::min<uint32_t>(a.n_tiles, fgrid_env);
-        if (short_codes) RSN_LAUNCH("huff_dec_fused", (k_dec_fused<true>), dim3(fgrid), dim3(DB), dyn, s, a);
-        else RSN_LAUNCH("huff_dec_fused", (k_dec_fused<false>), dim3(fgrid), dim3(DB), dyn, s, a);
-        if (a.n_tiles > 1) RSN_LAUNCH("huff_dec_joints", k_dec_joints, dim3((uint32_t)ceil_div(a.n_tiles, 256)), dim3(256), 0, s, a.tile_entry, a.tile_exit, a.n_tiles, a.flags);
-        struct FusedTail { unsigned long long total; uint32_t ticket; int flags[3]; };
-        FusedTail *ft = (FusedTail *)hp;
-        RSN_HIP(hipMemcpyAsync(ft, a.total_out, sizeof(FusedTail), hipMemcpyDeviceToHost, s));
-        RSN_HIP(hipStreamSynchronize(s));
-        if (!ft->flags[0]) {
-            if (ft->flags[1]) return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
-            const size_t total = (size_t)ft->total;
-            *out_n = total;
-            if (ft->flags[2] || total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
-            return RSN_OK;
-        }
-        if (dbg) fprintf(stderr, "huffman decode: a tile's guessed entry was not its predecessor's exit -- decoding again with the three-kernel path\n");
-    }
-
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;
     rc = dev_buf(c, 7, ((size_t)n_blk * 2 + 4) * 8 + (size_t)n_blk * 4 + 64, &p); if (rc) return rc;
@@ -1206,9 +921,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     uint32_t *d_fix_count = (uint32_t *)(d_changed + 1);                 // (zeroed together with `changed`)
     uint32_t *d_fix_list = (uint32_t *)(d_total + 4);
     a.changed = d_changed;
-    static const bool no_fix_list = getenv("RSN_DEC_NO_FIX_LIST") != nullptr;   // A/B switch: every block of a fixing pass looks for itself
 
-    static const uint32_t grid_env = [] { const char *e = getenv("RSN_DEC_GRID"); return e ? (uint32_t)std::max(atoi(e), 1) : 256u * 8u * 2u; }();   // tuning switch: persistent blocks
+    constexpr uint32_t grid_env = 256u * 8u * 2u;                        // persistent blocks: two waves of them per CU slot
     const uint32_t grid_p = std::min<uint32_t>(n_blk, grid_env);          // persistent blocks: the LUT is staged once per block
     auto launch_sync = [&]() -> int {
         const char *nm = a.pass == 0 ? "huff_dec_sync" : a.pass == 1 ? "huff_dec_sync_fix" : "huff_dec_sync_verify";
@@ -1254,10 +968,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (n_blk > 1) {                                                  // (a single block starts from the exact entry and iterates to its fixed point in LDS)
         a.pass = 1;
         RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
-        if (!no_fix_list) {
-            RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
-            a.fix_list = d_fix_list; a.fix_count = d_fix_count;
-        }
+        RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
+        a.fix_list = d_fix_list; a.fix_count = d_fix_count;
         rc = launch_sync(); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
     }
@@ -1270,7 +982,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
             a.pass = (int)pass;
             RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
-            if (!no_fix_list) RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
+            RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
             rc = launch_sync(); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));

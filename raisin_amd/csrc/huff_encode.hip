@@ -838,9 +838,8 @@ int hist_ascii_or_rune(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uin
     unsigned long long *d_rh = (unsigned long long *)p;
     RSN_HIP(hipMemsetAsync(d_rh, 0, (size_t)kMaxRune * 8, s));
     const size_t rounds = ceil_div(n, ROUND);
-    static const bool no_map = getenv("RSN_HUFF_NO_START_MAP") != nullptr;   // A/B switch: the later passes classify the input again
     uint16_t *d_smask = nullptr;
-    if (!no_map) { rc = dev_buf(c, 26, (ceil_div(n, 16) + 2) * 2 + 64, &p); if (rc) return rc; d_smask = (uint16_t *)p; }
+    { rc = dev_buf(c, 26, (ceil_div(n, 16) + 2) * 2 + 64, &p); if (rc) return rc; d_smask = (uint16_t *)p; }
     *smask_out = d_smask;
     RSN_LAUNCH("huff_rune_hist", k_rune_hist, dim3((uint32_t)std::min<size_t>(rounds, 4096)), dim3(HB), 0, s, d_in, n, d_rh, d_smask);
     // the present runes, compacted in rune order (see k_rune_flags)
@@ -882,15 +881,14 @@ size_t huff_compress_bound(size_t n) {
 // rune-start map).  huff_slice_emit: the slice's code bits at a given bit position of d_out, from the tree and codes of the WHOLE
 // input.  huff_encode_dev is the two in a row for a single slice.
 int huff_slice_hist(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, HuffSlice &sl) {
-    static const bool no_small_tiles = getenv("RSN_HUFF_NO_SMALL_TILES") != nullptr;   // A/B switch
-    sl.tile = n <= SMALL_INPUT && !no_small_tiles ? SMALL_TILE : TILE;
+    sl.tile = n <= SMALL_INPUT ? SMALL_TILE : TILE;
     sl.n_tiles = (uint32_t)ceil_div(n, sl.tile);
     void *p;
     int rc = dev_buf(c, 0, (size_t)sl.n_tiles * 128 * 4, &p); if (rc) return rc;
     sl.d_tile_hist = (uint32_t *)p;
     sl.d_smask = nullptr;                                                 // rune path: which positions start a rune (k_rune_hist's classification, kept)
     rc = hist_ascii_or_rune(c, s, d_in, n, sl.n_tiles, sl.tile, sl.d_tile_hist, sl.syms, sl.ascii, &sl.d_smask); if (rc) return rc;
-    if (!sl.ascii && !no_small_tiles && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
+    if (!sl.ascii && n <= RUNE_SMALL_INPUT) {   // the rune path has no per-tile histograms to pay for: small tiles longer (8 MiB: 413 -> 353 us)
         sl.tile = SMALL_TILE;
         sl.n_tiles = (uint32_t)ceil_div(n, sl.tile);
     }
@@ -994,12 +992,7 @@ int huff_slice_emit(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, const 
     RSN_LAUNCH("huff_emit_init", k_emit_init, dim3((uint32_t)ceil_div(n_blocks + 1, 256)), dim3(256), 0, s,
                (uint32_t *)d_out, d_tile_off, base_bits, tiles_per_block, n_tiles, n_blocks, base_bits + slice_bits);
     if (H) RSN_HIP(hipMemcpyAsync(d_out, hdr.data(), H, hipMemcpyHostToDevice, s));
-    static const bool emit16 = getenv("RSN_EMIT16") != nullptr;   // A/B switch: the 16-symbols-per-lane generic kernel
-    static const int emit_spl = [] { const char *e = getenv("RSN_EMIT_SPL"); return e ? atoi(e) : 32; }();
-    if (mode == MODE_ASCII && !emit16 && emit_spl == 64) RSN_LAUNCH("huff_emit", k_emit_ascii32<64>, dim3(n_blocks), dim3(HB), 0, s, a);
-    else if (mode == MODE_ASCII && !emit16 && emit_spl == 48) RSN_LAUNCH("huff_emit", k_emit_ascii32<48>, dim3(n_blocks), dim3(HB), 0, s, a);
-    else if (mode == MODE_ASCII && !emit16) RSN_LAUNCH("huff_emit", k_emit_ascii32<32>, dim3(n_blocks), dim3(HB), 0, s, a);
-    else if (mode == MODE_ASCII) RSN_LAUNCH("huff_emit", k_emit<MODE_ASCII>, dim3(n_blocks), dim3(HB), 0, s, a);
+    if (mode == MODE_ASCII) RSN_LAUNCH("huff_emit", k_emit_ascii32<32>, dim3(n_blocks), dim3(HB), 0, s, a);   // (32 symbols a lane: 48 / 64 measured no better, r02)
     else if (mode == MODE_ASCII_WIDE) RSN_LAUNCH("huff_emit_wide", k_emit<MODE_ASCII_WIDE>, dim3(n_blocks), dim3(HB), 0, s, a);
     else RSN_LAUNCH("huff_emit_rune", k_emit<MODE_RUNE>, dim3(n_blocks), dim3(HB), 0, s, a);
     RSN_HIP(hipStreamSynchronize(s));   // hdr (host memory) must outlive the copy

@@ -3,18 +3,18 @@
 // Replaces lz.Decompress (compressor/lz/lzss.go:323-364) and
 // DecodeOpeningSymbols (:391-406).
 //
-//   L1 k_lzd_count / k_lzd_expand   parse "<ptr,len>" tokens in parallel ('<' never
+//   L1 k_lzd_count2 / k_lzd_expand  parse "<ptr,len>" tokens in parallel ('<' never
 //        occurs in literals: EncodeOpeningSymbols maps it to FF, lzss.go:373-377), scan
 //        the output lengths, then give every escaped-stream byte a SOURCE: itself for a
 //        literal, position-ptr for a byte produced by a token.
 //   L2 a token may copy bytes that were themselves produced by a token (the reference resolves
 //        that by running serially, lzss.go:349-353).  Tile path (every back-pointer <= DT):
-//          k_lzd_tiles    validate the tokens, find the item that starts every DT-byte output tile
+//          k_lzd_check / k_lzd_tilemap (k_lzd_tiles for streams with huge tokens)   validate the tokens, find the item that starts every DT-byte output tile
 //          k_lzd_resolve  one block per tile: parse its items into LDS descriptors (literal /
 //                         position inside the tile / position in the previous tile's tail),
 //                         pointer-jump the in-tile references inside LDS
-//          k_lzd_compose / k_lzd_chain   tails only depend on the previous tail: compose the
-//                         tail maps of 32 tiles, chain the groups serially (a few MB in total)
+//          k_lzd_compose / k_lzd_mapscan   tails only depend on the previous tail: compose the
+//                         tail maps of a group of tiles, scan the groups' maps under composition (a few MB in total)
 //          k_lzd_emit     per group, tile after tile: literal or byte of the previous tail
 //        Fallback for larger pointers: k_lzd_expand / k_lzd_jump / k_lzd_gather, pointer
 //        jumping src[p] = src[src[p]] over the whole stream in HBM.
@@ -301,27 +301,6 @@ __device__ __forceinline__ int stage_block(const uint8_t *__restrict__ in, size_
     return left >= 16 ? 16 : left > 0 ? (int)left : 0;
 }
 
-__global__ __launch_bounds__(ZB) void k_lzd_count(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, int *__restrict__ err) {
-    __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
-    __shared__ uint32_t masks[ZB + 3], cdm[ZB + 3];
-    __shared__ unsigned long long part[ZB / 64];
-    Span r;
-    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, cdm, r);
-    unsigned long long mine = 0;
-    if (valid) {
-        span_parse(sw, masks, cdm, threadIdx.x, ZPAD + 16 * threadIdx.x, valid, r);
-        mine = r.out;
-        if (r.err) atomicOr(err, 1);
-    }
-    // err[4]: the stream holds a 5C byte somewhere (tokens are digits and punctuation, so that is a literal of the escaped stream: an
-    // escape marker or an escaped backslash).  Without one, DecodeOpeningSymbols is the byte map FF -> '<' and k_lzd_emit applies it.
-    if (__ballot(valid && mask_5c(r.w) != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(&err[4], __ATOMIC_RELAXED) == 0) atomicOr(&err[4], 1);
-    for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) blk_len[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-}
-
 __global__ __launch_bounds__(ZB) void k_lzd_expand(const uint8_t *__restrict__ in, size_t n, const unsigned long long *__restrict__ blk_off,
                                                    uint32_t *__restrict__ src, uint8_t *__restrict__ esc, int *__restrict__ err) {
     __shared__ unsigned long long wsum[ZB / 64];
@@ -603,7 +582,6 @@ __global__ __launch_bounds__(256) void k_lzd_tilemap(const uint8_t *__restrict__
 constexpr int RT_ITEMS = 32, RT_RUNS = 64;                                // most tokens of a run tile, most runs after resolving them
 constexpr int RT_BYTES = 448;                                             // most input bytes of a run tile (32 tokens of up to 13 bytes, and room to see a 33rd)
 struct ResolveArgs { const uint8_t *in; size_t n; const uint2 *tile_info; uint32_t n_tiles, E, TL; uint16_t *desc; int *fallback;
-                     unsigned long long *stats;      // RSN_LZD_STATS: cycles per phase, summed over blocks
                      uint32_t *rt_cnt, *rt_runs; };  // per tile: 0 = descriptors, else the number of runs; RT_RUNS words per tile
 
 __global__ __launch_bounds__(64) void k_lzd_runs(const uint8_t *__restrict__ in, size_t n, const uint2 *__restrict__ tile_info, uint32_t n_tiles, uint32_t E, uint32_t TL,
@@ -688,10 +666,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     // (r02 marked every literal with its own byte: 16 address computations and 16 LDS stores per lane where a span holds one or two runs.)
     constexpr uint32_t NONE = 0u, M_LIT = 0x8000u, M_TOK = 0x4000u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long t_prev = a.stats ? __builtin_amdgcn_s_memtime() : 0;
-    auto phase_done = [&](int q) {                                        // RSN_LZD_STATS: cycles of the phase that just ended (thread 0's view)
-        if (a.stats) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&a.stats[q], now - t_prev); t_prev = now; }
-    };
     const uint32_t k = blockIdx.x, ts = k * DT;
     const uint32_t is_run_tile = a.rt_cnt ? a.rt_cnt[k] : 0u;             // (arrives together with the tile's record below)
     const int tlen = (int)min((uint32_t)DT, a.E - ts);
@@ -711,7 +685,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     }
     for (int v = tid; v < DT / 8; v += DTH) reinterpret_cast<uint4 *>(sd)[v] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    phase_done(0);
     const int TL = (int)a.TL;
     // ---- A: every item marks the output position it starts at -- a literal with its byte, a token with D_LOC | (ptr - 1).
     // every token here has 1 <= len <= ptr <= DT (k_lzd_tiles checked it), so 32-bit offsets cannot overflow
@@ -733,10 +706,8 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             masks[DTH + 2] = ltgt_masks(w); cdm[DTH + 2] = c_mask(w);
         }
         __syncthreads();
-        phase_done(6);
         uint32_t mine = 0;
         if (valid) { span_parse<true>(sw, masks, cdm, tid, sbyte, valid, r); mine = r.out; }
-        phase_done(7);
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
         if (lane == 63) s_part[wv] = incl;
@@ -749,7 +720,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
             tot = (uint32_t)__builtin_amdgcn_readlane((int)ws, DTH / 64 - 1);
             if (wv) o += (int)(uint32_t)__builtin_amdgcn_readlane((int)ws, wv - 1);
         }
-        phase_done(8);
         if (valid && o < tlen) {
             for (uint32_t st = r.lit & ~(r.lit << 1); st; st &= st - 1) {   // the first literal of every run of literals in the span
                 const int j = __builtin_ctz(st);
@@ -773,7 +743,6 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         run += (int)tot;
     }
     __syncthreads();
-    phase_done(1);
     // ---- B: a lane owns 16 consecutive output positions.  The item a position belongs to is the last mark at or before it
     // (fill forward: a scan with "rightmost mark" inside the lane, across the wavefront, across the block), and a token's
     // bytes get their descriptor from the position and the token's back-pointer alone.
@@ -858,16 +827,13 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
     __syncthreads();                                                      // every lane has read its marks
     write_back();
     __syncthreads();
-    phase_done(2);
     // ---- C: in-tile pointer jumping, the lane's 16 descriptors in registers (packed in pairs, as B left them); only the unresolved
     // ones -- bits 15:14 == 01: D_LOC -- read LDS, two hops a round.
     // (A reader may see another lane's descriptor before or after that lane's update of the same round: both name the same byte.
     //  Giving lane t the positions t, t + DTH, ... instead -- consecutive lanes on consecutive addresses -- measured slower.)
     auto loc_halves = [&](uint32_t d) { return pk_sign((d << 1) & ~d); }; // 0xFFFF in a half that holds a D_LOC descriptor
     const uint8_t *sdb = reinterpret_cast<const uint8_t *>(sd);
-    uint32_t rounds = 0;
     for (;;) {
-        rounds++;
         uint32_t um[8], any = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) { um[k] = loc_halves(dp[k]); any |= um[k]; }
@@ -893,10 +859,7 @@ __global__ __launch_bounds__(DTH, 8) void k_lzd_resolve(ResolveArgs a) {   // 8 
         }
         if (!__syncthreads_or(any != 0)) break;
     }
-    phase_done(3);
     for (int v = tid; v * 8 < tlen; v += DTH) st16<(RSN_NT_MASK & 32) != 0>(reinterpret_cast<uint4 *>(a.desc + ts) + v, reinterpret_cast<const uint4 *>(sd)[v]);
-    phase_done(4);
-    if (a.stats && tid == 0) atomicAdd(&a.stats[5], (unsigned long long)rounds);
 }
 
 // C_g = the tail map of the group's last tile expressed in the tail that precedes the group
@@ -979,31 +942,6 @@ __global__ __launch_bounds__(DTH) void k_lzd_compose(const uint16_t *__restrict_
 }
 
 // gtail[g] = the bytes of the tail that ends group g: one block walks the groups in order
-__global__ __launch_bounds__(DTH) void k_lzd_chain(const uint16_t *__restrict__ comp, uint32_t TL, uint32_t n_links, uint8_t *__restrict__ gtail) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dsm[];
-    uint8_t *prev = dsm, *val = dsm + TL;
-    constexpr int PER = DT / DTH;                                         // TL <= DT: at most this many entries per lane
-    for (uint32_t j = threadIdx.x; j < TL; j += DTH) prev[j] = 0;
-    uint32_t m[PER], mn[PER];
-#pragma unroll
-    for (int q = 0; q < PER; q++) { const uint32_t j = threadIdx.x + q * DTH; m[q] = j < TL && n_links ? comp[j] : 0; mn[q] = 0; }
-    __syncthreads();
-    for (uint32_t g = 0; g < n_links; g++) {
-        if (g + 1 < n_links) {                                            // the next group's map is in flight during this step
-#pragma unroll
-            for (int q = 0; q < PER; q++) { const uint32_t j = threadIdx.x + q * DTH; if (j < TL) mn[q] = comp[(size_t)(g + 1) * TL + j]; }
-        }
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const uint32_t j = threadIdx.x + q * DTH;
-            if (j < TL) { const uint8_t b = (m[q] & D_EXT) ? prev[m[q] & D_PAY] : (uint8_t)m[q]; val[j] = b; gtail[(size_t)g * TL + j] = b; }
-        }
-        __syncthreads();
-        uint8_t *sw = prev; prev = val; val = sw;
-#pragma unroll
-        for (int q = 0; q < PER; q++) m[q] = mn[q];
-    }
-}
 
 // The same without the serial walk: an inclusive scan of the group maps under composition.  After the round with stride d, map g
 // is expressed in the tail that precedes group g - 2d + 1 (or in nothing at all: only literals left); ceil(log2(links)) rounds of
@@ -1367,13 +1305,10 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
     unsigned long long *h64 = (unsigned long long *)hp;
     volatile int *hflag = (volatile int *)(h64 + 1);
     RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));                          // ... [4] the stream holds a 5C byte, [5] a span produces 65535 bytes or more
-    static const bool three_pass = getenv("RSN_LZSS_DEC_3PASS") != nullptr;   // A/B switch: r02's front end (count, scan, then k_lzd_tiles parsing everything again)
     uint16_t *d_span = nullptr; unsigned long long *d_need = nullptr;
-    if (!three_pass) {
-        rc = dev_buf(c, 27, (size_t)n_cb * ZB * 2 + (size_t)n_cb * 8 + 64, &p); if (rc) return rc;
-        d_need = (unsigned long long *)p; d_span = (uint16_t *)(d_need + n_cb);
-        RSN_LAUNCH("lzss_dec_count", k_lzd_count2, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_span, d_need, (uint32_t *)(d_flag + 2), d_flag);
-    } else RSN_LAUNCH("lzss_dec_count", k_lzd_count, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_flag);
+    rc = dev_buf(c, 27, (size_t)n_cb * ZB * 2 + (size_t)n_cb * 8 + 64, &p); if (rc) return rc;
+    d_need = (unsigned long long *)p; d_span = (uint16_t *)(d_need + n_cb);
+    RSN_LAUNCH("lzss_dec_count", k_lzd_count2, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_blen, d_span, d_need, (uint32_t *)(d_flag + 2), d_flag);
     rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
@@ -1384,7 +1319,7 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         if (esc_dst) return c.fail(RSN_ERR_LIMIT, "lzss: decoded stream too large for one call");
         return lzss_decode_sections(c, s, d_in, n, d_out, out_cap, out_n);   // (counts again: a stream of 4 GiB does not notice)
     }
-    const bool one_pass = !three_pass && hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
+    const bool one_pass = hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
     DecGate gate(c);
@@ -1393,8 +1328,7 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         *out_n = round_up((size_t)E, 16) + 16;
         return c.fail(RSN_ERR_CAPACITY, "lzss: output needs at most %u bytes", E);
     }
-    static const bool no_plain = getenv("RSN_LZSS_DEC_UNESCAPE") != nullptr;   // A/B switch: always the separate unescape passes
-    const bool plain = hflag[4] == 0 && !no_plain && !esc_dst;          // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
+    const bool plain = hflag[4] == 0 && !esc_dst;          // no 5C anywhere: unescaping is FF -> '<', done by k_lzd_emit on its way out
     uint8_t *d_esc = esc_dst;
     if (!d_esc) { rc = dev_buf(c, 15, (size_t)E + 64, &p); if (rc) return rc; d_esc = (uint8_t *)p; }
     const uint32_t n_ub = (uint32_t)ceil_div(E, ZTILE);                 // unescape blocks
@@ -1413,7 +1347,7 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         RSN_LAUNCH("lzss_dec_tiles", k_lzd_check, dim3((uint32_t)ceil_div(n_cb, 256)), dim3(256), 0, s, (const unsigned long long *)d_need, (const unsigned long long *)d_boff, n_cb, d_flag);
         RSN_LAUNCH("lzss_dec_tiles", k_lzd_tilemap, dim3((uint32_t)ceil_div(n_tiles, 4)), dim3(256), 0, s, d_in, n, (const unsigned long long *)d_boff, n_cb, (const uint16_t *)d_span, n_tiles, d_tinfo);
     } else {
-        if (!three_pass) RSN_HIP(hipMemsetAsync(d_maxptr, 0, 4, s));      // (k_lzd_tiles raises it again)
+        RSN_HIP(hipMemsetAsync(d_maxptr, 0, 4, s));      // (k_lzd_tiles raises it again)
         RSN_LAUNCH("lzss_dec_tiles", k_lzd_tiles, dim3(n_cb), dim3(ZB), 0, s, d_in, n, d_boff, d_tinfo, d_maxptr, d_flag);
         RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 16, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));   // nothing may chase a pointer before every token has been validated
@@ -1435,19 +1369,9 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
             rc = dev_buf(c, 23, (size_t)n_tiles * (RT_RUNS + 1) * 4 + 128, &p); if (rc) return rc;
             d_rt_runs = (uint32_t *)p; d_rt_cnt = d_rt_runs + (size_t)n_tiles * RT_RUNS;
         }
-        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, nullptr, d_rt_cnt, d_rt_runs};
-        static const bool lzd_stats = getenv("RSN_LZD_STATS") != nullptr;
-        if (lzd_stats) { void *sp; rc = dev_buf(c, 25, 128, &sp); if (rc) return rc; RSN_HIP(hipMemsetAsync(sp, 0, 128, s)); ra.stats = (unsigned long long *)sp; }
+        ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, d_rt_cnt, d_rt_runs};
         if (d_rt_cnt) RSN_LAUNCH("lzss_dec_runs", k_lzd_runs, dim3(n_tiles), dim3(64), 0, s, d_in, n, (const uint2 *)d_tinfo, n_tiles, E, TL, d_rt_cnt, d_rt_runs);
         RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
-        if (lzd_stats) {
-            unsigned long long hs[16];
-            RSN_HIP(hipMemcpyAsync(hs, ra.stats, 128, hipMemcpyDeviceToHost, s));
-            RSN_HIP(hipStreamSynchronize(s));
-            fprintf(stderr, "lzss_dec_resolve, cycles per tile: staging %.0f, parse + item marks %.0f, fill forward %.0f, pointer jumping %.0f (%.2f rounds), store %.0f\n",
-                    (double)hs[0] / n_tiles, (double)hs[1] / n_tiles, (double)hs[2] / n_tiles, (double)hs[3] / n_tiles, (double)hs[5] / n_tiles, (double)hs[4] / n_tiles);
-            fprintf(stderr, "  parse + item marks in parts: masks + exchange %.0f, span parse %.0f, scan %.0f, marks %.0f\n", (double)hs[6] / n_tiles, (double)hs[7] / n_tiles, (double)hs[8] / n_tiles, (double)hs[1] / n_tiles);
-        }
         static thread_local size_t attr_tl = 0;
         if ((size_t)TL * 4 > attr_tl) {
             RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lzd_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TL * 4)));
@@ -1455,10 +1379,8 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         }
         if (n_groups > 1) {
             RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, dgrp, d_comp, (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);
-            static const bool serial_chain = getenv("RSN_LZSS_DEC_SERIAL_CHAIN") != nullptr;   // A/B switch: one block walks the groups in order
             const uint32_t n_links = n_groups - 1;
-            if (serial_chain) RSN_LAUNCH("lzss_dec_chain", k_lzd_chain, dim3(1), dim3(DTH), (size_t)TL * 2, s, d_comp, TL, n_links, d_gtail);
-            else {
+            {
                 const uint16_t *cur = d_comp; uint16_t *oth = d_comp2;
                 for (uint32_t d = 1; d < n_links; d <<= 1) {
                     RSN_LAUNCH("lzss_dec_chain", k_lzd_mapscan, dim3(n_links), dim3(256), 0, s, cur, oth, TL, d);

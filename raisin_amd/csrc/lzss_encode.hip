@@ -12,7 +12,7 @@
 //        k_match_hash  common case (W <= 4096): bigram buckets in LDS, work proportional to how
 //                      often a bigram recurs in the window; exact, hands pathological strips back
 //        k_match2      general case / hand-backs: diagonal sweep, O(1) per (position, distance)
-//                      pair whatever the data (k_match: the older 32-bit form, A/B only)
+//                      pair whatever the data (two diagonals per lane, lengths only: the distance is recovered where it matters)
 //   E3 k_parse_exit / k_parse_super / k_parse_chain / k_parse_fill / k_parse_mark
 //                  the greedy chain of lzss.go:136-151 (position i is visited iff no earlier
 //                  visited reference covers it), without a serial walk over the stream
@@ -34,7 +34,6 @@ int lzss_encode_big(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint
 constexpr int LB = 256;                 // threads per block
 constexpr int ESC_TILE = LB * 16;       // input bytes per escape block
 constexpr int MATCH_STRIP = 16384;      // positions per match block
-constexpr int MATCH_WAVES = 4;          // each takes a quarter of the diagonals
 constexpr int PT = 8192;                // positions per parse tile
 constexpr uint32_t MAX_WINDOW = 8192;
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
@@ -207,119 +206,8 @@ struct MatchArgs {
 #define RSN_DPP_WAVE_SHL1 0x130   // lane i <- lane i+1
 #define RSN_DPP_WAVE_SHR1 0x138   // lane i <- lane i-1
 
-// One step of one lane: lanes 0..62 take the run of the lane above (position+1, same
-// diagonal), lane 63 takes the carry; key = min(run,d)<<16 | d folded into the maximum.
-template <bool MASKED>
-__device__ __forceinline__ void match_step(uint32_t X, uint32_t Y, uint32_t cin16, uint32_t &R16, uint32_t &Bd, uint32_t &best,
-                                           bool valid) {
-    const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)cin16, (int)R16, RSN_DPP_WAVE_SHL1, 0xF, 0xF, false);
-    bool eq = X == Y;
-    if (MASKED) eq = eq && valid;
-    R16 = eq ? sh + 0x10000u : 0u;
-    Bd += 0x10001u;
-    const uint32_t key = min((Bd & 0xFFFFu) | R16, Bd);   // min(run,d)<<16 | d
-    best = max(best, key);
-}
-
-// 64 steps t0..t0+63 of one wavefront.  MASKED: some lanes are outside this wave's
-// diagonal range (first/last 63 steps).  CHECKED: the candidate index may fall outside
-// the stream (only position blocks next to the start or the end of the stream).
-template <bool MASKED, bool CHECKED>
-__device__ __forceinline__ void match_chunk(const uint8_t *ybase, long long y0, uint32_t E, uint32_t t0, uint32_t nsteps, uint32_t DWk,
-                                            int lane, uint32_t X, uint32_t vCin, uint32_t &vCout, uint32_t &R16, uint32_t &Bd, uint32_t &best) {
-#pragma unroll
-    for (int k = 0; k < 64; k++) {
-        const uint32_t t = t0 + k;
-        if (!MASKED || t < nsteps) {
-            uint32_t Y = ybase[-(int)t];
-            if (CHECKED) { const long long y = y0 - (long long)t; if (y < 0 || y >= (long long)E) Y = 0x200; }
-            const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)vCin, k);
-            const bool valid = !MASKED || (t + (uint32_t)lane - 63u) < DWk;   // local diagonal index in [0, DWk)
-            match_step<MASKED>(X, Y, cin, R16, Bd, best, valid);
-        }
-        // collect lane 0's run: shift the collector up one lane, lane 0 <- R16[0]
-        vCout = (uint32_t)__builtin_amdgcn_update_dpp((int)R16, (int)vCout, RSN_DPP_WAVE_SHR1, 0xF, 0xF, false);
-    }
-}
-
-__global__ __launch_bounds__(LB) void k_match(MatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t W4 = a.DW * MATCH_WAVES;                          // >= W
-    const uint32_t WUB = (a.W + 63) / 64 * 64;                       // warm-up positions above the strip
-    const uint32_t RLEN = (MATCH_STRIP + WUB + W4 + 15) & ~15u;      // staged positions
-    uint8_t *s_b = smem;                                             // stream bytes (0 outside the stream: see CHECKED)
-    uint16_t *s_carry = reinterpret_cast<uint16_t *>(smem + RLEN);   // [MATCH_WAVES][DW] runs entering from the block above
-    uint32_t *s_comb = reinterpret_cast<uint32_t *>(s_carry + MATCH_WAVES * a.DW + (MATCH_WAVES * a.DW & 1));   // [2][MATCH_WAVES][64]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: keeps the loop bounds in SGPRs
-    const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
-    const long long r0 = b0 - (long long)W4;
-    for (uint32_t i = tid; i < RLEN; i += LB) {
-        const long long p = r0 + i;
-        s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0;
-    }
-    for (uint32_t i = tid; i < MATCH_WAVES * a.DW; i += LB) s_carry[i] = 0;
-    __syncthreads();
-
-    // Shortcut for W-periodic stretches: a match on diagonal W that fills the whole window
-    // (or reaches the end of the stream) cannot be beaten -- L <= W, and W is the largest
-    // distance, i.e. the leftmost occurrence.  If that holds for every position of the strip
-    // (no mismatch fc[q] != fc[q-W] anywhere in [b0, b0+STRIP+W)), the search is skipped.
-    {
-        const long long q_end = min(b0 + (long long)MATCH_STRIP + (long long)a.W - 1, (long long)a.E);
-        bool ok = b0 >= (long long)a.W;
-        if (ok) for (long long q = b0 + tid; q < q_end; q += LB) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
-        if (__syncthreads_and(ok)) {
-            for (long long p = b0 + tid; p < min(b0 + (long long)MATCH_STRIP, (long long)a.E); p += LB) {
-                const uint32_t L = (uint32_t)min((long long)a.W, (long long)a.E - p);
-                a.keys[p] = (L << 16) | a.W;
-            }
-            return;
-        }
-    }
-
-    const uint32_t Dk = wv * a.DW;                                    // this wave's diagonals: Dk+1 .. Dk+DWk
-    const uint32_t DWk = Dk >= a.W ? 0 : min(a.DW, a.W - Dk);
-    const uint32_t nsteps = DWk ? DWk + 63 : 0;
-    uint16_t *carry = s_carry + wv * a.DW;
-    const int nPB = (int)((MATCH_STRIP + WUB) / 64);
-
-    for (int pb = nPB - 1; pb >= 0; pb--) {
-        const long long P0 = b0 + 64ll * pb;
-        if (P0 >= (long long)a.E) continue;                           // nothing above the end of the stream: runs stay 0
-        const long long p = P0 + lane;
-        const uint32_t X = p < (long long)a.E ? (uint32_t)s_b[p - r0] : 0x300u;
-        uint32_t best = 0, R16 = 0;
-        // lane l meets diagonal Dk + (t - 62 + l) at step t; candidate index y = P0 + 62 - t - Dk for every lane
-        uint32_t Bd = (Dk + (uint32_t)lane - 63u) * 0x10001u;         // becomes (Dk + t - 62 + l)*0x10001 after the step's increment
-        const long long y0 = P0 + 62 - (long long)Dk;
-        const uint8_t *ybase = s_b + (y0 - r0);
-        const bool checked = P0 < (long long)W4 || P0 + 63 >= (long long)a.E;   // block-uniform
-        for (uint32_t t0 = 0; t0 < nsteps; t0 += 64) {
-            const uint32_t ci = t0 + lane;
-            const uint32_t vCin = ci < DWk ? (uint32_t)carry[ci] << 16 : 0u;
-            uint32_t vCout = 0;
-            if (checked) match_chunk<true, true>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
-            else if (t0 >= 63 && t0 + 64 <= DWk) match_chunk<false, false>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
-            else match_chunk<true, false>(ybase, y0, a.E, t0, nsteps, DWk, lane, X, vCin, vCout, R16, Bd, best);
-            // lane 0 met local diagonal index t-63 at step t; after 64 shifts the value of step k sits in lane 63-k
-            const uint32_t co = t0 - (uint32_t)lane;
-            if (co < DWk) carry[co] = (uint16_t)(vCout >> 16);
-        }
-        uint32_t *comb = s_comb + (pb & 1) * (MATCH_WAVES * 64);
-        comb[wv * 64 + lane] = best;
-        __syncthreads();
-        if (wv == 0 && pb < MATCH_STRIP / 64 && p < (long long)a.E) {
-            uint32_t k = max(max(comb[lane], comb[64 + lane]), max(comb[128 + lane], comb[192 + lane]));
-            if ((k >> 16) == 0) k = 0;
-            a.keys[p] = k;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ E2': packed match search (lengths only)
-// Same sweep as k_match with two diagonals per lane packed in the 16-bit halves of one VGPR
+// The sweep with two diagonals per lane packed in the 16-bit halves of one VGPR
 // (v_pk_* arithmetic): lane l meets diagonals Dk+1+j (low half) and Dk+H+1+j (high half),
 // j = t-63+l, so a wave's diagonal range takes half the steps.  Only the capped run length
 // survives packing (the 16-bit maximum cannot carry the distance); the distance of the few
@@ -386,7 +274,9 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
     }
     for (uint32_t i = tid; i < MW2 * H; i += MW2 * 64) s_carry[i] = 0;
     __syncthreads();
-    {   // W-periodic strip: nothing to search (see k_match)
+    {   // Shortcut for W-periodic stretches: a match on diagonal W that fills the whole window (or reaches the end of the stream)
+        // cannot be beaten -- L <= W, and W is the largest distance, i.e. the leftmost occurrence.  If that holds for every position
+        // of the strip (no mismatch fc[q] != fc[q-W] anywhere in [b0, b0+STRIP+W)), the search is skipped.
         const long long q_end = min(b0 + (long long)MATCH_STRIP + (long long)a.W - 1, (long long)a.E);
         bool ok = b0 >= (long long)a.W;
         if (ok) for (long long q = b0 + tid; q < q_end; q += MW2 * 64) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
@@ -451,7 +341,7 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
 //   * an answer of 0 or 1 is decided by whether ANY in-window entry of the 32 buckets that
 //     share the first byte exists.
 // Work is proportional to how often the bigram at i occurs in the window instead of W, which
-// on text is ~1% of W.  The result is the same function as k_match/k_match2; input where the
+// on text is ~1% of W.  The result is the same function as k_match2; input where the
 // assumption fails (an lcp of HLMAX or more, or a lane running past H_ITER_CAP entries) flags
 // its strip and k_match2 redoes exactly those strips.
 constexpr int HT = 4096;                 // positions per block
@@ -533,7 +423,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     if (tid < 4) s_cls[tid] = 0;
     __syncthreads();
 
-    if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match)
+    if (t0 >= (long long)W) {   // W-periodic tile: L = min(W, E-p) at distance W for every position (see k_match2)
         bool ok = true;
         const uint32_t qn = (uint32_t)min((long long)(HT + HLMAX), (long long)E - t0);
         for (uint32_t q = tid; q < qn; q += HTH) ok = ok && sb[HWMAX + q] == sb[HWMAX + q - W];
@@ -719,13 +609,10 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
 // KEY_UNKNOWN; if the true chain ever lands on one (k_parse_mark notices), that strip is redone for
 // all positions by k_match_hash and the parse is repeated -- correctness never rests on the merge,
 // only the speed does.
-#ifndef RSN_CHAIN_CSH
-#define RSN_CHAIN_CSH 9
-#endif
 template <int CT_, int CTH_, int CS_>
 struct ChainCfg {
     static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
-    static constexpr int CSH = RSN_CHAIN_CSH;               // a bucket's entries are ordered by staged offset >> CSH
+    static constexpr int CSH = 9;               // a bucket's entries are ordered by staged offset >> CSH
     static constexpr int CH = 128;                          // warm-up positions before the tile
     static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
     static constexpr int OFFB = NS <= 8192 ? 13 : NS <= 16384 ? 14 : 15;   // bits of a staged offset in a list entry
@@ -798,7 +685,7 @@ __global__ void k_tiles_from_blocks(const uint8_t *__restrict__ same_blk, uint32
 }
 
 // W-periodic tiles (config 3 is nothing else): fc[q] == fc[q - W] for every q the tile's matches can reach, so every position p has the
-// key (min(W, E-p), W) (see k_match).  Found by a pass of its own, straight from memory and without LDS -- inside k_match_chain the same
+// key (min(W, E-p), W) (see k_match2).  Found by a pass of its own, straight from memory and without LDS -- inside k_match_chain the same
 // check ran at that kernel's two blocks per CU and took 1.5 ms per GiB of periodic data; other tiles fail the first wavefront's sample
 // (64 x 16 bytes) and cost next to nothing.  Nobody writes a periodic tile's keys (4 bytes per position for nothing): k_chain_periodic
 // places the chain by arithmetic, k_tok_emit computes the key of a flagged position, k_chain_unknown stores them only if the general
@@ -828,26 +715,10 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
     if (tid == 0) { tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0}; step[blockIdx.x] = 0; }
 }
 
-#ifndef RSN_CHAIN_ROW_CS
-#define RSN_CHAIN_ROW_CS 64                                               // a start every so many positions when a chain has a row of lanes
-#endif
-#ifndef RSN_CHAIN_NARROW
-#define RSN_CHAIN_NARROW 64
-#endif
-#ifndef RSN_CHAIN_HEAVY
-#define RSN_CHAIN_HEAVY 128
-#endif
-// TIMING PROBE (-DRSN_CHAIN_PROBE_B2, never in the product: it misses the matches of exactly two bytes): buckets keyed by a hash of the
-// bigram AND three bits of the third byte, tag = two more bits of the third byte -- what the walk would cost if a visit only met the
-// candidates that share a trigram.  See DESIGN 8.
-#ifdef RSN_CHAIN_PROBE_B2
-__device__ __forceinline__ uint32_t probe_h(uint32_t b0, uint32_t b1, uint32_t b2) { return ((((b0 * 37u) ^ (b1 * 101u)) & 0x3FFu) << 3) | (b2 & 7u); }
-__device__ __forceinline__ uint32_t probe_tag(uint32_t b2) { return (b2 >> 3) & 3u; }
-#endif
-template <class C, int LW>
+template <class C>
 __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_match_chain(ChainArgs a) {   // (80: see ChainArgs)
-    // (a start every 64 positions for 128 walkers; a quad per chain is 256 walkers: a start every 32)
-    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = LW == 64 ? C::CS : (LW == 4 ? RSN_CHAIN_ROW_CS / 2 : RSN_CHAIN_ROW_CS), CH = C::CH, NS = C::NS;
+    constexpr int LW = 8;                                                 // lanes of a chain's home row: eight chains per wavefront (r03: a wavefront per chain 37.5 ms, four chains 31, sixteen 30.3, eight 28.8)
+    constexpr int CT = C::CT, CTH = C::CTH, CSH = C::CSH, CS = C::CS, CH = C::CH, NS = C::NS;
     constexpr uint32_t TAGM = (1u << C::TAGB) - 1;
     // A list entry is staged offset << TAGB | tag.  The test of a candidate -- its start in [i - W, i) and the same tag -- is then one
     // subtraction, one rotation and one compare: with Q = (offset of i - 1) << TAGB | tag of i, Q - entry is (distance - 1) << TAGB when
@@ -872,11 +743,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const long long t0 = (long long)bx * CT;
     const long long r0 = t0 - CH - HWMAX;
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
-#ifdef RSN_CHAIN_STATS
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-    uint32_t n_evals = 0, n_rounds = 0, n_ext = 0, n_iter = 0, n_act = 0;
-    uint32_t n_dealt = 0, n_heavy = 0, n_heavy_visits = 0, n_ok = 0, n_before = 0, n_after = 0, n_trips = 0;   // wave rounds dealt / heavy chunks / heavy visits / candidates that pass the window+tag test / bucket entries before and after trimming / narrowing trips
-#endif
     if ((a.redo & 4u) && bx < HALO_TILES) return;                         // a section's halo: candidates for the tiles behind it, no chain of its own
     if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
     for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
@@ -902,11 +768,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const uint32_t rlo = (uint32_t)(max(0ll, q0 - (long long)W) - r0), rhi = (uint32_t)(min((long long)E - 1, t0 + (long long)CT) - r0);
     for (uint32_t rel = tid; rel < (uint32_t)NS; rel += CTH) {
         if (rel < rlo || rel >= rhi) continue;
-#ifdef RSN_CHAIN_PROBE_B2
-        const uint32_t b0 = sb[rel], h = probe_h(b0, sb[rel + 1], sb[rel + 2]);
-#else
         const uint32_t b0 = sb[rel], h = (b0 << 5) | (sb[rel + 1] & 31u);
-#endif
         atomicAdd(&s_cur[h >> 1], 1u << (16 * (h & 1)));
         const unsigned long long bit = 1ull << (rel >> CSH);
         if (!(s_present[b0] & bit)) atomicOr(&s_present[b0], bit);
@@ -936,11 +798,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         const uint32_t rel = base + tid;
         const bool in = rel >= rlo && rel < rhi;
         const uint32_t b1 = sb[in ? rel + 1 : 0u];
-#ifdef RSN_CHAIN_PROBE_B2
-        const uint32_t h = probe_h(sb[in ? rel : 0u], b1, sb[in ? rel + 2 : 0u]), ent = (rel << C::TAGB) | (probe_tag(sb[in ? rel + 2 : 0u]) & TAGM);
-#else
         const uint32_t h = ((uint32_t)sb[in ? rel : 0u] << 5) | (b1 & 31u), ent = (rel << C::TAGB) | ((b1 >> 5) & TAGM);
-#endif
         const uint32_t sh = 16 * (h & 1);
 #pragma unroll
         for (int g = 0; g < (CTH >> CSH); g++) {
@@ -952,9 +810,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         }
     }
     const uint16_t *ends = reinterpret_cast<const uint16_t *>(s_cur);    // ends[h]; the bucket starts at ends[h-1]
-#ifdef RSN_CHAIN_STATS
-    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- chains.  Positions are counted from t0 - CH (kp); staged offset = HWMAX + kp.  Everything
     //      named u_* is the same in all 64 lanes.
@@ -979,199 +834,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     constexpr uint32_t LONG_CAP = 8;                                      // candidates with a common prefix of HLMAX bytes and more that a visit follows through memory
     // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
     //  state machine and spends ~40 scalar instructions per visit on its masks, and scalar issue is this kernel's bound.)
-    if constexpr (LW == 64) {
-    bool alive = true;
-    uint32_t u_next = 0xFFFFFFFFu, visits = 0, from_kp = 0;               // where the chain in hand goes on; its visits and its start
-    while (alive) {
-        uint32_t u_kp = uni(u_next);
-        u_next = 0xFFFFFFFFu;
-        if (u_kp >= kp_end) {                                             // the chain in hand has ended: a new start
-            uint32_t kq = 0;
-            if (lane == 0) kq = atomicAdd(&s_next, 1u);
-            kq = uni(kq);
-            alive = kq < nitems;
-            u_kp = kq == 0 ? kp_first : CH + (kq - 1) * CS;
-            visits = 0; from_kp = u_kp;
-        }
-        bool mine = false;
-        if (alive) {
-            const uint32_t v_kp = vec(u_kp);                               // (address and bit from vector registers, the atomic by lane 0 alone)
-            uint32_t old = 0;
-            if (lane == 0) old = atomicOr(&s_claim[v_kp >> 5], 1u << (v_kp & 31));
-            mine = !__ballot((old >> (v_kp & 31)) & 1);                   // somebody else's already: that wavefront walks the rest
-        }
-        if (mine) {
-            const uint32_t u_ipos = (uint32_t)(t0 - CH) + u_kp, u_irel = HWMAX + u_kp, u_capE = E - u_ipos;
-            // (the bigram, its bucket index and tag stay in vector registers although they are wave-uniform: scalar issue is the bound)
-            const uint32_t u_b0 = sb[u_irel], u_b1 = sb[u_irel + 1];
-            uint32_t best = 0;
-            bool longm = false;                                               // a common prefix reached HLMAX bytes
-            uint32_t long_best = 0, long_far = 0, n_long = 0;                 // wave-uniform: the best of the long candidates that were followed up, the farthest of all, how many (LONG_CAP + 1: too many)
-            {   // (a position with a single byte left needs no case of its own: the stage is zero behind the stream and L is capped at E - i)
-                const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM, v_q = cand_q(u_irel, u_tag);
-                // (bucket bounds and the bisection's arithmetic stay in VECTOR registers although every lane holds the same values:
-                //  the scalar unit is this kernel's bound; only the ballots and the loop branches are scalar)
-                const uint32_t v_lo0 = ends[max(u_h, 1u) - 1];
-                uint32_t v_lo = u_h ? v_lo0 : 0u;
-                const uint32_t v_hi = ends[u_h];
-                const uint32_t u_blk_lo = (u_irel - W) >> CSH, u_blk_i = u_irel >> CSH;
-                const unsigned long long pat0 = lds_load8(sw, vec(u_irel) + C::OFF0);  // the position's own bytes: one address for all lanes
-                bool narrowing = v_hi - v_lo > 64;
-                while (__ballot(narrowing)) {                                 // skip the entries before the window, 64-ary
-                    const uint32_t n = v_hi - v_lo, stride = (n + 63) >> 6;
-                    const uint32_t idx = min(v_lo + (uint32_t)lane * stride, v_hi - 1);
-                    const uint32_t blk = (uint32_t)s_list[idx] >> (C::TAGB + CSH);
-                    const unsigned long long in = __ballot(blk >= u_blk_lo);
-                    const uint32_t first = in ? (uint32_t)__builtin_ctzll(in) : 64u;   // lanes below `first` read entries before the window
-                    const uint32_t skip = max(first, 1u) - 1u;                // whole strides known to lie before the window
-                    v_lo = min(v_lo + skip * stride, v_hi - 1);               // (skip == 0 leaves v_lo: v_lo < v_hi)
-                    narrowing = skip * (stride - 1u) != 0 && v_hi - v_lo > 64;
-                }
-                // (lane predicates are folded into single vector compares: every s_and_b64 of two lane masks is one more
-                //  instruction on the scalar unit.  A lane beyond the bucket's end re-examines entry v_lo: harmless to a maximum.)
-                uint32_t v_base = v_lo, stop = 0;
-                if (__ballot(v_lo < v_hi)) do {
-#ifdef RSN_CHAIN_STATS
-                    n_rounds++;
-#endif
-                    const uint32_t idx = v_base + (uint32_t)lane;
-                    const uint32_t e = s_list[idx < v_hi ? idx : v_lo];
-                    const uint32_t rel = e >> C::TAGB, rot = cand_rot(v_q, e), dn = rot + 1u;
-                    // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
-                    const bool ok = rot < W;
-                    v_base += 64;
-                    // the last round if some lane's entry lies after i (the rest of the bucket does then) or no entries remain:
-                    // the sign bits of (block of i - block of the entry) and of NOT (next base - end), one vector value, one branch
-                    stop = ((u_blk_i - (rel >> CSH)) | ~(v_base - v_hi)) >> 31;
-                    if (__ballot(ok)) {
-                        const uint32_t lim = ok ? min(dn, u_capE) : 0u;        // entirely inside the window, and inside the stream; 0 = not a candidate
-                        uint32_t off = C::OFF0;
-                        unsigned long long x = lds_load8(sw, rel + off) ^ pat0;
-                        uint32_t room = x == 0 ? lim : 0u;                     // eight equal bytes so far: the match may run on up to here
-                        while (__ballot(off + 8 < room)) {                     // longer than eight bytes: the lanes concerned go on, eight at a time
-#ifdef RSN_CHAIN_STATS
-                            n_ext++;
-#endif
-                            const bool go = off + 8 < room;                    // (every lane computes, the lanes concerned commit)
-                            const uint32_t off2 = off + 8;
-                            const unsigned long long x2 = lds_load8(sw, rel + off2) ^ lds_load8(sw, u_irel + off2);
-                            off = go ? off2 : off;
-                            x = go ? x2 : x;
-                            room = go ? (x2 == 0 ? room : 0u) : 0u;
-                            if (__ballot((room ? off + 8 : 0u) >= HLMAX)) { longm = true; room = 0; }
-                        }
-                        if (__ballot(x == 0 && off + 8 >= HLMAX)) {
-                            // The candidates that were still going when the cap stopped the loop (they advance in step, so they are the
-                            // lanes with eight equal bytes at the last offset) agree with the position for HLMAX bytes and more -- further
-                            // than the stage reaches.  Up to LONG_CAP of them per visit are followed through memory to their true end,
-                            // min(common prefix, distance, bytes left): a repeated block has a handful of earlier copies.  Runs and short
-                            // periods have thousands: there only the farthest is kept (see the commit below).  Their entries in `best`
-                            // stay as the lower bounds they are.
-                            const bool fl = x == 0 && off + 8 >= HLMAX;
-                            unsigned long long fm = __ballot(fl);
-                            long_far = max(long_far, wave_max_u32(fl ? dn : 0u));
-                            while (fm && n_long < LONG_CAP) {
-                                const int j = __builtin_ctzll(fm);
-                                fm &= fm - 1;
-                                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dn, j), limj = (uint32_t)__builtin_amdgcn_readlane((int)lim, j);
-                                const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)off, j) + 8;   // equal so far: bytes [0, from)
-                                uint32_t mm = limj;                            // first byte that differs, if any lies below the limit
-                                for (uint32_t k = from + lane; k < limj && mm == limj; k += 64)
-                                    if (a.fc[(size_t)u_ipos + k] != a.fc[(size_t)u_ipos - dj + k]) mm = k;
-                                mm = ~wave_max_u32(~mm);                       // the minimum over the lanes
-                                long_best = max(long_best, (mm << 16) | dj);
-                                n_long++;
-                            }
-                            if (fm) n_long = LONG_CAP + 1;                     // more of them than are followed up
-                        }
-                        const uint32_t n = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                        uint32_t len = min(off + n, lim);
-                        if (C::OFF0 < 2) len = len < 2 ? 0u : len;             // the untagged bit of the second byte differed
-                        best = max(best, len ? (len << 16) | dn : 0u);        // longest, then farthest back (bytes.Index, lzss.go:419)
-                    }
-                } while (!__ballot(stop));
-                best = wave_max_u32(best);
-            }
-            auto commit = [&](uint32_t key) {
-                a.keys[vec(u_ipos)] = key;                                    // (all 64 lanes, one address: one request, and no exec-mask bookkeeping on the scalar unit)
-                u_next = vec(u_kp) + max(1u, vec(key) >> 16);                 // lzss.go:139-142: a reference skips size-1 positions
-                visits++;
-#ifdef RSN_CHAIN_STATS
-                n_evals++;
-#endif
-            };
-            if (best != 0 && !longm) commit(best);                            // the common case first, with nothing else on its path
-            else {
-                bool giveup_heavy = false, giveup_dense = false;
-                if (longm) {
-                    if (n_long <= LONG_CAP) best = max(best, long_best);             // every long candidate was followed to its end: the maximum is exact
-                    else {
-                        // More long candidates than are followed up: a run, a short period, the W-periodic stream of config 3.  No candidate's
-                        // L exceeds its distance, so if the FARTHEST long one matches over its whole distance (or to the end of the stream)
-                        // nothing beats it: the nearer ones are shorter, or tie and lose the tie (bytes.Index takes the leftmost,
-                        // lzss.go:419), and the farther ones stopped short of HLMAX bytes.
-                        const uint32_t Lp = min(long_far, u_capE);
-                        uint32_t mm = Lp;                                     // the first byte in which the farthest long candidate differs
-                        for (uint32_t k = lane; k < Lp && mm == Lp; k += 64) if (a.fc[(size_t)u_ipos + k] != a.fc[(size_t)u_ipos - long_far + k]) mm = k;
-                        mm = ~wave_max_u32(~mm);
-                        // (a maximum, not an assignment: where the END OF THE STREAM binds -- Lp = capE < long_far -- a candidate farther back
-                        //  that is not "long" may match all capE bytes too; `best` then already holds its exact key and the leftmost wins)
-                        if (mm == Lp) best = max(best, (Lp << 16) | long_far);
-                        else {
-                            // It stops after mm bytes (the end of a periodic stretch: all its candidates stop there).  Another candidate
-                            // does better only if it is more than mm back AND agrees with the position in byte mm -- those that stop at
-                            // the same byte tie and lose the tie to the farthest.  One byte per candidate settles it; if one does
-                            // agree there, the strip goes to the sweep after all.
-                            const uint32_t u_h = (u_b0 << 5) | (u_b1 & 31u), u_tag = (u_b1 >> 5) & TAGM;
-                            const uint32_t lo = u_h ? (uint32_t)ends[u_h - 1] : 0u, hi = ends[u_h];
-                            const uint32_t want = a.fc[(size_t)u_ipos + mm];
-                            bool other = false;
-                            for (uint32_t idx = lo + lane; idx < hi; idx += 64) {
-                                const uint32_t e = s_list[idx], rot = cand_rot(cand_q(u_irel, u_tag), e), dn = rot + 1u;
-                                const bool ok = rot < W;
-                                if (ok && dn > mm && dn <= u_ipos && a.fc[(size_t)u_ipos - dn + mm] == want) other = true;
-                            }
-                            if (__ballot(other)) giveup_heavy = true;
-                            else best = max(best, (mm << 16) | long_far);
-                        }
-                    }
-                }
-                if (best == 0 && !giveup_heavy) {   // no bigram of the window matches: L = 1 iff the byte occurs in the window at all
-                    // (the density test sits on this path because dense data comes through here all the time, text rarely)
-                    // (not in tile 0: every stream begins with an empty window and a run of one-byte steps, and the second look that a
-                    //  tile which gave up costs -- a launch that waits for one tile -- is a third of a small call's time)
-                    if (!(a.redo & 1u) && bx != 0 && visits >= DENSE_EVALS && u_kp - from_kp < 2 * visits) giveup_dense = true;
-                    else {
-                        const uint32_t ws = max(u_irel - min(W, u_irel), zrel);   // the window is staged [ws, irel)
-                        const uint32_t fb_lo = (ws + (1u << CSH) - 1) >> CSH, fb_hi = u_irel >> CSH;   // blocks fb_lo .. fb_hi-1 lie entirely inside it
-                        bool hit = false;
-                        if (fb_lo < fb_hi) {
-                            const unsigned long long m = (fb_hi >= 64 ? ~0ull : (1ull << fb_hi) - 1) & ~((1ull << fb_lo) - 1);
-                            hit = (s_present[u_b0] & m) != 0;
-                        }
-                        if (!hit) {                                               // the two ragged ends, byte by byte
-                            const uint32_t e1 = min(fb_lo << CSH, u_irel), s2 = max(min(fb_hi << CSH, u_irel), fb_lo < fb_hi ? ws : e1);
-                            bool f = false;
-                            for (uint32_t q = ws + lane; q < e1; q += 64) f = f || sb[q] == u_b0;
-                            for (uint32_t q = s2 + lane; q < u_irel; q += 64) f = f || sb[q] == u_b0;
-                            hit = __ballot(f) != 0;
-                        }
-                        best = hit ? (1u << 16) : 0u;
-                    }
-                }
-                if (longm && !giveup_heavy && (best >> 16) == (best & 0xFFFFu) && lane == 0) {   // (rare path: the counters cost the text walk nothing)
-                    atomicAdd(&s_nstep, 1u); atomicMin(&s_stepmin, best & 0xFFFFu); atomicMax(&s_stepmax, best & 0xFFFFu);
-                }
-                if (giveup_heavy || giveup_dense) {
-                    // the start counter is pushed past every item; the other wavefronts finish the chain they are on (text: a handful
-                    // of visits; dense data: they run into this test themselves within DENSE_EVALS visits) and find nothing more to start
-                    if (lane == 0) { atomicOr(&s_next, GIVE_UP); if (giveup_heavy) s_heavy = 1; else s_dense = 1; }
-                    alive = false;
-                } else commit(best);
-            }
-        }
-    }
-    } else {
+    {
         // ---- the same walk with K = 64 / LW chains per wavefront.  This kernel is bound by vector issue (scripts/valu_probe.cpp: a wave64
         //      integer VALU instruction holds its SIMD for ~4 cycles however many wavefronts share it; the walk's counters come to 3.4), and
         //      a visit on text examines a dozen candidates (half the visits: eight or fewer): with a wavefront per chain most of those
@@ -1185,8 +848,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
         //        3. the home rows commit (and take the rare paths: long matches, no bigram match).
         static_assert(LW == 16 || LW == 8 || LW == 4, "a DPP row, half of one, or a quad per chain");
         constexpr int K = 64 / LW, NWV = CTH / 64;
-        constexpr uint32_t NARROW = RSN_CHAIN_NARROW;                        // a bucket is trimmed while it holds more entries than this
-        constexpr uint32_t HEAVY_ROWS = RSN_CHAIN_HEAVY / LW < 16 ? RSN_CHAIN_HEAVY / LW : 16;   // a visit with this many rows of candidates takes the whole wavefront (a row index is four bits of the row map)
+        constexpr uint32_t NARROW = 64;                        // a bucket is trimmed while it holds more entries than this
+        constexpr uint32_t HEAVY_ROWS = 16;   // a visit with this many rows of candidates takes the whole wavefront (a row index is four bits of the row map)
         constexpr uint32_t LCAP = K > 8 ? 4 : LONG_CAP;                       // long candidates listed per chain (sixteen chains: the lists' LDS)
         // a wavefront's scratch, one record (one base address in a register; the members are offsets in the LDS instructions)
         struct WaveScratch {
@@ -1232,19 +895,11 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             if (mine) {
                 irel = HWMAX + kp; capE = E - ((uint32_t)(t0 - CH) + kp);
                 const uint32_t b0 = sb[irel], b1 = sb[irel + 1];
-#ifdef RSN_CHAIN_PROBE_B2
-                const uint32_t h = probe_h(b0, b1, sb[irel + 2]);
-                tag = probe_tag(sb[irel + 2]) & TAGM;
-#else
                 const uint32_t h = (b0 << 5) | (b1 & 31u);
                 tag = (b1 >> 5) & TAGM;
-#endif
                 lo = h ? (uint32_t)ends[h - 1] : 0u; hi = ends[h];
                 const uint32_t blk_lo = (irel - W) >> CSH, blk_i = irel >> CSH;
                 pat0 = lds_load8(sw, irel + C::OFF0);
-#ifdef RSN_CHAIN_STATS
-                if (leader) n_before += hi - lo;
-#endif
                 // (r04, measured and dropped: the window's slice of the bucket by INTERPOLATION -- entries are ordered by block and text spreads
                 //  a bigram evenly over the stage, so four guesses at each end, checked exactly by the block of the entry in front of / at the
                 //  guess, trim any bucket of more than two rows for one LDS read.  It works -- 85.5 entries per visit become 36.0 instead of
@@ -1266,14 +921,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     const uint32_t nhi = after ? min(lo + __umul24((uint32_t)__builtin_ctz(after), stride), hi - 1) : hi;   // that sample and everything behind it: after i
                     narrowing = (nlo != lo || nhi != hi) && nhi - nlo > NARROW;
                     lo = nlo; hi = max(nhi, nlo);
-#ifdef RSN_CHAIN_STATS
-                    if (leader) n_trips++;
-#endif
                 }
                 nrows = (hi - lo + LW - 1) / LW;
-#ifdef RSN_CHAIN_STATS
-                if (leader) n_after += hi - lo;
-#endif
             }
             // ---- 2. the candidates
             // one candidate per lane: its key L << 16 | distance (0: none).  c_*: the visit it belongs to, `ch` its chain.  A candidate that
@@ -1283,9 +932,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 const uint32_t rel = e >> C::TAGB, rot = cand_rot(c_q, e), dn = rot + 1u;
                 // candidate start in [i-W, i) and the same bigram up to the tag: one compare (a tag difference lands above any W)
                 const bool ok = valid && rot < W;
-#ifdef RSN_CHAIN_STATS
-                n_ok += ok ? 1u : 0u;
-#endif
                 uint32_t lim = 0, off = C::OFF0;
                 unsigned long long x = 1;
                 if (ok) {
@@ -1293,9 +939,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     x = lds_load8(sw, rel + off) ^ c_pat0;
                     uint32_t room = x == 0 ? lim : 0u;
                     while (off + 8 < room) {                                  // longer than eight bytes: this lane goes on, eight at a time
-#ifdef RSN_CHAIN_STATS
-                        n_ext++;
-#endif
                         off += 8;
                         x = lds_load8(sw, rel + off) ^ lds_load8(sw, c_irel + off);
                         if (x != 0 || off + 8 >= HLMAX) room = 0;             // (the stage reaches HLMAX bytes past a position)
@@ -1330,9 +973,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             while (hm) {
                 const int hl = __builtin_ctzll(hm);
                 hm &= hm - 1;
-#ifdef RSN_CHAIN_STATS
-                n_heavy_visits++;
-#endif
                 const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl), c_q = (uint32_t)__builtin_amdgcn_readlane((int)cand_q(irel, tag), hl),
                                c_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, hl), c_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, hl),
                                c_capE = (uint32_t)__builtin_amdgcn_readlane((int)capE, hl);
@@ -1340,9 +980,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pat0 >> 32), hl) << 32);
                 uint32_t wb = 0, n_long = 0, far = 0;
                 for (uint32_t base = c_lo; base < c_hi; base += 64) {
-#ifdef RSN_CHAIN_STATS
-                    n_rounds += K; n_heavy++;
-#endif
                     const uint32_t idx = base + (uint32_t)lane;
                     const bool valid = idx < c_hi;
                     const uint32_t e = s_list[valid ? idx : c_lo];
@@ -1386,9 +1023,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t g0 = 0; g0 < n_all; g0 += K) {
-#ifdef RSN_CHAIN_STATS
-                n_rounds++; n_dealt++;
-#endif
                 const uint32_t g = g0 + (uint32_t)slot;
                 const uint32_t rm = ws.rowmap[g < n_all ? g : 0u], ch = rm >> 4;
                 const uint4 p0 = *reinterpret_cast<const uint4 *>(&ws.par[ch][0]), p1 = *reinterpret_cast<const uint4 *>(&ws.par[ch][4]);
@@ -1425,9 +1059,6 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     a.keys[ipos] = key;
                     next = kp + max(1u, key >> 16);                           // lzss.go:139-142: a reference skips size-1 positions
                     visits++;
-#ifdef RSN_CHAIN_STATS
-                    if (leader) n_evals++;
-#endif
                 };
                 if (best != 0 && !longm) commit(best);                        // the common case first
                 else {
@@ -1518,28 +1149,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     } else commit(best);
                 }
             }
-#ifdef RSN_CHAIN_STATS
-            if (lane == 0) n_iter++;
-#endif
         }
     }
-#ifdef RSN_CHAIN_STATS
-    if (a.stats && (lane & (LW - 1)) == 0) {                               // (a row's leader counts for its chain)
-        atomicAdd(&a.stats[0], (unsigned long long)n_rounds); atomicAdd(&a.stats[1], (unsigned long long)n_evals); atomicAdd(&a.stats[2], (unsigned long long)n_ext);
-    }
-    if (a.stats && lane == 0) {
-        const unsigned long long st2 = __builtin_amdgcn_s_memtime();       // this wavefront is done
-        atomicAdd(&a.stats[4], st1 - st0); atomicAdd(&a.stats[5], st2 - st1); atomicAdd(&a.stats[6], 1ull);
-        atomicAdd(&a.stats[3], (unsigned long long)n_iter); atomicAdd(&a.stats[7], (unsigned long long)n_act);
-        atomicAdd(&a.stats[8], (unsigned long long)n_dealt); atomicAdd(&a.stats[9], (unsigned long long)n_heavy); atomicAdd(&a.stats[10], (unsigned long long)n_heavy_visits);
-    }
-    if (a.stats) {
-        unsigned long long okc = n_ok;
-        for (int d = 32; d; d >>= 1) okc += __shfl_down(okc, d);
-        if (lane == 0) atomicAdd(&a.stats[11], okc);
-        if ((lane & (LW - 1)) == 0) { atomicAdd(&a.stats[12], (unsigned long long)n_before); atomicAdd(&a.stats[13], (unsigned long long)n_after); atomicAdd(&a.stats[14], (unsigned long long)n_trips); }
-    }
-#endif
     __syncthreads();
     // (the thread's index once more, opaque to the compiler: or what the prologue derived from it is kept for the epilogue's loops and,
     //  the walk needing every register, spilled across it)
@@ -1761,12 +1372,8 @@ __global__ __launch_bounds__(512) void k_chain_tail(const uint8_t *__restrict__ 
 // The lane also leaves the keys it met inside the tile, in chain order, as a compact list (clist[tile * CT ..], ccnt[tile] entries): what
 // k_tok_emit needs of the 4 bytes per position of the key array is these -- one position in six on text -- and their positions follow
 // from the tile's entry by adding up max(1, L).
-#ifndef RSN_SERIAL_WIN
 #define RSN_SERIAL_WIN 32                                                 // records a lane stages at a time
-#endif
-#ifndef RSN_SERIAL_TILES
 #define RSN_SERIAL_TILES 64                                               // tiles per wavefront (fewer: more wavefronts in flight, emptier)
-#endif
 template <class C>
 __global__ __launch_bounds__(64) void k_chain_serial(const uint32_t *__restrict__ keys, uint32_t E, uint32_t n_tiles, TileChain *__restrict__ tchain,
                                                      uint32_t *__restrict__ flags, unsigned long long *__restrict__ tile_bytes,
@@ -2582,35 +2189,20 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     const uint32_t n_strips = (uint32_t)ceil_div(E, MATCH_STRIP);
     rc = dev_buf(c, 18, (size_t)n_strips * 12 + 64, &p); if (rc) return rc;
     uint32_t *d_heavy = (uint32_t *)p, *d_redo = d_heavy + n_strips, *d_dense = d_redo + n_strips;
-    static const bool brute = getenv("RSN_LZSS_BRUTE") != nullptr || getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: sweep every strip
     static const bool allpos = getenv("RSN_LZSS_ALLPOS") != nullptr;                                            // A/B switch: bucket search at every position
-    const bool hashed = W <= HWMAX && !brute;
+    const bool hashed = W <= HWMAX;
     if ((halo || stop_tile) && !hashed) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %d", HWMAX);
     bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
-    auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 (or k_match) on every strip, or on the flagged ones
-        MatchArgs ma{d_fc, E, W, (W + MATCH_WAVES - 1) / MATCH_WAVES, d_keys, only};
-        const uint32_t W4 = ma.DW * MATCH_WAVES, WUB = (W + 63) / 64 * 64;
-        const size_t shmem = (size_t)((MATCH_STRIP + WUB + W4 + 15) & ~15u) + (size_t)(MATCH_WAVES * ma.DW + 1) * 2 + 2 * MATCH_WAVES * 64 * 4 + 16;
-        static thread_local size_t attr_set = 0;
-        if (shmem > attr_set) {
-            RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            attr_set = shmem;
+    auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 on every strip, or on the flagged ones
+        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only};
+        const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
+        const size_t shmem2 = (size_t)((MATCH_STRIP + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
+        static thread_local size_t attr2_set = 0;
+        if (shmem2 > attr2_set) {
+            RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+            attr2_set = shmem2;
         }
-        static const bool unpacked = getenv("RSN_LZSS_UNPACKED") != nullptr;   // A/B switch: the 32-bit (length+distance) sweep
-        if (unpacked) {
-            RSN_LAUNCH("lzss_match", k_match, dim3(n_strips), dim3(LB), shmem, s, ma);
-        } else {
-            MatchArgs m2 = ma;
-            m2.DW = (W + MW2 - 1) / MW2;
-            const uint32_t W4b = m2.DW * MW2 + 16;
-            const size_t shmem2 = (size_t)((MATCH_STRIP + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
-            static thread_local size_t attr2_set = 0;
-            if (shmem2 > attr2_set) {
-                RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-                attr2_set = shmem2;
-            }
-            RSN_LAUNCH("lzss_match", k_match2, dim3(n_strips), dim3(MW2 * 64), shmem2, s, m2);
-        }
+        RSN_LAUNCH("lzss_match", k_match2, dim3(n_strips), dim3(MW2 * 64), shmem2, s, m2);
         return RSN_OK;
     };
     // E3 buffers (the chain walk fills flags and tile bytes itself when its per-tile chains join up)
@@ -2621,17 +2213,9 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     uint32_t *d_flags = d_entry + n_pt;
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
-#ifndef RSN_CHAIN_CTH
-#define RSN_CHAIN_CTH 1024
-#endif
-    using CC = ChainCfg<8192, RSN_CHAIN_CTH, 128>;                 // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 128 positions (measured: 64 / 256 within 4 %)
-    // lanes per chain in k_match_chain: 8 or 16 = eight or four chains per wavefront, 64 = a wavefront per chain (RSN_LZSS_CHAIN_LANES, A/B)
-    static const int chain_lanes = [] { const char *e = getenv("RSN_LZSS_CHAIN_LANES"); const int v = e ? atoi(e) : 8; return v == 64 || v == 16 || v == 4 ? v : 8; }();
+    using CC = ChainCfg<8192, 1024, 64>;                           // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 64 positions
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
-        if (chain_lanes == 64) RSN_LAUNCH(name, (k_match_chain<CC, 64>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
-        else if (chain_lanes == 8) RSN_LAUNCH(name, (k_match_chain<CC, 8>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
-        else if (chain_lanes == 4) RSN_LAUNCH(name, (k_match_chain<CC, 4>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
-        else RSN_LAUNCH(name, (k_match_chain<CC, 16>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        RSN_LAUNCH(name, (k_match_chain<CC>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         return RSN_OK;
     };
     uint8_t *d_dump = nullptr;
@@ -2659,10 +2243,9 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     else if (chain_mode) RSN_LAUNCH("lzss_tile_periodic", k_tile_periodic, dim3(n_pt), dim3(256), 0, s, d_fc, E, W, (uint32_t)PT, d_tchain, d_step);
     if (chain_mode && halo) RSN_LAUNCH("lzss_tile_periodic", k_halo_init<CC>, dim3(std::min(HALO_TILES, n_pt)), dim3(256), 0, s, d_tchain, d_flags, d_tbytes, d_dump, d_step, (uint32_t)PT);
     constexpr uint32_t SAMPLE_TILES = 64;
-    static const bool no_sample = getenv("RSN_LZSS_NO_SAMPLE") != nullptr;   // A/B switch
     const char *smin_env = getenv("RSN_LZSS_SAMPLE_MIN_TILES");
     const uint32_t sample_min = smin_env ? std::max<uint32_t>((uint32_t)atoi(smin_env), 16 * SAMPLE_TILES) : 128 * SAMPLE_TILES;
-    if (chain_mode && !no_sample && n_pt >= sample_min) {
+    if (chain_mode && n_pt >= sample_min) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
@@ -2675,38 +2258,21 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     if (chain_mode) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
         // k_chain_serial's compact key lists (k_tok_emit's input where a tile has one): in the memory the general parse would use for its
-        // exits -- the lists are read only if that parse never runs.  RSN_LZSS_NO_LIST: always the flag form (A/B).  Where k_chain_serial
-        // will run, k_match_chain leaves it the claimed positions' keys in the same memory (RSN_LZSS_NO_CKEYS: it reads the key array).
-        static const bool no_list = getenv("RSN_LZSS_NO_LIST") != nullptr, no_ckeys = getenv("RSN_LZSS_NO_CKEYS") != nullptr;
-        static const bool tail_doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr, tail_serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;
+        // exits -- the lists are read only if that parse never runs.  Where k_chain_serial will run, k_match_chain leaves it the
+        // claimed positions' keys in the same memory (RSN_LZSS_NO_CKEYS: it reads the key array, as it does for a tile whose records do
+        // not fit -- the tests' way to that path; RSN_LZSS_TAIL_SERIAL: k_chain_serial whatever the size, the tests' way to what 256 MiB take).
+        static const bool no_ckeys = getenv("RSN_LZSS_NO_CKEYS") != nullptr, tail_serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;
         uint32_t *d_ckn = nullptr;
-        if (!no_list) {
+        {
             void *lp; rc = dev_buf(c, 11, std::max((size_t)E * 2, (size_t)n_pt * PT * 4) + 64, &lp); if (rc) return rc;
             d_clist = (uint32_t *)lp;
             rc = dev_buf(c, 27, (size_t)n_pt * 8 + 64, &lp); if (rc) return rc;
             d_ccnt = (uint32_t *)lp;
             RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
-            if (!no_ckeys && !tail_doubling && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
+            if (!no_ckeys && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
         }
         ChainArgs ha{d_fc, E, W, d_keys, halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
-#ifdef RSN_CHAIN_STATS
-        void *stp; rc = dev_buf(c, 23, 128, &stp); if (rc) return rc;
-        RSN_HIP(hipMemsetAsync(stp, 0, 128, s));
-        ha.stats = (unsigned long long *)stp;
-#endif
         rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
-#ifdef RSN_CHAIN_STATS
-        {
-            unsigned long long hs[16];
-            RSN_HIP(hipMemcpyAsync(hs, stp, 128, hipMemcpyDeviceToHost, s));
-            RSN_HIP(hipStreamSynchronize(s));
-            fprintf(stderr, "chain stats+: per visit: dealt wave-rounds %.3f, heavy chunks %.3f (heavy visits %.4f), candidates passing window+tag %.2f, bucket entries %.1f -> %.1f after trimming (%.3f trips); per iteration: visits %.2f, dealt rounds %.2f, heavy chunks %.2f\n",
-                    (double)hs[8] / hs[1], (double)hs[9] / hs[1], (double)hs[10] / hs[1], (double)hs[11] / hs[1], (double)hs[12] / hs[1], (double)hs[13] / hs[1], (double)hs[14] / hs[1],
-                    (double)hs[1] / hs[3], (double)hs[8] / hs[3], (double)hs[9] / hs[3]);
-            fprintf(stderr, "chain stats: rounds %llu evals %llu (%.3f per position) ext-steps %llu | waves %llu | cycles/wave: setup %.0f walk %.0f | rounds/eval %.2f | iterations %llu, rows at work %llu\n",
-                    hs[0], hs[1], (double)hs[1] / E, hs[2], hs[6], (double)hs[4] / hs[6], (double)hs[5] / hs[6], (double)hs[0] / hs[1], hs[3], hs[7]);
-        }
-#endif
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
         const uint32_t n_prev = (uint32_t)ceil_div(n_pt, PREV_BLK);
@@ -2715,14 +2281,12 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         bool list_gave = true;                                                    // tiles that gave up are on the look's list (until there are too many of them)
         auto resolve = [&](bool second, bool with_pred) -> int {                  // in-tile chains, periodic stretches, the joints, the offsets; one host sync
             RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
-            static const bool doubling = getenv("RSN_LZSS_TAIL_DOUBLING") != nullptr;   // A/B switches: the in-tile parse by pointer doubling in LDS,
-            static const bool serial = getenv("RSN_LZSS_TAIL_SERIAL") != nullptr;       //               or by one lane per tile whatever the size
             // (the second look concerns a handful of tiles, dense ones among them: a lone lane's 8 000 dependent loads would be all
             //  the call waits for -- there the block-per-tile kernel, which returns at once everywhere else, is the faster one.
             //  The same holds for a whole stream below 256 MiB: a lone lane's walk is 235 us on short steps and 0.7 ms on text
             //  however few the tiles, the blocks take 17-23 ns per tile -- text: 0.29 against 0.96 ms at 64 MiB, 0.56 against 0.95
             //  at 127 MiB, level at 256 MiB, 3 against 1.9 ms at 1 GiB)
-            if (doubling || second || (n_pt < 32768 && !serial)) {
+            if (second || (n_pt < 32768 && !tail_serial)) {
                 RSN_LAUNCH("lzss_chain_tail", (k_chain_tail<CC, (CC::CH + CC::CT) / 2>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
                 RSN_LAUNCH("lzss_chain_tail_big", (k_chain_tail<CC, CC::CH + CC::CT>), dim3(n_pt), dim3(512), 0, s, d_dump, d_keys, E, d_tchain, d_flags, d_tbytes, d_ccnt);
             } else {
@@ -2753,7 +2317,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         };
         rc = resolve(false, false); if (rc) return rc;
         parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
-        static const bool dbg = getenv("RSN_LZSS_DEBUG") != nullptr;
+        static const bool dbg = getenv("RSN_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         // A few tiles gave up (a stretch of one- and two-byte steps looked "dense"), or entered on a chain that had not merged with the
         // true one yet: walk just those -- without that test / from the true entry, the tile before's exit -- and check again.  A joint
@@ -2765,13 +2329,12 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         // converge: a look that leaves more than half of its list behind is the last, and a list of more than half the tiles is not tried.
         // Joints that fail by the hundred may also be whole-distance stretches (k_stretch_pred): the list is then drawn up again with the
         // true chain placed through them by arithmetic, and the look walks every tile of a stretch from its predicted entry.
-        static const bool no_pred = getenv("RSN_LZSS_NO_STRETCH") != nullptr;   // A/B switch
         bool use_pred = false;
         // (With more tiles given up than a look takes -- sections of noise -- the stream ends in the general parse whatever happens; the
         //  looks still mend the joints and place the stretches of the rest, so that the parse finds the chain on evaluated positions
         //  there and does not send those strips to the bucket search and the sweep as well.)
         list_gave = (uint32_t)h64[1] <= gave_cap;
-        if (!parsed && !no_fused && !no_pred && (uint32_t)(h64[1] >> 32) > 64) {
+        if (!parsed && !no_fused && (uint32_t)(h64[1] >> 32) > 64) {
             use_pred = true;
             rc = resolve(true, true); if (rc) return rc;
             if (dbg) fprintf(stderr, "lzss chain walk, stretches placed: list of %u tiles, %u of them by arithmetic\n", (uint32_t)(h64[2] >> 32), (uint32_t)h64[3]);
@@ -2788,21 +2351,6 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             rc = resolve(true, use_pred); if (rc) return rc;
             parsed = h64[1] == 0 && (uint32_t)h64[2] == 0;
             if (dbg) fprintf(stderr, "lzss chain walk, look %d: %u gave up, %u chains that do not join, %u periodic tiles not placed\n", look, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
-            if (dbg && !parsed) {                                         // the first few tiles still on the list, with their neighbours' records
-                const uint32_t nl = std::min<uint32_t>((uint32_t)(h64[2] >> 32), 4);
-                uint32_t hl[4], hs[4];
-                RSN_HIP(hipMemcpy(hl, d_redo_list, nl * 4, hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(hs, d_redo_start, nl * 4, hipMemcpyDeviceToHost));
-                for (uint32_t q = 0; q < nl; q++) {
-                    const uint32_t k = hl[q] & 0x3FFFFFFFu, k0 = k ? k - 1 : 0;
-                    TileChain tcs[3] = {}; uint32_t st[3] = {}, pd[3] = {};
-                    const uint32_t cnt = std::min<uint32_t>(3, n_pt - k0);
-                    RSN_HIP(hipMemcpy(tcs, d_tchain + k0, cnt * sizeof(TileChain), hipMemcpyDeviceToHost)); RSN_HIP(hipMemcpy(st, d_step + k0, cnt * 4, hipMemcpyDeviceToHost));
-                    if (use_pred) RSN_HIP(hipMemcpy(pd, d_pred + k0, cnt * 4, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "   listed tile %u (%s, start %u):", k, hl[q] >> 31 ? "joint" : "gave up", hs[q]);
-                    for (uint32_t u = 0; u < cnt; u++) fprintf(stderr, "  [%u: entry %u exit %u walked %u step %u pred %u]", k0 + u, tcs[u].entry, tcs[u].exit, tcs[u].walked, st[u], pd[u]);
-                    fprintf(stderr, "\n");
-                }
-            }
         }
         parsed_by_walk = parsed;
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
@@ -2894,15 +2442,13 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
-    static const bool no_try = getenv("RSN_LZSS_ESC_TWO_PASS") != nullptr;   // A/B switch: always count, scan, write
     bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
     // (the window, should nothing need an escape -- then E = n; a multiple of 16 for k_esc_try's periodicity flags, see there)
     const uint32_t Wp = window > 0 && (uint64_t)window <= HWMAX && (uint64_t)window < n && window % 16 == 0 ? (uint32_t)window : 0u;
-    static const bool no_fused_periodic = getenv("RSN_LZSS_NO_FUSED_PERIODIC") != nullptr;   // A/B switch: k_tile_periodic reads the stream itself
     uint8_t *d_same = nullptr;
-    if (!no_try) {
+    {
         rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
-        if (Wp && !no_fused_periodic) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
+        if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
         RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
         RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
         RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);

@@ -541,7 +541,7 @@ struct BatchPipe {
 static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
     const size_t m = idx.size();
     if (m == 0) return RSN_OK;
-    if (env_int("RSN_BATCH_LANES", 3) == 1 || m < 2) {
+    if (m < 2) {
         for (size_t j = 0; j < m; j++) {
             const size_t i = idx[j];
             const int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);

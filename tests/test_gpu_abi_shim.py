@@ -28,9 +28,9 @@ def test_abi_shim_compiles_and_host_only_part_runs(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"RSN_BATCH_WORKERS": "3"}, {"RSN_BATCH_WORKERS": "2", "RSN_BATCH_LANES": "1"},
+@pytest.mark.parametrize("env", [{}, {"RSN_BATCH_WORKERS": "3"}, {"RSN_BATCH_WORKERS": "2"},
                                  {"RSN_DEVICE": "rr", "RSN_MAX_PARKED": "1"}, {"RSN_BATCH_KEEP_MIB": "0", "RSN_BATCH_WORKERS": "8"}],
-                         ids=["default", "3 workers", "2 serial workers", "round-robin devices, 1 parked", "8 workers, ring released"])
+                         ids=["default", "3 workers", "2 workers", "round-robin devices, 1 parked", "8 workers, ring released"])
 def test_abi_shim_call_sequence(tmp_path, env):
     """The shim's call sequence, also with the batch split over several per-device workers (on a one-GPU box they share the
     device: the dealing-out, the per-worker rings and the error path are the same code a multi-GPU node runs), with the default

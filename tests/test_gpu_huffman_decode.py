@@ -216,9 +216,8 @@ def test_device_resident_round_trip_256MiB(huff):
 def test_second_level_tables_and_switches(oracle):
     """Codes longer than the first-level table: sub-tables in LDS (byte alphabets), through L2 (rune alphabets with tens of
     thousands of symbols), and the bit-by-bit walk below them (Fibonacci counts: 29-bit codes).  The same streams decode
-    the same with RSN_DEC_NO_LUT2=1 (no second level at all), RSN_DEC_K=8 (a smaller first level), RSN_DEC_KWIDE=0 (first level no
-    wider than the longest code: the r03 rule), RSN_DEC_FUSED=1 (the one-pass decoder with its look-back) and RSN_NO_MULTI=1: separate processes,
-    the switches are read once."""
+    the same with RSN_NO_MULTI=1 (one codeword per lookup: the second formulation of the walks) and RSN_DEC_WARM=0 (no warm-up:
+    most blocks' guessed entries are wrong and the fixing passes do the work): separate processes, the switches are read once."""
     import hashlib
     import os
     import subprocess
@@ -235,8 +234,7 @@ def test_second_level_tables_and_switches(oracle):
             "    print(hashlib.sha256(huffman.Decompress(c)).hexdigest(), hashlib.sha256(oracle.huffman_decompress(c)).hexdigest())\n"
             ) % (root, os.path.join(root, "tests"))
     outs = []
-    for env in ({}, {"RSN_DEC_NO_LUT2": "1"}, {"RSN_DEC_K": "8"}, {"RSN_DEC_KWIDE": "0"}, {"RSN_DEC_FUSED": "1"}, {"RSN_NO_MULTI": "1"},
-                {"RSN_DEC_WARM": "0"}, {"RSN_DEC_WARM": "0", "RSN_DEC_NO_FIX_LIST": "1"}, {"RSN_DEC_WARM": "0", "RSN_DEC_FUSED": "1"}):   # no warm-up: most blocks' guessed entries are wrong -- the fixing passes (and the one-pass decoder's fallback) do the work
+    for env in ({}, {"RSN_NO_MULTI": "1"}, {"RSN_DEC_WARM": "0"}, {"RSN_DEC_WARM": "0", "RSN_NO_MULTI": "1"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]

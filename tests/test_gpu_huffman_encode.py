@@ -131,12 +131,7 @@ def test_large_property_256MiB(huff, oracle):
 def test_rune_start_map_at_every_lane_and_stream_edge(huff, oracle):
     """The rune path classifies once (k_rune_hist) and the later passes take rune starts from the map: sequences of 2, 3 and 4 bytes
     straddling every 16-byte lane boundary, invalid bytes next to them, streams that end inside a sequence (Go: U+FFFD per byte,
-    huffman.go:309) and right after one -- against the oracle -- and the same bytes with the map switched off in a process of its own."""
-    import hashlib
-    import pickle
-    import subprocess
-    import sys
-    import tempfile
+    huffman.go:309) and right after one -- against the oracle."""
     pieces = ["\u00e9".encode(), "\u20ac".encode(), "\U0001F600".encode(), b"a", b"\x80", b"\xc2", b"\xe2\x82", b"\xf0\x9f\x98", b"\xff", b"\xed\xa0\x80", b"\xc0\x80"]
     cases = []
     for shift in range(0, 20):
@@ -147,12 +142,3 @@ def test_rune_start_map_at_every_lane_and_stream_edge(huff, oracle):
     cases.append(bytes(range(256)) * 40)
     got = [huff.Compress(c) for c in cases]
     assert got == [oracle.huffman_compress(c) for c in cases]
-    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import huffman\n"
-            "cases = pickle.load(open(sys.argv[1], 'rb'))\n"
-            "print(' '.join(hashlib.sha256(huffman.Compress(c)).hexdigest() for c in cases))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
-        pickle.dump(cases, f)
-        f.flush()
-        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=300, env=dict(os.environ, RSN_HUFF_NO_START_MAP="1"))
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split()[-len(cases):] == [hashlib.sha256(g).hexdigest() for g in got]

@@ -275,7 +275,7 @@ def test_whole_distance_stretches_placed_by_arithmetic(lz, oracle, period):
         c, p = _prof(lz, d)
         assert c == oracle.lzss_compress_mt(d, 4096, oracle.host_cores(), 4096)
         assert lz.Decompress(c) == d
-        if _chain_mode() and not any(os.environ.get(k) for k in ("RSN_LZSS_NO_FUSED_PARSE", "RSN_LZSS_NO_STRETCH")):
+        if _chain_mode() and not os.environ.get("RSN_LZSS_NO_FUSED_PARSE"):
             # (without the tail the last match runs to the very end of the stream and jumps over the final partial tile, which then
             #  holds no chain position at all: k_chain_verify accepts that)
             assert "lzss_chain_stretch" in p and "lzss_parse_mark" not in p, sorted(p)
@@ -292,7 +292,7 @@ def test_noise_sections_do_not_keep_the_looks_from_the_rest(lz, oracle):
     c, p = _prof(lz, data)
     assert c == oracle.lzss_compress_mt(data, 4096, oracle.host_cores(), 4096)
     assert lz.Decompress(c) == data
-    if _chain_mode() and not any(os.environ.get(k) for k in ("RSN_LZSS_NO_FUSED_PARSE", "RSN_LZSS_NO_STRETCH")):
+    if _chain_mode() and not os.environ.get("RSN_LZSS_NO_FUSED_PARSE"):
         assert "lzss_chain_stretch" in p and p["lzss_match_chain"][0] >= 2, sorted(p)
 
 
@@ -322,8 +322,8 @@ def test_decode_front_end_in_one_pass(lz, oracle, monkeypatch):
     valid, and per 16-byte span what it produces; the tile kernels then run without a second parse of the tokens (k_lzd_tilemap).
     Checked here: a pointer before the start of the data deep inside a stream (the compare per block, read back only after the tile
     kernels have run), at a block edge and inside a tile; spans that produce 65535 bytes and more (the pass hands those streams
-    to the r02 front end); tile boundaries that fall inside literals, inside tokens and right after zero-output spans; and the
-    same bytes from the r02 front end (RSN_LZSS_DEC_3PASS) on everything."""
+    to k_lzd_tiles); tile boundaries that fall inside literals, inside tokens and right after zero-output spans; and the
+    same bytes from the decoder's second formulation (RSN_LZSS_DEC_JUMP: pointer jumping over the whole stream) on everything."""
     from raisin_amd import RsnError
     rng = np.random.default_rng(9)
     lit = rng.integers(97, 123, size=5000, dtype=np.uint8).tobytes()
@@ -339,7 +339,6 @@ def test_decode_front_end_in_one_pass(lz, oracle, monkeypatch):
                oracle.lzss_compress(lit * 40), (lit * 4)[:16384 - 5] + b"<9,9>" + (lit * 4)[:16384 - 9] + b"<16384,16384>" * 5 + b"q"]
     want = [oracle.lzss_decompress(c) for c in streams]
     assert [lz.Decompress(c) for c in streams] == want
-    monkeypatch.setenv("RSN_LZSS_DEC_3PASS", "1")                # (read once per process: effective only if nothing decoded before -- the subprocess below is the real A/B)
     import subprocess, sys, hashlib
     code = ("import sys, hashlib; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
             "import pickle; streams = pickle.load(open(sys.argv[1], 'rb'))\n"
@@ -348,7 +347,7 @@ def test_decode_front_end_in_one_pass(lz, oracle, monkeypatch):
     with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
         pickle.dump(streams, f)
         f.flush()
-        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=300, env=dict(os.environ, RSN_LZSS_DEC_3PASS="1"))
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=300, env=dict(os.environ, RSN_LZSS_DEC_JUMP="1"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-len(streams):] == [hashlib.sha256(w).hexdigest() for w in want]
 
@@ -444,7 +443,7 @@ def long_copies(seed, n, seg=(90, 240)):
 def _chain_mode():
     """False when an A/B switch replaces the chain walk (the suites are also run under those switches)."""
     import os
-    return not any(os.environ.get(k) for k in ("RSN_LZSS_ALLPOS", "RSN_LZSS_BRUTE", "RSN_LZSS_UNPACKED"))
+    return not os.environ.get("RSN_LZSS_ALLPOS")
 
 
 def _prof(lz_mod, data, w=4096):
@@ -522,9 +521,8 @@ def test_chain_periodic_stretches_between_text(lz, oracle):
 def test_chain_vs_allpos_switch(oracle):
     """RSN_LZSS_ALLPOS=1 (bucket search at every position) gives the same bytes, and so does the in-tile parse by
     one lane per tile (RSN_LZSS_TAIL_SERIAL: what streams of 256 MiB and more take; below, a block per tile does
-    it) -- through the records k_match_chain leaves it and, RSN_LZSS_NO_CKEYS, through the key array -- and the chain
-    walk with a wavefront or a row of 16 lanes per chain instead of 8 (RSN_LZSS_CHAIN_LANES): separate processes,
-    the switches are read once.  The input has text, long copies, runs and a short period in it (the walk's long-match
+    it) -- through the records k_match_chain leaves it and, RSN_LZSS_NO_CKEYS, through the key array -- and the general
+    parse instead of the walk's own (RSN_LZSS_NO_FUSED_PARSE): separate processes, the switches are read once.  The input has text, long copies, runs and a short period in it (the walk's long-match
     paths: candidates followed through memory, the early end of a bucketful visit)."""
     import os
     import subprocess
@@ -537,7 +535,7 @@ def test_chain_vs_allpos_switch(oracle):
             "print(hashlib.sha256(lz.CompressAsync(d)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     envs = ({}, {"RSN_LZSS_ALLPOS": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1"}, {"RSN_LZSS_TAIL_SERIAL": "1", "RSN_LZSS_NO_CKEYS": "1"},
-            {"RSN_LZSS_CHAIN_LANES": "64"}, {"RSN_LZSS_CHAIN_LANES": "16", "RSN_LZSS_TAIL_SERIAL": "1"}, {"RSN_LZSS_CHAIN_LANES": "4"})
+            {"RSN_LZSS_NO_FUSED_PARSE": "1"}, {"RSN_LZSS_ALLPOS": "1", "RSN_LZSS_NO_FUSED_PARSE": "1"})
     for env in envs:
         e = dict(os.environ); e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip())
@@ -587,7 +585,7 @@ def test_sample_sends_incompressible_streams_to_the_bucket_search(lz, oracle):
     try:
         for data, walks in ((noise, False), (half, True)):
             c, p = _prof(lz, data)
-            if _chain_mode() and not os.environ.get("RSN_LZSS_NO_SAMPLE"):
+            if _chain_mode():
                 assert p["lzss_sample"][0] == 2                            # the list and the 64-tile walk
                 assert ("lzss_match_chain" in p) == walks
             assert c == want[id(data)]
@@ -612,7 +610,7 @@ def test_chain_entry_fixed_by_second_look(lz, oracle):
         assert c == oracle.lzss_compress(data, 300)
         assert lz.Decompress(c) == data
         if _chain_mode() and "RSN_LZSS_NO_FUSED_PARSE" not in __import__("os").environ:
-            # (with a wavefront per chain -- RSN_LZSS_CHAIN_LANES=64 -- every lead needs the second look; with eight chains per
+            # (with a wavefront per chain -- r03: one chain per wavefront -- every lead needs the second look; with eight chains per
             #  wavefront and a start every 64 positions some of these joints come out right at once)
             assert 1 <= p["lzss_match_chain"][0] <= 4 and "lzss_parse_mark" not in p, sorted(p)
 
