@@ -143,6 +143,7 @@ def test_benchmark_suite_runs_entries_concurrently_with_a_deadline(tmp_path, sam
     """engine.go:235-263: one goroutine per algorithm entry, a one-minute deadline, ">1m0s" DNF rows for the stragglers."""
     import io
     import threading
+    import time
     from raisin_amd import engine
     assert engine._go_duration(60.0) == "1m0s" and engine.BenchmarkTimeout == 60.0
     src = tmp_path / "sam.txt"
@@ -160,6 +161,11 @@ def test_benchmark_suite_runs_entries_concurrently_with_a_deadline(tmp_path, sam
         assert len(set(seen)) == 4 and threading.get_ident() not in seen      # four entries, four threads, none the caller's
         assert all(r.Lossless and not r.Failed for r in res) and len(res) == 4
         buf = io.StringIO()
+
+        def slow(layer, f):                                                  # (a warm 170 KB round trip takes a fraction of a millisecond: without
+            time.sleep(0.3)                                                  #  the pause an entry can deliver before the suite has looked at its clock)
+            return real(layer, f)
+        engine.AsyncBenchmarkFile = slow
         res = engine.BenchmarkSuite([str(src)], algos, out=buf, timeout=0.0)   # nothing can deliver in time
         assert all(r.Failed and r.TimeTaken == ">0s" for r in res) and buf.getvalue().count("DNF") == 12
     finally:
