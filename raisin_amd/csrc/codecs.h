@@ -1,6 +1,8 @@
 // codecs.h -- device-resident codec entry points shared between translation units.
 #pragma once
 
+#include <functional>
+
 #include "huff_host.h"
 #include "lzss_legacy.h"
 #include "rsn_common.h"
@@ -21,7 +23,16 @@ int huff_slice_hist(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, HuffSl
 int huff_slice_emit(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, const HuffSlice &sl, const HuffTree &tree, const HuffCodes &codes, bool flat,
                     const std::string &hdr, unsigned long long base_bits, unsigned long long slice_bits, uint8_t *d_out);
 bool huff_flat_code(const HuffTree &tree, const HuffCodes &codes);
-int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
+// A host-buffer decode in SLICES (rsn_api.hip: the upload is still running while the first slices decode, and their bytes go down while
+// the later ones decode): the decoder asks for its input as it needs it and announces its output as it becomes final.  The stream is one
+// bit string without a block index (huffman.go:258-297), so a slice starts exactly where its predecessor's last codeword ended -- the
+// hand-over is that bit position and the output offset, nothing else.
+struct HuffStream {
+    std::function<bool(size_t)> need_in;            // returns once d_in[0, bytes) is on the device; false: give up (the call fails)
+    std::function<bool(size_t, size_t)> have_out;   // d_out[off, off + len) is final; false: give up
+    size_t slice_bytes = (size_t)32 << 20;          // payload bytes per slice (a multiple of 8 KiB: whole blocks of subsequences)
+};
+int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const HuffStream *st = nullptr);
 int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 

@@ -713,7 +713,7 @@ int rep_for(int K) {   // replicate small tables up to 32x (one copy per LDS ban
 
 }  // namespace
 
-int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const HuffStream *st) {
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
     *out_n = 0;
     // ---- header to the host: strings.SplitN(content, "\\\n", 2) (huffman.go:261)
@@ -724,6 +724,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         const size_t k = std::min(want, n);
         const size_t old = head.size();
         if (k > old) {
+            if (st && !st->need_in(k)) return c.fail(RSN_ERR_DEVICE, "huffman: the upload of a sliced call failed");
             void *hpin; int prc = pinned_buf(c, k - old + 64, &hpin); if (prc) return prc;
             RSN_HIP(hipMemcpyAsync(hpin, d_in + old, k - old, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
@@ -736,6 +737,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     if (sep == (size_t)-1) return c.fail(RSN_ERR_FORMAT, "huffman: no '\\\\\\n' separator (reference: index out of range, huffman.go:264)");
     if (sep + 3 > head.size() && sep + 3 <= n) {   // make sure the pad byte is on the host
         const size_t old = head.size();
+        if (st && !st->need_in(sep + 3)) return c.fail(RSN_ERR_DEVICE, "huffman: the upload of a sliced call failed");
         void *hpin; int prc = pinned_buf(c, 64, &hpin); if (prc) return prc;
         RSN_HIP(hipMemcpyAsync(hpin, d_in + old, sep + 3 - old, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -825,15 +827,30 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         fa.base = d_in + A0; fa.nbytes = n - A0; fa.p0 = 8ull * (pay - A0) + diff; fa.n_sym = n_sym;
         fa.out = d_out;
         for (uint32_t i = 0; i < tree.n_leaves; i++) fa.lut[codes.code[i]] = (uint8_t)tree.rune[i];
-        const dim3 grid((uint32_t)std::min<size_t>(ceil_div((size_t)n_sym, FLAT_SYMS), 256 * 8));
-        switch (L) {
+        // (a sliced call: symbols [q0, q1) a launch -- a multiple of FLAT_SYMS, so that a slice's first field keeps the stream's bit phase --
+        //  once the bytes that hold them, and the words a block loads beyond its own, are up)
+        const unsigned long long per = st ? std::max<unsigned long long>(FLAT_SYMS, (unsigned long long)st->slice_bytes * 8 / L / FLAT_SYMS * FLAT_SYMS) : n_sym;
+        const unsigned long long p0_all = fa.p0;
+        for (unsigned long long q0 = 0; q0 < n_sym || q0 == 0; q0 += per) {
+            const unsigned long long q1 = std::min(n_sym, q0 + per);
+            if (st) {
+                const size_t upto = std::min(n, A0 + (size_t)((p0_all + q1 * L + 7) / 8) + 4096);
+                if (!st->need_in(upto)) return c.fail(RSN_ERR_DEVICE, "huffman: the upload of a sliced call failed");
+                fa.nbytes = upto - A0;
+            }
+            fa.p0 = p0_all + q0 * L; fa.n_sym = q1 - q0; fa.out = d_out + q0;
+            const dim3 grid((uint32_t)std::min<size_t>(ceil_div((size_t)(q1 - q0), FLAT_SYMS), 256 * 8));
+            switch (L) {
 #define RSN_FLAT_CASE(LL) case LL: RSN_LAUNCH("huff_dec_flat", k_dec_flat<LL>, grid, dim3(FDB), 0, s, fa); break;
-            RSN_FLAT_CASE(1) RSN_FLAT_CASE(2) RSN_FLAT_CASE(3) RSN_FLAT_CASE(4) RSN_FLAT_CASE(5) RSN_FLAT_CASE(6)
-            RSN_FLAT_CASE(7)   // ASCII alphabets hold at most 2^7 symbols
+                RSN_FLAT_CASE(1) RSN_FLAT_CASE(2) RSN_FLAT_CASE(3) RSN_FLAT_CASE(4) RSN_FLAT_CASE(5) RSN_FLAT_CASE(6)
+                RSN_FLAT_CASE(7)   // ASCII alphabets hold at most 2^7 symbols
 #undef RSN_FLAT_CASE
-            default: return c.fail(RSN_ERR_LIMIT, "huffman: flat code length %u", L);
+                default: return c.fail(RSN_ERR_LIMIT, "huffman: flat code length %u", L);
+            }
+            RSN_HIP(hipStreamSynchronize(s));
+            if (st && !st->have_out((size_t)q0, (size_t)(q1 - q0))) return c.fail(RSN_ERR_DEVICE, "huffman: the download of a sliced call failed");
+            if (q1 >= n_sym) break;
         }
-        RSN_HIP(hipStreamSynchronize(s));
         return RSN_OK;
     }
 
@@ -896,21 +913,26 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         if (!lut2.empty()) RSN_HIP(hipMemcpyAsync(d_lut2, lut2.data(), lut2.size() * 4, hipMemcpyHostToDevice, s));
     }
 
+    // ---- the payload, whole or slice by slice.  A range is the subsequences of [base, base + 32 n_sub): its first codeword starts at bit p0
+    //      of it (the pad for the stream's first range, the predecessor's last exit for a later one), no codeword is taken that starts at or
+    //      after bit `end`; *last_exit: where the codeword after the range's last one starts, in bits past the range (BAD_REL: the range ran
+    //      off the payload).
+    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 128; }();
+    auto decode_range = [&](const uint8_t *rbase, size_t rnbytes, unsigned long long rp0, unsigned long long rend, unsigned long long rsubs, uint8_t *rout, size_t rcap,
+                            size_t *rtotal, uint32_t *rlast) -> int {
     DecArgs a{};
-    a.base = d_in + A0; a.nbytes = n - A0;
-    a.p0 = 8ull * (pay - A0) + diff;
-    a.end = 8ull * (n - A0);
-    const unsigned long long n_sub64 = (a.end + SBITS - 1) / SBITS;
+    a.base = rbase; a.nbytes = rnbytes;
+    a.p0 = rp0;
+    a.end = rend;
+    const unsigned long long n_sub64 = rsubs;                           // (a slice's `end` lies behind its last subsequence: what its last codeword may reach into)
     if (n_sub64 > 0xFFFFFF00ull) return c.fail(RSN_ERR_LIMIT, "huffman: payload too large for one call");
     a.n_sub = (uint32_t)n_sub64;
     a.lut = d_lut; a.K = K; a.rep_log2 = rep_for(K); a.child = d_child; a.child_n = (uint32_t)child.size(); a.min_len = codes.min_len;
     a.lut2 = d_lut2; a.lut2_n = (uint32_t)lut2.size();
     a.flat_guess = codes.min_len == codes.max_len;
-    static const int warm_env = [] { const char *e = getenv("RSN_DEC_WARM"); return e ? atoi(e) : 128; }();
     a.warm = std::min(std::max(warm_env, 0), ORG - 32);
     const uint32_t n_blk = (uint32_t)ceil_div(a.n_sub, DB);
-    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
-
     rc = dev_buf(c, 6, (size_t)a.n_sub * 6 + 64, &p); if (rc) return rc;
     a.exit_rel = (uint16_t *)p; a.entry_rel = a.exit_rel + a.n_sub; a.nbyte = a.entry_rel + a.n_sub;
     rc = dev_buf(c, 7, ((size_t)n_blk * 2 + 4) * 8 + (size_t)n_blk * 4 + 64, &p); if (rc) return rc;
@@ -938,7 +960,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // for `changed`, for the total, at the end -- ~0.15 ms of a 1.8 ms decode): D3 skips any block that would write past out_cap, so it
     // can run before the host has seen the total; if the fixing pass did hand some block a different exit (rare), everything
     // after it is queued again.
-    a.blk_off = d_blk_off; a.out = d_out; a.out_cap = out_cap;
+    a.blk_off = d_blk_off; a.out = rout; a.out_cap = rcap;
     struct Tail { unsigned long long total; uint16_t last_exit; int changed; };
     Tail *ht = (Tail *)hp;
     auto launch_emit = [&]() -> int {
@@ -990,12 +1012,47 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         rc = offsets_and_bytes(); if (rc) return rc;
         RSN_HIP(hipStreamSynchronize(s));
     }
-    if (ht->last_exit != 0)
-        return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
-    const size_t total = (size_t)ht->total;
-    *out_n = total;
-    if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
+    *rlast = ht->last_exit;
+    *rtotal = (size_t)ht->total;
     return RSN_OK;
+    };
+
+    const uint8_t *base0 = d_in + A0;
+    const unsigned long long end0 = 8ull * (n - A0), p00 = 8ull * (pay - A0) + diff;
+    auto finish = [&](size_t total, uint32_t last_exit, size_t cap) -> int {
+        if (last_exit != 0)
+            return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
+        *out_n = total;
+        if (total > cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "huffman: output needs %zu bytes, buffer holds %zu", total, out_cap); }
+        return RSN_OK;
+    };
+    if (!st) {
+        size_t total = 0; uint32_t last = 0;
+        rc = decode_range(base0, n - A0, p00, end0, (end0 + SBITS - 1) / SBITS, d_out, out_cap, &total, &last); if (rc) return rc;
+        return finish(total, last, out_cap);
+    }
+    // slices of whole blocks of subsequences; a slice may look 4096 bits past its own end (a codeword that begins in it ends there, and the
+    // kernels stage a few words beyond a block), the next one begins where its last codeword ended
+    const unsigned long long slice_bits = std::max<unsigned long long>((unsigned long long)DB * SBITS, (unsigned long long)st->slice_bytes * 8 / (DB * SBITS) * (DB * SBITS));
+    size_t produced = 0;
+    unsigned long long entry = p00;                                      // (bits from the slice's base)
+    for (unsigned long long b0 = 0; b0 < end0; b0 += slice_bits) {
+        const bool fin = b0 + slice_bits >= end0;
+        const unsigned long long rend = fin ? end0 - b0 : std::min(end0 - b0, slice_bits + 4096);
+        const unsigned long long rsubs = fin ? (rend + SBITS - 1) / SBITS : slice_bits / SBITS;
+        const size_t upto = fin ? n : std::min(n, A0 + (size_t)((b0 + rend) / 8) + 4096);
+        if (!st->need_in(upto)) return c.fail(RSN_ERR_DEVICE, "huffman: the upload of a sliced call failed");
+        size_t total = 0; uint32_t last = 0;
+        rc = decode_range(base0 + b0 / 8, upto - A0 - (size_t)(b0 / 8), entry, rend, rsubs, d_out + produced, out_cap > produced ? out_cap - produced : 0, &total, &last);
+        if (rc) return rc;
+        if (total > out_cap - std::min(out_cap, produced)) return finish(produced + total, fin ? last : 0, out_cap);   // more than the header announced: the caller decodes it whole
+        if (!fin && last == BAD_REL) return c.fail(RSN_ERR_FORMAT, "huffman: payload ends inside a codeword (reference: index out of range, huffman.go:145)");
+        if (!st->have_out(produced, total)) return c.fail(RSN_ERR_DEVICE, "huffman: the download of a sliced call failed");
+        produced += total;
+        if (fin) return finish(produced, last, out_cap);
+        entry = last;
+    }
+    return finish(produced, 0, out_cap);
 }
 
 }  // namespace rsn

@@ -240,7 +240,7 @@ namespace {
 // touches it -- several times the PCIe transfer itself -- so blocks of 1 MiB and more go back
 // to a small process-wide pool on rsn_free() and the next call of similar size reuses pages
 // that are already mapped (the cgo shim's pattern: call, C.GoBytes, rsn_free).  A 64-byte header
-// in front of the returned pointer carries the capacity.  RSN_HOST_POOL=0 turns the pool off.
+// in front of the returned pointer carries the capacity.
 constexpr size_t RES_HDR = 64, POOL_MIN = 1u << 20;
 constexpr size_t POOL_BLOCKS = 12;      // a batch of 8 chunks holds 8 results at once
 struct ResHdr { unsigned long long magic, cap; };
@@ -248,7 +248,7 @@ constexpr unsigned long long RES_MAGIC = 0x52534E5F52455330ull;
 std::mutex g_pool_mu;
 std::vector<std::pair<size_t, void *>> g_pool;                    // (capacity, base)
 
-bool pool_enabled() { static const bool on = !(getenv("RSN_HOST_POOL") && atoi(getenv("RSN_HOST_POOL")) == 0); return on; }
+bool pool_enabled() { return true; }
 
 void *result_alloc(size_t n) {
     const size_t need = n ? n : 1;
@@ -463,11 +463,170 @@ int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out
     return huffman_compress_single(in, n, out, out_n);
 }
 
-int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+static int huffman_decompress_serial(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     return host_call(in, n, out, out_n, 4 * n + (1 << 16), n / 8,
                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {
                          return huff_decode_dev(c, s, di, n, dout, cap, got);
                      });
+}
+
+// A large host-buffer decode as a PIPELINE (what the cgo shim binds was upload, then codec, then download -- 16 + 0.5 + 19 ms
+// for a GiB of 2a, the codec the smallest part).  The header is on the host already: its counts give the output's size (what a stream this
+// library or the reference wrote decodes to), so the result block and both device buffers exist before a byte has moved; an uploader thread
+// sends the stream up in pieces, this thread decodes slice after slice as the pieces land (huff_decode_dev with a HuffStream: a slice
+// starts where its predecessor's last codeword ended), a downloader thread brings every finished slice down while the next decodes.  PCIe
+// is full duplex: the call takes the longer of the two transfers, not their sum.  A stream whose payload decodes to more than its header
+// says (a foreign header: the counts only shape the tree) is decoded again by the serial call.  ENCODE has nothing to overlap: the first
+// output byte -- header counts, pad (huffman.go:245-255) -- depends on the last input byte.
+// Returns 1 when the stream is not for this path (small, malformed, foreign): the caller takes the serial call, which also words the errors.
+static int huffman_decompress_piped(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    // Pieces of 64 MiB, each REGISTERED (pinned in place, hipHostRegister: 0.65 ms for 64 MiB) before its copy is queued, the next
+    // piece's registration under the copy of this one: copies of pageable memory in pieces ran at half the link's rate once the other
+    // direction was busy too (measured: 27 ms up + the download behind it = the serial call's 36 ms; two 256 MiB copies at once: 94 GB/s).
+    constexpr size_t PIPE_MIN = (size_t)32 << 20, PIECE = (size_t)64 << 20;
+    // [lo, hi) of a host range whose pages no neighbouring piece shares: piece k of a buffer at `base` is [cut(k), cut(k + 1))
+    auto cut = [](const uint8_t *base, size_t total, size_t k) -> size_t {
+        if (k == 0) return 0;
+        const uintptr_t a = ((uintptr_t)base + k * PIECE + 4095) & ~(uintptr_t)4095;
+        return std::min(total, (size_t)(a - (uintptr_t)base));
+    };
+    if (n < PIPE_MIN) return 1;
+    // ---- the header: strings.SplitN(content, "\\\n", 2) (huffman.go:261), the counts (huffman.go:196-227)
+    size_t sep = (size_t)-1;
+    for (size_t i = 0; i + 1 < std::min(n, (size_t)64 << 20); i++) if (in[i] == 0x5C && in[i + 1] == 0x0A) { sep = i; break; }
+    if (sep == (size_t)-1 || sep + 3 > n) return 1;
+    std::vector<HuffSym> syms; std::string msg;
+    if (!parse_header(in, sep, syms, msg) || syms.size() < 2) return 1;
+    const size_t sn = n - sep - 2;
+    const unsigned long long nbits = (unsigned long long)(sn - 1) * 8, diff = in[sep + 2];
+    if (diff > nbits || nbits == diff) return 1;
+    const unsigned long long max_bits = nbits - diff;
+    unsigned long long total = 0, expect = 0;
+    for (const HuffSym &sy : syms) {
+        if (sy.freq > max_bits - total) return 1;                         // more symbols than the payload has bits: a foreign header
+        total += sy.freq;
+        expect += sy.freq * (unsigned long long)utf8_len(sy.rune);
+    }
+    if (expect == 0) return 1;
+    Ctx &c = ctx();
+    int rc = ctx_init(c); if (rc) return rc;
+    hipStream_t s = c.own_stream;
+    struct Admitted { Ctx &c; size_t held; ~Admitted() { scratch_release(c, held, (3ull << 20) | (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35)); } };
+    Admitted gate{c, scratch_admit(c, round_up(n, 16) + 64 + (size_t)expect + n / 8)};
+    void *d_in, *d_out;
+    rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
+    rc = dev_buf(c, 21, round_up((size_t)expect, 16) + 64, &d_out); if (rc) return rc;
+    uint8_t *res = (uint8_t *)result_alloc((size_t)expect);
+    if (!res) return c.fail(RSN_ERR_NOMEM, "allocating %llu result bytes failed", expect);
+    RSN_HIP(hipMemsetAsync((uint8_t *)d_in + (n & ~(size_t)15), 0, 64, s));
+    RSN_HIP(hipStreamSynchronize(s));                                     // (before the uploader's first piece lands on the same bytes)
+
+    struct Pipe {
+        std::mutex mu; std::condition_variable cv;
+        size_t uploaded = 0;                                              // bytes of the stream on the device
+        std::vector<std::pair<size_t, size_t>> ready;                     // decoded ranges not yet asked for by the downloader
+        size_t taken = 0; bool decoded_all = false, failed = false; std::string msg;
+        void fail(const char *m) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } cv.notify_all(); }
+    } P;
+    const int device = c.device;
+    static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::thread uploader([&] {
+        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
+        hipStream_t su = ctx().own_stream;
+        const size_t n_pieces = (n + PIECE - 1) / PIECE + 1;
+        std::vector<char> pinned(n_pieces, 0);
+        auto pin = [&](size_t k) { const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1); if (hi > lo) pinned[k] = hipHostRegister((void *)(in + lo), hi - lo, hipHostRegisterDefault) == hipSuccess; if (hi > lo && !pinned[k]) (void)hipGetLastError(); };
+        pin(0);
+        for (size_t k = 0; cut(in, n, k) < n; k++) {
+            const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1);
+            hipError_t e = hipMemcpyAsync((uint8_t *)d_in + lo, in + lo, hi - lo, hipMemcpyHostToDevice, su);
+            if (e == hipSuccess && hi < n) pin(k + 1);                        // (under this piece's copy)
+            if (e == hipSuccess) e = hipStreamSynchronize(su);
+            if (pinned[k]) (void)hipHostUnregister((void *)(in + lo));
+            if (e != hipSuccess) { if (hi < n && pinned[k + 1]) (void)hipHostUnregister((void *)(in + hi)); P.fail(hipGetErrorString(e)); return; }
+            { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) { if (hi < n && pinned[k + 1]) (void)hipHostUnregister((void *)(in + hi)); return; } P.uploaded = hi; }
+            P.cv.notify_all();
+        }
+        if (timing) { size_t np_ = 0; for (char x : pinned) np_ += x != 0; fprintf(stderr, "piped decode: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
+    });
+    std::thread downloader([&] {
+        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
+        hipStream_t sd = ctx().own_stream;
+        const size_t total_out = (size_t)expect;
+        std::vector<char> pinned((total_out + PIECE - 1) / PIECE + 1, 0);
+        size_t next_pin = 0;                                              // pieces of the result block below this index have been tried
+        for (;;) {
+            std::pair<size_t, size_t> r;
+            {
+                std::unique_lock<std::mutex> lk(P.mu);
+                P.cv.wait(lk, [&] { return P.failed || P.taken < P.ready.size() || P.decoded_all; });
+                if (P.failed || P.taken >= P.ready.size()) break;
+                r = P.ready[P.taken++];
+            }
+            if (!r.second) continue;
+            auto pin_below = [&](size_t limit) {                              // the pieces of the result block that begin below `limit`
+                while (cut(res, total_out, next_pin) < std::min(total_out, limit)) {
+                    const size_t lo = cut(res, total_out, next_pin), hi = cut(res, total_out, next_pin + 1);
+                    if (hi > lo) { pinned[next_pin] = hipHostRegister(res + lo, hi - lo, hipHostRegisterDefault) == hipSuccess; if (!pinned[next_pin]) (void)hipGetLastError(); }
+                    next_pin++;
+                }
+            };
+            pin_below(r.first + r.second);                                    // the pieces this range lands in (all but the first call's were pinned a range ahead)
+            hipError_t e = hipSuccess;                                        // (a copy may not straddle two registrations: cut at the pieces' edges)
+            for (size_t at = r.first, end = r.first + r.second; at < end && e == hipSuccess;) {
+                size_t k = at / PIECE;                                        // the piece that holds `at`: cut(k) <= at < cut(k + 1)
+                while (cut(res, total_out, k + 1) <= at) k++;
+                while (k > 0 && cut(res, total_out, k) > at) k--;
+                const size_t stop = std::min(end, cut(res, total_out, k + 1));
+                e = hipMemcpyAsync(res + at, (const uint8_t *)d_out + at, stop - at, hipMemcpyDeviceToHost, sd);
+                at = stop;
+            }
+            if (e == hipSuccess) pin_below(r.first + 2 * r.second);            // under these copies: where the next range will land
+            if (e == hipSuccess) e = hipStreamSynchronize(sd);
+            if (e != hipSuccess) { P.fail(hipGetErrorString(e)); break; }
+            if (timing) fprintf(stderr, "piped decode: [%zu, +%zu) down by +%.2f ms\n", r.first, r.second, since());
+        }
+        if (timing) { size_t np_ = 0; for (size_t k = 0; k < next_pin; k++) np_ += pinned[k] != 0; fprintf(stderr, "piped decode: %zu of %zu pieces of the result registered\n", np_, next_pin); }
+        for (size_t k = 0; k < next_pin; k++) if (pinned[k]) (void)hipHostUnregister(res + cut(res, total_out, k));
+    });
+    HuffStream st;
+    st.slice_bytes = (size_t)64 << 20;
+    st.need_in = [&](size_t bytes) { std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.failed || P.uploaded >= std::min(bytes, n); }); return !P.failed; };
+    st.have_out = [&](size_t off, size_t len) {
+        if (timing) fprintf(stderr, "piped decode: [%zu, +%zu) decoded by +%.2f ms\n", off, len, since());
+        { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) return false; P.ready.emplace_back(off, len); }
+        P.cv.notify_all();
+        return true;
+    };
+    size_t got = 0;
+    rc = huff_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, (size_t)expect, &got, &st);
+    if (rc != RSN_OK) P.fail(c.err.c_str());                              // (stops both threads)
+    { std::lock_guard<std::mutex> lk(P.mu); P.decoded_all = true; }
+    P.cv.notify_all();
+    uploader.join();
+    downloader.join();
+    (void)hipSetDevice(c.device);
+    trim_parked_excess(c.device);                                         // (the two threads have parked their contexts)
+    if (rc == RSN_ERR_CAPACITY) { result_free(res); return 1; }           // decodes to more than the header says: the serial call sizes it
+    if (rc != RSN_OK && P.failed && P.msg != c.err) { result_free(res); return c.fail(rc, "%s (%s)", std::string(c.err).c_str(), P.msg.c_str()); }
+    if (rc != RSN_OK) { result_free(res); return rc; }
+    if (P.failed) { result_free(res); return c.fail(RSN_ERR_DEVICE, "huffman: a transfer of the pipelined call failed: %s", P.msg.c_str()); }
+    *out = res; *out_n = got;
+    return RSN_OK;
+}
+
+int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    Ctx &c = ctx();
+    if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
+    *out = nullptr; *out_n = 0;
+    static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;     // A/B switch (tests): upload, decode, download, one after the other
+    if (!serial) {
+        const int rc = huffman_decompress_piped(in, n, out, out_n);
+        if (rc != 1) return rc;
+    }
+    return huffman_decompress_serial(in, n, out, out_n);
 }
 
 int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {

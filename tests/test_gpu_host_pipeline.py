@@ -1,0 +1,76 @@
+"""The pipelined host-buffer Huffman decode (rsn_api.hip: huffman_decompress_piped): upload, slice-by-slice decode and
+download overlapped -- the same bytes as the serial call (RSN_HOST_SERIAL=1), which are the oracle's."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inputs():
+    import workloads as W
+    n = 40 << 20                                   # above the pipeline's 32 MiB threshold: two slices of 32 MiB of payload and a rest
+    rng = np.random.default_rng(5)
+    return {
+        "flat": bytes(W.config_input("2a", n).numpy()),                       # k_dec_flat in slices
+        "skewed": bytes(W.config_input("skewed", n + 12345).numpy()),         # the general kernels: a slice starts where the last codeword ended
+        "text": bytes(W.config_input("4", n).numpy()),
+        "runes": ("Жук €\U0001F600 " * ((n // 3) // 17)).encode(),   # 2-, 3- and 4-byte symbols: output bytes != symbols
+        "two": bytes(rng.integers(0, 2, size=n, dtype=np.uint8) + 65),        # one-bit codes: 8 symbols a payload byte, slices of 256 MiB of output... (n symbols)
+    }
+
+
+def test_pipelined_decode_is_the_serial_decode(oracle):
+    from raisin_amd import huffman
+    datas = _inputs()
+    comp = {k: huffman.Compress(v) for k, v in datas.items()}
+    for k, v in datas.items():
+        assert huffman.Decompress(comp[k]) == v, k                            # pipelined (the default above 32 MiB)
+    # a header that announces HALF of what the payload holds (every count even: the same tree): the pipeline's buffer is too small,
+    # the serial call decodes it -- and one that announces double: decodes in the pipeline, to the payload's symbols
+    d2 = datas["skewed"][: 17 << 20] * 2
+    c2 = huffman.Compress(d2)
+    sep = c2.index(b"\\\n")
+    ents, _ = oracle.header_entries(c2)
+    assert all(int(f) % 2 == 0 for f, _ in ents)
+
+    ents = sorted(ents, key=lambda e: e[1] != b"\\")                          # (the backslash's entry first: last, it would run into the separator, huffman.go:210)
+
+    def rewrite(scale):
+        hdr = b"".join(str(int(int(f) * scale)).encode() + b"|" + (b"\\n" if sym == b"\n" else sym) for f, sym in ents)
+        return hdr + c2[sep:]
+    assert huffman.Decompress(rewrite(0.5)) == d2
+    assert huffman.Decompress(rewrite(2)) == d2
+    # the serial call in a process of its own: the same bytes
+    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import huffman\n"
+            "comp = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "print(' '.join(k + ':' + hashlib.sha256(huffman.Decompress(c)).hexdigest() for k, c in sorted(comp.items())))\n" % ROOT)
+    import pickle
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump(comp, f)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=600, env=dict(os.environ, RSN_HOST_SERIAL="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = " ".join(k + ":" + hashlib.sha256(v).hexdigest() for k, v in sorted(datas.items()))
+    assert out.stdout.strip().splitlines()[-1] == want
+
+
+def test_pipelined_decode_reports_a_truncated_payload(oracle):
+    """A payload cut inside a codeword: RSN_ERR_FORMAT from the last slice, like the serial call; a cut header: the serial call's message."""
+    from raisin_amd import RsnError, huffman
+    import workloads as W
+    data = bytes(W.config_input("skewed", 36 << 20).numpy())
+    c = huffman.Compress(data)
+    for cut in (len(c) - 1, len(c) - (3 << 20) - 1):
+        bad = c[:cut]
+        try:
+            got = huffman.Decompress(bad)                                     # (a cut that happens to fall on a codeword boundary decodes to a prefix)
+            assert data.startswith(got)
+        except RsnError as e:
+            assert e.code == -3
