@@ -20,6 +20,7 @@ for k in ("general_path_2a","cold_start"):
     print(k, j.get(k))
 PY
 for L in headline 2b config3 config4 skewed; do bash scripts/profile.sh $TAG $L > gpurun_out/prof_${TAG}_${L}.txt 2>&1; tail -2 gpurun_out/prof_${TAG}_${L}.txt; done
+cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 python3 scripts/traffic_report.py $TAG > profiles/${TAG}_traffic.txt 2>&1
 mkdir -p gpurun_out/profiles_new && cp profiles/${TAG}_* gpurun_out/profiles_new/ && cp gpurun_out/${TAG}_bench.json gpurun_out/profiles_new/
 ls gpurun_out/profiles_new | grep $TAG
