@@ -72,7 +72,7 @@ TRACE_CANDIDATES = {
     "huff_byte_hist": ["k_byte_hist"], "huff_rune_hist": ["k_rune_hist"], "huff_tile_bits_rune": ["k_tile_bits_rune"],
     "huff_dec_flat": ["k_dec_flat"], "huff_dec_emit": ["k_dec_emit"], "huff_dec_sync": ["k_dec_sync"], "huff_dec_fused": ["k_dec_fused"],
     "lzss_match_chain": ["k_match_chain"], "lzss_match_hash": ["k_match_hash"], "lzss_match": ["k_match2", "k_match"],
-    "lzss_tok_emit": ["k_tok_emit"], "lzss_esc_write": ["k_esc_try", "k_esc_write"], "lzss_tile_periodic": ["k_tile_periodic"],
+    "lzss_tok_emit": ["k_tok_emit"], "lzss_esc_write": ["k_esc_try", "k_esc_write"], "lzss_esc_check": ["k_esc_try"], "lzss_tile_periodic": ["k_tile_periodic"],
     "lzss_chain_tail": ["k_chain_serial", "k_chain_tail"], "lzss_dec_resolve": ["k_lzd_resolve"], "lzss_dec_emit": ["k_lzd_emit"],
     "lzss_dec_count": ["k_lzd_count2", "k_lzd_count"], "lzss_dec_compose": ["k_lzd_compose"], "lzss_dec_runs": ["k_lzd_runs"],
     "lzss_dec_lit": ["k_lzd_lit"], "lzss_dec_patch": ["k_lzd_patch"],
@@ -264,7 +264,7 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
                          "huff_dec_sync": C, "huff_dec_emit": C + l1, "huff_dec_flat": C + l1})
         if name in ("3", "4"):
             lc = sizes[0]                                   # the LZSS stream
-            kalg.update({"lzss_tok_emit": n + lc, "lzss_esc_write": n, "lzss_tile_periodic": n, "lzss_dec_resolve": lc + n, "lzss_dec_emit": lc + n,
+            kalg.update({"lzss_tok_emit": n + lc, "lzss_esc_write": n, "lzss_esc_check": n, "lzss_tile_periodic": n, "lzss_dec_resolve": lc + n, "lzss_dec_emit": lc + n,
                          "lzss_dec_count": lc, "lzss_dec_lit": lc + n, "lzss_dec_patch": n})
         launches = {**{k: v[0] for k, v in prof_e.items()}, **{k: v[0] for k, v in prof_d.items()}}
         if dom in kalg:

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
                                                 uint32_t Wp, uint8_t *__restrict__ same_blk, uint32_t n_chunks) {
     uint32_t prev[4] = {0, 0, 0, 0};
     int prev_cnt = -1;                                                     // -1: nothing in `prev` (the run's first chunk, or Wp is not a chunk)
+    uint32_t seen = 0;                                                     // bit 0: a 5C / FF, bit 1: a '<' -- one look at the flag per BLOCK, at the end (r05: a stream with a '<' in
+                                                                           // every wavefront's 1 KiB -- config 3 -- had sixteen million wavefronts read the one flag word: 0.44 ms against 0.25)
     for (uint32_t k = 0; k < (uint32_t)ESC_RUN; k++) {
         const uint32_t chunk = blockIdx.x * ESC_RUN + k;
         if (chunk >= n_chunks) break;                                      // (block-uniform)
@@ -180,17 +182,24 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             }
             prev[0] = w[0]; prev[1] = w[1]; prev[2] = w[2]; prev[3] = w[3]; prev_cnt = cnt;   // (the INPUT bytes: before '<' becomes FF below)
         }
-        uint32_t special = 0;
+        uint32_t special = 0, lt = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); w[j] |= bytes_equal(w[j], 0x3Cu); }
-        if (__ballot(special != 0) && (threadIdx.x & 63) == 0 && __atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1ull);
-        uint8_t *d = fc + P;
-        if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
-        else for (int q = 0; q < cnt; q++) d[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+        for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); const uint32_t m = bytes_equal(w[j], 0x3Cu); lt |= m; w[j] |= m; }
+        seen |= (special != 0 ? 1u : 0u) | (lt != 0 ? 2u : 0u);
+        if (fc) {                                                          // (null: the check alone -- r05: the stream is then the input itself, '<' mapped where it is loaded)
+            uint8_t *d = fc + P;
+            if (cnt == 16) *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+            else for (int q = 0; q < cnt; q++) d[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+        }
         if (Wp) {
             const int all = __syncthreads_and(same);
             if (threadIdx.x == 0) same_blk[chunk] = (uint8_t)all;
         }
+    }
+    const int any1 = __syncthreads_or(seen & 1u), any2 = __syncthreads_or(seen & 2u);
+    if (threadIdx.x == 0) {
+        const unsigned long long want = (any1 ? 1ull : 0ull) | (any2 ? 2ull : 0ull);
+        if (want & ~__atomic_load_n(flag, __ATOMIC_RELAXED)) atomicOr(flag, want);
     }
 }
 
@@ -745,6 +754,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
     if ((a.redo & 4u) && bx < HALO_TILES) return;                         // a section's halo: candidates for the tiles behind it, no chain of its own
     if (chain_tail().tchain[bx].walked == 2) return;                      // W-periodic (k_tile_periodic found so): no chain of its own, see there
+    const bool raw = (a.redo & 8u) != 0;                                  // fc is the INPUT (nothing in it needs an escape): '<' -> FF on the way into the stage (lzss.go:373-377)
     for (uint32_t v = tid; v < C::STAGE / 16; v += CTH) {
         const long long P = r0 + 16ll * v;
         uint4 x = {0, 0, 0, 0};
@@ -754,6 +764,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             for (int k = 0; k < 16; k++) { const long long q = P + k; if (q >= 0 && q < (long long)E) w[k >> 2] |= (uint32_t)a.fc[q] << (8 * (k & 3)); }
             x = {w[0], w[1], w[2], w[3]};
         }
+        if (raw) { x.x |= bytes_equal(x.x, 0x3Cu); x.y |= bytes_equal(x.y, 0x3Cu); x.z |= bytes_equal(x.z, 0x3Cu); x.w |= bytes_equal(x.w, 0x3Cu); }
         reinterpret_cast<uint4 *>(sw)[v] = x;
     }
     for (int i = tid; i < HNB / 2; i += CTH) s_cur[i] = 0;
@@ -1967,7 +1978,11 @@ __device__ __forceinline__ uint8_t *put_dec(uint8_t *o, uint32_t v) {
 __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc, const uint32_t *__restrict__ keys, uint32_t E,
                                                  const uint32_t *__restrict__ flags, const unsigned long long *__restrict__ tile_off,
                                                  uint8_t *__restrict__ out, const TileChain *__restrict__ tchain, uint32_t W,
-                                                 const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt) {
+                                                 const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt, uint32_t raw) {
+    // raw: fc is the INPUT, not a copy of it with '<' turned into FF (nothing in it needs an escape, lzss.go:373-379): the map is applied here,
+    // where its bytes are loaded (r05: the copy was N bytes written and read again for one byte value in 254)
+    auto map16 = [&](uint4 x) { if (raw) { x.x |= bytes_equal(x.x, 0x3Cu); x.y |= bytes_equal(x.y, 0x3Cu); x.z |= bytes_equal(x.z, 0x3Cu); x.w |= bytes_equal(x.w, 0x3Cu); } return x; };
+    auto map1 = [&](uint8_t v) -> uint8_t { return raw && v == 0x3C ? (uint8_t)0xFF : v; };
     constexpr int RP = LB * 16;                                    // positions per round
     constexpr int LE = 4, LR = LB * LE;                            // list form: entries per lane and per round (a round emits at most 11 * LR bytes)
     __shared__ uint32_t wsum[LB / 64];
@@ -1988,7 +2003,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             uint4 x = {0, 0, 0, 0};
             if (p + 16 <= E) x = *reinterpret_cast<const uint4 *>(fc + p);
             else if (p < E) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t k = 0; p + k < E; k++) w[k >> 2] |= (uint32_t)fc[p + k] << (8 * (k & 3)); x = {w[0], w[1], w[2], w[3]}; }
-            reinterpret_cast<uint4 *>(l_fc)[v] = x;
+            reinterpret_cast<uint4 *>(l_fc)[v] = map16(x);
         }
         for (int v = tid; v < (11 * LR + 64) / 16; v += LB) reinterpret_cast<uint4 *>(l_img)[v] = make_uint4(0u, 0u, 0u, 0u);   // the entries are ORed into it
         const uint32_t *cl = clist + (size_t)blockIdx.x * PT;
@@ -2081,7 +2096,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
                 const uint32_t L = min(W, E - x);                          // < W only for the stream's last token
                 uint8_t *o = out + run + (size_t)tid * enc_len(W, W);
                 if (enc_len(W, L) < L) { *o++ = '<'; o = put_dec(o, W); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
-                else for (uint32_t j = 0; j < L; j++) *o++ = fc[x + j];
+                else for (uint32_t j = 0; j < L; j++) *o++ = map1(fc[x + j]);
             }
         }
         return;
@@ -2111,9 +2126,9 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             for (uint32_t m = fw; m; m &= m - 1) {
                 const uint32_t p = rb + i0 + __builtin_ctz(m);
                 const uint32_t k = key_at(p), L = k >> 16, off = k & 0xFFFF;
-                if (L == 0) { *o++ = fc[p]; continue; }
+                if (L == 0) { *o++ = map1(fc[p]); continue; }
                 if (enc_len(off, L) < L) { *o++ = '<'; o = put_dec(o, off); *o++ = ','; o = put_dec(o, L); *o++ = '>'; }
-                else for (uint32_t j = 0; j < L; j++) *o++ = fc[p + j];
+                else for (uint32_t j = 0; j < L; j++) *o++ = map1(fc[p + j]);
             }
             run += tot;
             __syncthreads();
@@ -2132,7 +2147,7 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
             uint4 x = {0, 0, 0, 0};
             if (p + 16 <= E) x = *reinterpret_cast<const uint4 *>(fc + p);
             else if (p < E) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t k = 0; p + k < E; k++) w[k >> 2] |= (uint32_t)fc[p + k] << (8 * (k & 3)); x = {w[0], w[1], w[2], w[3]}; }
-            reinterpret_cast<uint4 *>(s_fc)[v] = x;
+            reinterpret_cast<uint4 *>(s_fc)[v] = map16(x);
         }
         __syncthreads();
         uint32_t mine = 0;
@@ -2171,14 +2186,21 @@ size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
 // longer one -- its first HALO_TILES tiles are window only and the chain enters at the first position behind them; stop_tile (0: none):
 // the section ends in front of that tile -- *out_n is then the bytes of the items that begin before it, *exit_pos where the chain first
 // lands in or behind it (the next section's entry).  d_same / Wp: k_esc_try's periodicity flags for this very stream, or null.
+// materialize (r05; may be empty): d_fc is the caller's INPUT, which needs no escape -- the chain walk and the token emitter map '<' to FF
+// where they load it (ChainArgs::redo bit 3, k_tok_emit's `raw`); every other kernel wants the escaped stream in memory, and the first
+// time one of them is about to run the callback writes that copy and returns it.
 static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint32_t W, const uint8_t *d_same, uint32_t Wp, bool copied,
-                              bool halo, uint32_t stop_tile, uint8_t *d_out, size_t out_cap, size_t *out_n, uint32_t *exit_pos) {
+                              bool halo, uint32_t stop_tile, uint8_t *d_out, size_t out_cap, size_t *out_n, uint32_t *exit_pos,
+                              const std::function<int(const uint8_t **)> &materialize = {}) {
     void *p; int rc;
+    bool raw = (bool)materialize;
+    auto need_copy = [&]() -> int { if (!raw) return RSN_OK; raw = false; return materialize(&d_fc); };
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     const uint32_t halo_bit = halo ? 4u : 0u;
     if (W > MAX_WINDOW) {
         if (halo || stop_tile) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %u", MAX_WINDOW);
+        rc = need_copy(); if (rc) return rc;
         return lzss_encode_big(c, s, d_fc, E, W, d_out, out_cap, out_n);   // lzss_big.hip: exact at any window, not fast
     }
     // ---- E2 + E3.  Chain mode (default, W <= 4096): keys only where greedy chains land, everything else
@@ -2193,6 +2215,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     const bool hashed = W <= HWMAX;
     if ((halo || stop_tile) && !hashed) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %d", HWMAX);
     bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
+    if (!chain_mode) { rc = need_copy(); if (rc) return rc; }
     auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 on every strip, or on the flagged ones
         MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only};
         const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
@@ -2249,11 +2272,11 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
-        ChainArgs hs{d_fc, E, W, d_keys, 2u | halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
+        ChainArgs hs{d_fc, E, W, d_keys, 2u | halo_bit | (raw ? 8u : 0u), nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
         rc = launch_chain("lzss_sample", SAMPLE_TILES, hs); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
-        if ((uint32_t)h64[3] * 4 >= SAMPLE_TILES * 3) chain_mode = false;
+        if ((uint32_t)h64[3] * 4 >= SAMPLE_TILES * 3) { chain_mode = false; rc = need_copy(); if (rc) return rc; }
     }
     if (chain_mode) {
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));   // (the keys are not cleared: k_chain_unknown marks the gaps if the general parse is needed)
@@ -2271,7 +2294,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
             if (!no_ckeys && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
         }
-        ChainArgs ha{d_fc, E, W, d_keys, halo_bit, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
+        ChainArgs ha{d_fc, E, W, d_keys, halo_bit | (raw ? 8u : 0u), nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
         rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
@@ -2345,7 +2368,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             const uint32_t n_plain = n_list - std::min(n_list, n_arith);         // entries that are not placed by arithmetic: tiles that gave up, joints to mend
             if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
             prev_plain = n_plain;
-            ha.redo = 3u | halo_bit; ha.tail.redo_list = d_redo_list;
+            ha.redo = 3u | halo_bit | (raw ? 8u : 0u); ha.tail.redo_list = d_redo_list;
             ha.tail.ckeys = nullptr; ha.tail.ckn = nullptr;                   // (a look's tiles are resolved by k_chain_tail, from the key array)
             rc = launch_chain("lzss_match_chain", n_list, ha); if (rc) return rc;
             rc = resolve(true, use_pred); if (rc) return rc;
@@ -2354,6 +2377,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         }
         parsed_by_walk = parsed;
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
+            rc = need_copy(); if (rc) return rc;                      // (the bucket search, the sweep and the general parse read the escaped stream itself)
             RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
             RSN_LAUNCH("lzss_match_hash", k_match_hash, dim3((uint32_t)ceil_div(E, HT)), dim3(HTH), 0, s, hd);   // the strips the chain walk found dense
@@ -2413,7 +2437,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     if (total > out_cap) { *out_n = round_up(total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %zu bytes, buffer holds %zu", total, out_cap); }
     // ---- E4
     RSN_LAUNCH("lzss_tok_emit", k_tok_emit, dim3(stop_tile && stop_tile < n_pt ? stop_tile : n_pt), dim3(LB), 0, s, d_fc, d_keys, E, d_flags, d_toff, d_out, (const TileChain *)(chain_mode ? d_tchain : nullptr), W,
-               (const uint32_t *)(parsed_by_walk ? d_clist : nullptr), (const uint32_t *)(parsed_by_walk ? d_ccnt : nullptr));
+               (const uint32_t *)(parsed_by_walk ? d_clist : nullptr), (const uint32_t *)(parsed_by_walk ? d_ccnt : nullptr), raw ? 1u : 0u);
     RSN_HIP(hipStreamSynchronize(s));
     return RSN_OK;
 }
@@ -2442,21 +2466,21 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
-    bool copied = false;                                              // d_fc already holds the escaped stream (nothing needed an escape)
+    bool copied = false;                                              // nothing in the input needs an escape: E = n, every byte keeps its place
     // (the window, should nothing need an escape -- then E = n; a multiple of 16 for k_esc_try's periodicity flags, see there)
     const uint32_t Wp = window > 0 && (uint64_t)window <= HWMAX && (uint64_t)window < n && window % 16 == 0 ? (uint32_t)window : 0u;
     uint8_t *d_same = nullptr;
-    {
-        rc = dev_buf(c, 9, n + 64, &p); if (rc) return rc;
-        if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
-        RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
-        RSN_HIP(hipMemsetAsync((uint8_t *)p + n, 0, 64, s));          // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)p, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
-        RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
-        RSN_HIP(hipStreamSynchronize(s));
-        copied = h64[0] == 0;
-        h64[0] = 0;
-    }
+    // The check first (r05: a READ of the input -- does anything need an escape, is there a '<', which 4 KiB chunks repeat the bytes Wp
+    // before them): most inputs hold no 5C and no FF, and then the escaped stream is the input with '<' mapped to FF (lzss.go:373-377),
+    // which the chain walk and the token emitter can do where they load it.  The copy (r04 wrote it here, N bytes out and N back in for
+    // one byte value in 254: half of config 3's traffic) is written only if a kernel that wants the stream in memory has to run.
+    if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
+    RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
+    RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)nullptr, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
+    RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    copied = (h64[0] & 1ull) == 0;
+    h64[0] = 0;
     if (!copied) {
         RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
         rc = scan_u64(c, s, "lzss_scan", d_extra, d_eoff, n_eb, d_etot); if (rc) return rc;
@@ -2464,12 +2488,15 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
         RSN_HIP(hipStreamSynchronize(s));
     }
     const size_t E64 = n + (size_t)h64[0];
-    rc = dev_buf(c, 9, E64 + 64, &p); if (rc) return rc;
-    uint8_t *d_fc = (uint8_t *)p;
-    if (!copied) {
-        RSN_HIP(hipMemsetAsync(d_fc + E64, 0, 64, s));                // readable padding behind the stream
-        RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
-    }
+    uint8_t *d_fc = nullptr;
+    auto write_stream = [&]() -> int {                                // the escaped stream in memory (slot 9), zeroed padding behind it
+        void *q; int r2 = dev_buf(c, 9, E64 + 64, &q); if (r2) return r2;
+        d_fc = (uint8_t *)q;
+        RSN_HIP(hipMemsetAsync(d_fc + E64, 0, 64, s));
+        if (copied) RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, d_fc, d_etot + 1, 0u, (uint8_t *)nullptr, n_eb);
+        else RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
+        return RSN_OK;
+    };
     // One pass takes a stream of up to SEC_MAX positions (32-bit positions, and ~10 bytes of scratch per position); a longer one goes
     // section by section (RSN_LZSS_SECTION_MIB: a smaller section, for the tests).
     static const size_t sec_env = [] { const char *e = getenv("RSN_LZSS_SECTION_MIB"); return e && atoi(e) > 0 ? (size_t)atoi(e) << 20 : (size_t)0; }();
@@ -2481,8 +2508,13 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
         if (window <= 0) W = E;                                       // unbounded search buffer (lzss.go:125)
         else W = (uint32_t)std::min<uint64_t>((uint64_t)window, E);   // a window longer than the stream never binds
         if (W == 0) W = 1;
+        if (copied)                                                   // the input IS the stream up to the '<' map: no copy unless a kernel asks for one
+            return lzss_encode_stream(c, s, d_in, E, W, d_same, Wp, copied, false, 0, d_out, out_cap, out_n, nullptr,
+                                      [&](const uint8_t **fcp) -> int { const int r2 = write_stream(); *fcp = d_fc; return r2; });
+        rc = write_stream(); if (rc) return rc;
         return lzss_encode_stream(c, s, d_fc, E, W, d_same, Wp, copied, false, 0, d_out, out_cap, out_n, nullptr);
     }
+    rc = write_stream(); if (rc) return rc;                           // (sections are cut out of the stream in memory)
     // ---- sections: [entry, entry + sec) each, entry = where the chain left the section before (lzss.go:134-151 is one serial walk: the
     //      only thing a section needs from its predecessors is that position and the W bytes in front of it)
     if (window <= 0 || (uint64_t)window > HWMAX) return c.fail(RSN_ERR_LIMIT, "lzss: %zu escaped bytes need sections, which take windows up to %d (asked: %lld)", E64, HWMAX, (long long)window);
