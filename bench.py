@@ -437,21 +437,28 @@ def config1_and_host_api(torch, device, n, with_host_gib):
             d, td = _host_call(L.rsn_lzss_decompress, c)
         ha["lzss_text"] = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src)),
                            "encode_GBps": round(n / te / 1e6, 2), "decode_GBps": round(n / td / 1e6, 2)}
-        # the same Huffman calls from a plain C++ process (what a cgo caller is like): the pipelined decode overlaps its two transfers
-        # there -- 24.4 against 37 ms -- and, for a reason r05 did not find, not inside a Python process (36 ms either way)
+        # the same calls from a plain C++ process (what a cgo caller is like), pipelined and with RSN_HOST_SERIAL=1: the pipelined Huffman
+        # decode overlaps its two transfers there -- 24.4 against 37 ms -- and, for a reason r05 did not find, not inside a Python
+        # process (36 ms either way); the pipelined LZSS encode hides both transfers under the encoder
+        text_file = "/tmp/rsn_bench_text_%d.bin" % os.getpid()
         try:
             import subprocess
             exe = "/tmp/rsn_host_call_probe"
             subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "scripts", "probes", "host_call_probe.cpp"),
                                    "-L" + os.path.join(ROOT, "raisin_amd"), "-lrsn", "-Wl,-rpath," + os.path.join(ROOT, "raisin_amd")])
-            res = {}
-            for label, env in (("pipelined", {}), ("serial", {"RSN_HOST_SERIAL": "1"})):
-                r = subprocess.run([exe, str(n >> 20), "0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-                line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
-                res[label] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
-            ha["huffman_2a_like_from_a_c_process"] = res
+            src.tofile(text_file)
+            for key, kind in (("huffman_2a_like_from_a_c_process", "0"), ("lzss_text_from_a_c_process", "@" + text_file)):
+                res = {}
+                for label, env in (("pipelined", {}), ("serial", {"RSN_HOST_SERIAL": "1"})):
+                    r = subprocess.run([exe, str(n >> 20), kind], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+                    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
+                    res[label] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+                ha[key] = res
         except Exception as e:                              # noqa: BLE001
-            ha["huffman_2a_like_from_a_c_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            ha["from_a_c_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            if os.path.exists(text_file):
+                os.remove(text_file)
         out["host_api"] = ha
         L.rsn_trim()
     return out

@@ -27,13 +27,17 @@ bool huff_flat_code(const HuffTree &tree, const HuffCodes &codes);
 // the later ones decode): the decoder asks for its input as it needs it and announces its output as it becomes final.  The stream is one
 // bit string without a block index (huffman.go:258-297), so a slice starts exactly where its predecessor's last codeword ended -- the
 // hand-over is that bit position and the output offset, nothing else.
-struct HuffStream {
+struct SliceStream {
     std::function<bool(size_t)> need_in;            // returns once d_in[0, bytes) is on the device; false: give up (the call fails)
     std::function<bool(size_t, size_t)> have_out;   // d_out[off, off + len) is final; false: give up
+    std::function<size_t()> in_so_far;              // how much of d_in is on the device now (does not wait; may be empty)
     size_t slice_bytes = (size_t)32 << 20;          // payload bytes per slice (a multiple of 8 KiB: whole blocks of subsequences)
 };
-int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const HuffStream *st = nullptr);
+int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream *st = nullptr);
 int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
+// the same in SECTIONS as the input lands (a host-buffer call, rsn_api.hip): returns 1 when the input is not for it -- something in it needs
+// an escape, or the window is not one the sections take -- and the caller encodes it whole.  slice_bytes = positions per section.
+int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream &st);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
 // exclusive scan of n counts on the stream (huff_encode.hip); *total (may be null) receives the sum; in and out must not overlap

@@ -713,7 +713,7 @@ int rep_for(int K) {   // replicate small tables up to 32x (one copy per LDS ban
 
 }  // namespace
 
-int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const HuffStream *st) {
+int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream *st) {
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "huffman: device buffers must be 16-byte aligned");
     *out_n = 0;
     // ---- header to the host: strings.SplitN(content, "\\\n", 2) (huffman.go:261)

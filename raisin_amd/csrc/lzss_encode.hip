@@ -26,6 +26,7 @@
 // LDS read), the run counters move one lane down per step (DPP wave_shl:1) and every (i,d)
 // pair costs O(1) regardless of the data.
 #include "codecs.h"
+#include <chrono>
 
 namespace rsn {
 
@@ -2539,6 +2540,90 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
         rc = lzss_encode_stream(c, s, fc_s, Es, std::min(W, Es), nullptr, 0, copied, halo, stop_tile, d_out + written, out_cap > written ? out_cap - written : 0, &got, &exit_local);
         if (rc == RSN_ERR_CAPACITY) { *out_n = lzss_compress_bound(n); return rc; }
         if (rc) return rc;
+        written += got;
+        if (last) break;
+        if ((size_t)exit_local < entry - a0 + sec || exit_local > Es) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: a section's chain left it at %u", exit_local);
+        entry = a0 + exit_local;
+    }
+    *out_n = written;
+    return RSN_OK;
+}
+
+// '<' -> FF in place: a section's copy of the INPUT becomes the escaped stream it stands for (nothing in it needs an escape)
+__global__ __launch_bounds__(LB) void k_map3c(uint8_t *p, size_t n) {
+    const size_t P = ((size_t)blockIdx.x * LB + threadIdx.x) * 16;
+    if (P + 16 <= n) {
+        uint4 x = *reinterpret_cast<uint4 *>(p + P);
+        x.x |= bytes_equal(x.x, 0x3Cu); x.y |= bytes_equal(x.y, 0x3Cu); x.z |= bytes_equal(x.z, 0x3Cu); x.w |= bytes_equal(x.w, 0x3Cu);
+        *reinterpret_cast<uint4 *>(p + P) = x;
+    } else for (size_t k = P; k < n; k++) if (p[k] == 0x3C) p[k] = 0xFF;
+}
+
+// The encoder in SECTIONS as the input lands (a host-buffer call whose upload is still running, rsn_api.hip piped_call): the same
+// sections a stream of 2 GiB and more takes (above) -- entry = where the chain left the section before, 64 halo tiles in front of it,
+// W bytes of look-ahead behind it -- only smaller, each encoded as soon as its bytes are on the device and announced as soon as its
+// tokens are final, so that the upload of the next and the download of the last run under it.  For inputs in which nothing needs an
+// escape (the escaped stream is then the input, position for position; checked range by range as it arrives): anything else returns 1
+// before a byte of output has been announced, and the caller encodes it whole.  Same bytes as the single pass (tested).
+int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream &st) {
+    *out_n = 0;
+    static const bool dbg = getenv("RSN_DEBUG") != nullptr;
+    if (window <= 0 || (uint64_t)window > HWMAX) return 1;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return c.fail(RSN_ERR_ARG, "lzss: device buffers must be 16-byte aligned");
+    const uint32_t W = (uint32_t)window;
+    const size_t halo_len = (size_t)HALO_TILES * PT;
+    const size_t sec = std::max<size_t>(st.slice_bytes, 4 * halo_len) / PT * PT;
+    if (n < 2 * sec || n >= ((size_t)1 << 40)) { if (dbg) fprintf(stderr, "lzss sliced: %zu bytes are not worth sections of %zu\n", n, sec); return 1; }
+    // what the sections have produced is ANNOUNCED (and goes down) only once the whole input has been checked: an escape in the last range
+    // would otherwise turn up behind output that is already on its way
+    const auto t_in = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
+    std::vector<std::pair<size_t, size_t>> held;
+    auto announce = [&](bool all_checked) -> bool { if (!all_checked) return true; for (auto &r : held) if (!st.have_out(r.first, r.second)) return false; held.clear(); return true; };
+    void *p; int rc;
+    rc = dev_buf(c, 8, 64, &p); if (rc) return rc;
+    unsigned long long *d_flag = (unsigned long long *)p;
+    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    unsigned long long *h64 = (unsigned long long *)hp;
+    RSN_HIP(hipMemsetAsync(d_flag, 0, 8, s));
+    size_t entry = 0, written = 0, checked = 0;
+    void *sp = nullptr;
+    while (entry < n) {
+        const bool halo = entry >= halo_len;
+        const size_t a0 = halo ? entry - halo_len : 0;
+        const bool last = n - entry <= sec + sec / 4;
+        const size_t b0 = last ? n : entry + sec + W;
+        const size_t upto = last ? n : std::min(n, round_up(b0, (size_t)ESC_TILE));      // (whole 4 KiB chunks: the check's unit)
+        if (!st.need_in(upto)) return c.fail(RSN_ERR_DEVICE, "lzss: the upload of a sliced call failed");
+        if (dbg) fprintf(stderr, "lzss sliced: +%.2f ms: input below %zu is up\n", since(), upto);
+        size_t upto_chk = upto;                                        // (as far as the upload has come: the sooner the end has been seen, the sooner the output moves)
+        if (st.in_so_far) { const size_t up = st.in_so_far(); upto_chk = std::max(upto, up >= n ? n : up / ESC_TILE * ESC_TILE); }
+        if (upto_chk > checked) {                                     // does anything in the new range need an escape?  (lzss.go:378-379)
+            const size_t upto = upto_chk, m = upto - checked;
+            const uint32_t n_eb = (uint32_t)ceil_div(m, ESC_TILE);
+            RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in + checked, m, (uint8_t *)nullptr, d_flag, 0u, (uint8_t *)nullptr, n_eb);
+            RSN_HIP(hipMemcpyAsync(h64, d_flag, 8, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            if (h64[0] & 1ull) { if (dbg) fprintf(stderr, "lzss sliced: a byte that needs an escape below position %zu: encoded whole instead\n", upto); return 1; }
+            checked = upto;
+            if (!announce(checked == n)) return c.fail(RSN_ERR_DEVICE, "lzss: the download of a sliced call failed");
+        }
+        const uint32_t Es = (uint32_t)(b0 - a0);
+        const uint32_t stop_tile = last ? 0u : (uint32_t)((entry - a0 + sec) / PT);
+        rc = dev_buf(c, 36, (size_t)Es + 64, &sp); if (rc) return rc;
+        RSN_HIP(hipMemcpyAsync(sp, d_in + a0, Es, hipMemcpyDeviceToDevice, s));
+        RSN_HIP(hipMemsetAsync((uint8_t *)sp + Es, 0, 64, s));
+        size_t got = 0; uint32_t exit_local = 0;
+        rc = lzss_encode_stream(c, s, (const uint8_t *)sp, Es, std::min(W, Es), nullptr, 0, true, halo, stop_tile, d_out + written, out_cap > written ? out_cap - written : 0, &got, &exit_local,
+                                [&](const uint8_t **fcp) -> int {     // (the section's copy is the input: mapped in place should a kernel want the stream itself)
+                                    RSN_LAUNCH("lzss_esc_write", k_map3c, dim3((uint32_t)ceil_div((size_t)Es, (size_t)LB * 16)), dim3(LB), 0, s, (uint8_t *)sp, (size_t)Es);
+                                    *fcp = (const uint8_t *)sp;
+                                    return RSN_OK;
+                                });
+        if (rc) return rc;                                            // (RSN_ERR_CAPACITY: the caller's buffer was sized for an input without escapes -- cannot happen; reported as it is)
+        held.emplace_back(written, got);
+        if (!announce(checked == n)) return c.fail(RSN_ERR_DEVICE, "lzss: the download of a sliced call failed");
+        if (dbg) fprintf(stderr, "lzss sliced: +%.2f ms: section [%zu, %zu) -> %zu bytes at %zu%s\n", since(), entry, b0, got, written, checked == n ? "" : " (held: input not checked to its end yet)");
         written += got;
         if (last) break;
         if ((size_t)exit_local < entry - a0 + sec || exit_local > Es) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: a section's chain left it at %u", exit_local);

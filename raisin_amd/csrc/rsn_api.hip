@@ -339,6 +339,136 @@ int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t 
     return RSN_OK;
 }
 
+// ---- a host-buffer call as a PIPELINE: an uploader thread sends the input up in pieces, the calling thread runs the codec in slices as
+// they land (`run` gets a SliceStream), a downloader thread brings every finished range of the output down while the next is produced.
+// out_cap: what the output can take at most (the result block and the device buffer are that large); codec_need: the codec's scratch, for
+// the admission.  `run` returns 1 when the stream turns out not to be for slicing: the caller then takes the serial call.
+template <class Run>
+static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_need, uint8_t **out, size_t *out_n, Run run) {
+    // Pieces of 64 MiB, each REGISTERED (pinned in place, hipHostRegister: 0.65 ms for 64 MiB) before its copy is queued, the next
+    // piece's registration under the copy of this one: copies of pageable memory in pieces ran at half the link's rate once the other
+    // direction was busy too (measured: 27 ms up + the download behind it = the serial call's 36 ms; two 256 MiB copies at once: 94 GB/s).
+    // The registrations are RELEASED when the codec has returned, not piece by piece: hipHostUnregister waits for every stream of the
+    // process, the codec's kernels included (scripts/probes/copy_under_kernel.hip: 256 MiB up beside a 20 ms kernel in 4.8 ms when the
+    // pieces stay registered, in 24-35 ms when each is released behind its copy -- the upload then only moves between kernels).
+    constexpr size_t PIECE = (size_t)64 << 20;
+    // [lo, hi) of a host range whose pages no neighbouring piece shares: piece k of a buffer at `base` is [cut(k), cut(k + 1))
+    auto cut = [](const uint8_t *base, size_t total, size_t k) -> size_t {
+        if (k == 0) return 0;
+        const uintptr_t a = ((uintptr_t)base + k * PIECE + 4095) & ~(uintptr_t)4095;
+        return std::min(total, (size_t)(a - (uintptr_t)base));
+    };
+    Ctx &c = ctx();
+    int rc = ctx_init(c); if (rc) return rc;
+    hipStream_t s = c.own_stream;
+    struct Admitted { Ctx &c; size_t held; ~Admitted() { scratch_release(c, held, (3ull << 20) | (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35)); } };
+    Admitted gate{c, scratch_admit(c, round_up(n, 16) + 64 + out_cap + codec_need)};
+    void *d_in, *d_out;
+    rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
+    rc = dev_buf(c, 21, round_up(out_cap, 16) + 64, &d_out); if (rc) return rc;
+    uint8_t *res = (uint8_t *)result_alloc(out_cap);
+    if (!res) return c.fail(RSN_ERR_NOMEM, "allocating %zu result bytes failed", out_cap);
+    RSN_HIP(hipMemsetAsync((uint8_t *)d_in + (n & ~(size_t)15), 0, 64, s));
+    RSN_HIP(hipStreamSynchronize(s));                                     // (before the uploader's first piece lands on the same bytes)
+
+    struct Pipe {
+        std::mutex mu; std::condition_variable cv;
+        size_t uploaded = 0;                                              // bytes of the stream on the device
+        std::vector<std::pair<size_t, size_t>> ready;                     // decoded ranges not yet asked for by the downloader
+        size_t taken = 0; bool decoded_all = false, failed = false; std::string msg;
+        void fail(const char *m) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } cv.notify_all(); }
+    } P;
+    const int device = c.device;
+    static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<char> in_pinned((n + PIECE - 1) / PIECE + 2, 0);         // the input's pieces that are registered (released below)
+    std::thread uploader([&] {
+        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
+        hipStream_t su = ctx().own_stream;
+        std::vector<char> &pinned = in_pinned;
+        auto pin = [&](size_t k) { const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1); if (hi > lo) pinned[k] = hipHostRegister((void *)(in + lo), hi - lo, hipHostRegisterDefault) == hipSuccess; if (hi > lo && !pinned[k]) (void)hipGetLastError(); };
+        pin(0);
+        for (size_t k = 0; cut(in, n, k) < n; k++) {
+            const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1);
+            hipError_t e = hipMemcpyAsync((uint8_t *)d_in + lo, in + lo, hi - lo, hipMemcpyHostToDevice, su);
+            if (e == hipSuccess && hi < n) pin(k + 1);                        // (under this piece's copy)
+            if (e == hipSuccess) e = hipStreamSynchronize(su);
+            if (e != hipSuccess) { P.fail(hipGetErrorString(e)); return; }
+            { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) return; P.uploaded = hi; }
+            P.cv.notify_all();
+        }
+        if (timing) { size_t np_ = 0; for (char x : pinned) np_ += x != 0; fprintf(stderr, "piped call: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
+    });
+    std::thread downloader([&] {
+        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
+        hipStream_t sd = ctx().own_stream;
+        const size_t total_out = out_cap;
+        std::vector<char> pinned((total_out + PIECE - 1) / PIECE + 1, 0);
+        size_t next_pin = 0;                                              // pieces of the result block below this index have been tried
+        for (;;) {
+            std::pair<size_t, size_t> r;
+            {
+                std::unique_lock<std::mutex> lk(P.mu);
+                P.cv.wait(lk, [&] { return P.failed || P.taken < P.ready.size() || P.decoded_all; });
+                if (P.failed || P.taken >= P.ready.size()) break;
+                r = P.ready[P.taken++];
+            }
+            if (!r.second) continue;
+            auto pin_below = [&](size_t limit) {                              // the pieces of the result block that begin below `limit`
+                while (cut(res, total_out, next_pin) < std::min(total_out, limit)) {
+                    const size_t lo = cut(res, total_out, next_pin), hi = cut(res, total_out, next_pin + 1);
+                    if (hi > lo) { pinned[next_pin] = hipHostRegister(res + lo, hi - lo, hipHostRegisterDefault) == hipSuccess; if (!pinned[next_pin]) (void)hipGetLastError(); }
+                    next_pin++;
+                }
+            };
+            pin_below(r.first + r.second);                                    // the pieces this range lands in (all but the first call's were pinned a range ahead)
+            hipError_t e = hipSuccess;                                        // (a copy may not straddle two registrations: cut at the pieces' edges)
+            for (size_t at = r.first, end = r.first + r.second; at < end && e == hipSuccess;) {
+                size_t k = at / PIECE;                                        // the piece that holds `at`: cut(k) <= at < cut(k + 1)
+                while (cut(res, total_out, k + 1) <= at) k++;
+                while (k > 0 && cut(res, total_out, k) > at) k--;
+                const size_t stop = std::min(end, cut(res, total_out, k + 1));
+                e = hipMemcpyAsync(res + at, (const uint8_t *)d_out + at, stop - at, hipMemcpyDeviceToHost, sd);
+                at = stop;
+            }
+            if (e == hipSuccess) pin_below(r.first + 2 * r.second);            // under these copies: where the next range will land
+            if (e == hipSuccess) e = hipStreamSynchronize(sd);
+            if (e != hipSuccess) { P.fail(hipGetErrorString(e)); break; }
+            if (timing) fprintf(stderr, "piped call: [%zu, +%zu) down by +%.2f ms\n", r.first, r.second, since());
+        }
+        if (timing) { size_t np_ = 0; for (size_t k = 0; k < next_pin; k++) np_ += pinned[k] != 0; fprintf(stderr, "piped call: %zu of %zu pieces of the result registered\n", np_, next_pin); }
+        for (size_t k = 0; k < next_pin; k++) if (pinned[k]) (void)hipHostUnregister(res + cut(res, total_out, k));
+    });
+    SliceStream st;
+    st.slice_bytes = (size_t)64 << 20;
+    st.need_in = [&](size_t bytes) { std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.failed || P.uploaded >= std::min(bytes, n); }); return !P.failed; };
+    st.in_so_far = [&] { std::lock_guard<std::mutex> lk(P.mu); return P.uploaded; };
+    st.have_out = [&](size_t off, size_t len) {
+        if (timing) fprintf(stderr, "piped call: [%zu, +%zu) decoded by +%.2f ms\n", off, len, since());
+        { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) return false; P.ready.emplace_back(off, len); }
+        P.cv.notify_all();
+        return true;
+    };
+    size_t got = 0;
+    rc = run(c, s, (const uint8_t *)d_in, (uint8_t *)d_out, out_cap, &got, &st);
+    if (rc != RSN_OK) P.fail(c.err.c_str());                              // (stops both threads)
+    { std::lock_guard<std::mutex> lk(P.mu); P.decoded_all = true; }
+    P.cv.notify_all();
+    uploader.join();
+    downloader.join();
+    (void)hipSetDevice(c.device);
+    for (size_t k = 0; k < in_pinned.size(); k++) if (in_pinned[k]) (void)hipHostUnregister((void *)(in + cut(in, n, k)));
+    trim_parked_excess(c.device);                                         // (the two threads have parked their contexts)
+    if (timing) fprintf(stderr, "piped call: the codec returned %d (%s) at +%.2f ms\n", rc, rc > 0 || rc == RSN_OK ? "" : c.err.c_str(), since());
+    if (rc == RSN_ERR_CAPACITY || rc == 1) { result_free(res); return 1; }   // more output than the caller allowed for, or not a stream for slices: the serial call
+    if (rc != RSN_OK && P.failed && P.msg != c.err) { result_free(res); return c.fail(rc, "%s (%s)", std::string(c.err).c_str(), P.msg.c_str()); }
+    if (rc != RSN_OK) { result_free(res); return rc; }
+    if (P.failed) { result_free(res); return c.fail(RSN_ERR_DEVICE, "a transfer of the pipelined call failed: %s", P.msg.c_str()); }
+    *out = res; *out_n = got;
+    return RSN_OK;
+}
+
 // the codecs read d_in while they write d_out: the two ranges must not overlap
 bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
     if (!a || !b || !na || !nb) return false;
@@ -473,23 +603,14 @@ static int huffman_decompress_serial(const uint8_t *in, size_t n, uint8_t **out,
 // A large host-buffer decode as a PIPELINE (what the cgo shim binds was upload, then codec, then download -- 16 + 0.5 + 19 ms
 // for a GiB of 2a, the codec the smallest part).  The header is on the host already: its counts give the output's size (what a stream this
 // library or the reference wrote decodes to), so the result block and both device buffers exist before a byte has moved; an uploader thread
-// sends the stream up in pieces, this thread decodes slice after slice as the pieces land (huff_decode_dev with a HuffStream: a slice
+// sends the stream up in pieces, this thread decodes slice after slice as the pieces land (huff_decode_dev with a SliceStream: a slice
 // starts where its predecessor's last codeword ended), a downloader thread brings every finished slice down while the next decodes.  PCIe
 // is full duplex: the call takes the longer of the two transfers, not their sum.  A stream whose payload decodes to more than its header
 // says (a foreign header: the counts only shape the tree) is decoded again by the serial call.  ENCODE has nothing to overlap: the first
 // output byte -- header counts, pad (huffman.go:245-255) -- depends on the last input byte.
 // Returns 1 when the stream is not for this path (small, malformed, foreign): the caller takes the serial call, which also words the errors.
 static int huffman_decompress_piped(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
-    // Pieces of 64 MiB, each REGISTERED (pinned in place, hipHostRegister: 0.65 ms for 64 MiB) before its copy is queued, the next
-    // piece's registration under the copy of this one: copies of pageable memory in pieces ran at half the link's rate once the other
-    // direction was busy too (measured: 27 ms up + the download behind it = the serial call's 36 ms; two 256 MiB copies at once: 94 GB/s).
-    constexpr size_t PIPE_MIN = (size_t)32 << 20, PIECE = (size_t)64 << 20;
-    // [lo, hi) of a host range whose pages no neighbouring piece shares: piece k of a buffer at `base` is [cut(k), cut(k + 1))
-    auto cut = [](const uint8_t *base, size_t total, size_t k) -> size_t {
-        if (k == 0) return 0;
-        const uintptr_t a = ((uintptr_t)base + k * PIECE + 4095) & ~(uintptr_t)4095;
-        return std::min(total, (size_t)(a - (uintptr_t)base));
-    };
+    constexpr size_t PIPE_MIN = (size_t)32 << 20;
     if (n < PIPE_MIN) return 1;
     // ---- the header: strings.SplitN(content, "\\\n", 2) (huffman.go:261), the counts (huffman.go:196-227)
     size_t sep = (size_t)-1;
@@ -508,113 +629,10 @@ static int huffman_decompress_piped(const uint8_t *in, size_t n, uint8_t **out, 
         expect += sy.freq * (unsigned long long)utf8_len(sy.rune);
     }
     if (expect == 0) return 1;
-    Ctx &c = ctx();
-    int rc = ctx_init(c); if (rc) return rc;
-    hipStream_t s = c.own_stream;
-    struct Admitted { Ctx &c; size_t held; ~Admitted() { scratch_release(c, held, (3ull << 20) | (0xFFFull << 8) | (0x3Full << 22) | (3ull << 35)); } };
-    Admitted gate{c, scratch_admit(c, round_up(n, 16) + 64 + (size_t)expect + n / 8)};
-    void *d_in, *d_out;
-    rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
-    rc = dev_buf(c, 21, round_up((size_t)expect, 16) + 64, &d_out); if (rc) return rc;
-    uint8_t *res = (uint8_t *)result_alloc((size_t)expect);
-    if (!res) return c.fail(RSN_ERR_NOMEM, "allocating %llu result bytes failed", expect);
-    RSN_HIP(hipMemsetAsync((uint8_t *)d_in + (n & ~(size_t)15), 0, 64, s));
-    RSN_HIP(hipStreamSynchronize(s));                                     // (before the uploader's first piece lands on the same bytes)
-
-    struct Pipe {
-        std::mutex mu; std::condition_variable cv;
-        size_t uploaded = 0;                                              // bytes of the stream on the device
-        std::vector<std::pair<size_t, size_t>> ready;                     // decoded ranges not yet asked for by the downloader
-        size_t taken = 0; bool decoded_all = false, failed = false; std::string msg;
-        void fail(const char *m) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } cv.notify_all(); }
-    } P;
-    const int device = c.device;
-    static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    std::thread uploader([&] {
-        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
-        hipStream_t su = ctx().own_stream;
-        const size_t n_pieces = (n + PIECE - 1) / PIECE + 1;
-        std::vector<char> pinned(n_pieces, 0);
-        auto pin = [&](size_t k) { const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1); if (hi > lo) pinned[k] = hipHostRegister((void *)(in + lo), hi - lo, hipHostRegisterDefault) == hipSuccess; if (hi > lo && !pinned[k]) (void)hipGetLastError(); };
-        pin(0);
-        for (size_t k = 0; cut(in, n, k) < n; k++) {
-            const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1);
-            hipError_t e = hipMemcpyAsync((uint8_t *)d_in + lo, in + lo, hi - lo, hipMemcpyHostToDevice, su);
-            if (e == hipSuccess && hi < n) pin(k + 1);                        // (under this piece's copy)
-            if (e == hipSuccess) e = hipStreamSynchronize(su);
-            if (pinned[k]) (void)hipHostUnregister((void *)(in + lo));
-            if (e != hipSuccess) { if (hi < n && pinned[k + 1]) (void)hipHostUnregister((void *)(in + hi)); P.fail(hipGetErrorString(e)); return; }
-            { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) { if (hi < n && pinned[k + 1]) (void)hipHostUnregister((void *)(in + hi)); return; } P.uploaded = hi; }
-            P.cv.notify_all();
-        }
-        if (timing) { size_t np_ = 0; for (char x : pinned) np_ += x != 0; fprintf(stderr, "piped decode: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
-    });
-    std::thread downloader([&] {
-        if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
-        hipStream_t sd = ctx().own_stream;
-        const size_t total_out = (size_t)expect;
-        std::vector<char> pinned((total_out + PIECE - 1) / PIECE + 1, 0);
-        size_t next_pin = 0;                                              // pieces of the result block below this index have been tried
-        for (;;) {
-            std::pair<size_t, size_t> r;
-            {
-                std::unique_lock<std::mutex> lk(P.mu);
-                P.cv.wait(lk, [&] { return P.failed || P.taken < P.ready.size() || P.decoded_all; });
-                if (P.failed || P.taken >= P.ready.size()) break;
-                r = P.ready[P.taken++];
-            }
-            if (!r.second) continue;
-            auto pin_below = [&](size_t limit) {                              // the pieces of the result block that begin below `limit`
-                while (cut(res, total_out, next_pin) < std::min(total_out, limit)) {
-                    const size_t lo = cut(res, total_out, next_pin), hi = cut(res, total_out, next_pin + 1);
-                    if (hi > lo) { pinned[next_pin] = hipHostRegister(res + lo, hi - lo, hipHostRegisterDefault) == hipSuccess; if (!pinned[next_pin]) (void)hipGetLastError(); }
-                    next_pin++;
-                }
-            };
-            pin_below(r.first + r.second);                                    // the pieces this range lands in (all but the first call's were pinned a range ahead)
-            hipError_t e = hipSuccess;                                        // (a copy may not straddle two registrations: cut at the pieces' edges)
-            for (size_t at = r.first, end = r.first + r.second; at < end && e == hipSuccess;) {
-                size_t k = at / PIECE;                                        // the piece that holds `at`: cut(k) <= at < cut(k + 1)
-                while (cut(res, total_out, k + 1) <= at) k++;
-                while (k > 0 && cut(res, total_out, k) > at) k--;
-                const size_t stop = std::min(end, cut(res, total_out, k + 1));
-                e = hipMemcpyAsync(res + at, (const uint8_t *)d_out + at, stop - at, hipMemcpyDeviceToHost, sd);
-                at = stop;
-            }
-            if (e == hipSuccess) pin_below(r.first + 2 * r.second);            // under these copies: where the next range will land
-            if (e == hipSuccess) e = hipStreamSynchronize(sd);
-            if (e != hipSuccess) { P.fail(hipGetErrorString(e)); break; }
-            if (timing) fprintf(stderr, "piped decode: [%zu, +%zu) down by +%.2f ms\n", r.first, r.second, since());
-        }
-        if (timing) { size_t np_ = 0; for (size_t k = 0; k < next_pin; k++) np_ += pinned[k] != 0; fprintf(stderr, "piped decode: %zu of %zu pieces of the result registered\n", np_, next_pin); }
-        for (size_t k = 0; k < next_pin; k++) if (pinned[k]) (void)hipHostUnregister(res + cut(res, total_out, k));
-    });
-    HuffStream st;
-    st.slice_bytes = (size_t)64 << 20;
-    st.need_in = [&](size_t bytes) { std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.failed || P.uploaded >= std::min(bytes, n); }); return !P.failed; };
-    st.have_out = [&](size_t off, size_t len) {
-        if (timing) fprintf(stderr, "piped decode: [%zu, +%zu) decoded by +%.2f ms\n", off, len, since());
-        { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) return false; P.ready.emplace_back(off, len); }
-        P.cv.notify_all();
-        return true;
-    };
-    size_t got = 0;
-    rc = huff_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, (size_t)expect, &got, &st);
-    if (rc != RSN_OK) P.fail(c.err.c_str());                              // (stops both threads)
-    { std::lock_guard<std::mutex> lk(P.mu); P.decoded_all = true; }
-    P.cv.notify_all();
-    uploader.join();
-    downloader.join();
-    (void)hipSetDevice(c.device);
-    trim_parked_excess(c.device);                                         // (the two threads have parked their contexts)
-    if (rc == RSN_ERR_CAPACITY) { result_free(res); return 1; }           // decodes to more than the header says: the serial call sizes it
-    if (rc != RSN_OK && P.failed && P.msg != c.err) { result_free(res); return c.fail(rc, "%s (%s)", std::string(c.err).c_str(), P.msg.c_str()); }
-    if (rc != RSN_OK) { result_free(res); return rc; }
-    if (P.failed) { result_free(res); return c.fail(RSN_ERR_DEVICE, "huffman: a transfer of the pipelined call failed: %s", P.msg.c_str()); }
-    *out = res; *out_n = got;
-    return RSN_OK;
+    return piped_call(in, n, (size_t)expect, n / 8, out, out_n,
+                      [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got, const SliceStream *st) {
+                          return huff_decode_dev(c, s, di, n, dout, cap, got, st);
+                      });
 }
 
 int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
@@ -630,6 +648,23 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
 }
 
 int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+    // From 128 MiB up, with the engine's kind of window: the pipeline (piped_call) -- sections of a quarter of the input (at most 256 MiB),
+    // each encoded as soon as its bytes are up, its tokens on their way down while the next is encoded.  The upload (19 ms per GiB) and the
+    // download (12) disappear under the encoder's 31; what does not: the first section's upload and the last one's download.  For inputs in
+    // which nothing needs an escape (so the output is at most the input): the encoder checks the input as it lands and lets the first output
+    // byte go only when it has seen the last input byte (the upload is done well before the encoder is); an input with a 5C or an FF in it,
+    // and every call under RSN_HOST_SERIAL=1, takes the serial call.
+    static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;
+    if (!serial && in && out && out_n && n >= ((size_t)128 << 20) && window > 0 && window <= 4096) {
+        const size_t sec = std::min((size_t)256 << 20, n / 4);            // (eight sections instead of four: the same 46 ms per GiB -- half a millisecond of fixed cost per section)
+        const int rc = piped_call(in, n, n + 4096, 15 * (sec + ((size_t)1 << 20)), out, out_n,
+                                  [n, window, sec](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got, const SliceStream *st) {
+                                      SliceStream mine = *st;
+                                      mine.slice_bytes = sec;
+                                      return lzss_encode_sliced(c, s, di, n, window, dout, cap, got, mine);
+                                  });
+        if (rc != 1) return rc;
+    }
     // (the encoder's own statement of need, lzss_encode_dev: ~13 bytes of scratch per position of a pass + the escaped stream)
     return host_call(in, n, out, out_n, lzss_compress_bound(n), n < ((size_t)32 << 20) ? 0 : 13 * std::min(n, (size_t)3 << 29) + 2 * n,
                      [n, window](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t cap, size_t *got) {

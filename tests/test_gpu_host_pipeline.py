@@ -74,3 +74,34 @@ def test_pipelined_decode_reports_a_truncated_payload(oracle):
             assert data.startswith(got)
         except RsnError as e:
             assert e.code == -3
+
+
+def test_pipelined_lzss_compress_is_the_serial_compress(oracle):
+    """rsn_lzss_compress from 128 MiB up: sections of a quarter of the input, encoded as they land (lzss_encode_sliced) -- the serial call's
+    bytes (RSN_HOST_SERIAL=1, a process of its own) on text, on text with '<' in it (mapped to FF where a section is loaded), on a short
+    period and on mixed sections; an input with a byte that needs an escape, early or late, is encoded whole: the same bytes again."""
+    import workloads as W
+    from raisin_amd import lz
+    n = 136 << 20
+    text = bytes(W.config_input("4", n).numpy())
+    lt = bytearray(text); lt[7::1000] = b"<" * len(lt[7::1000]); lt = bytes(lt)
+    per = (bytes(range(33, 127)) * 50)[:4096 - 17]
+    mixed = text[: 40 << 20] + (per * ((50 << 20) // len(per) + 1))[: 50 << 20] + bytes(30 << 20) + text[40 << 20: 56 << 20]
+    esc_early = b"\\" + text[1:]
+    esc_late = text[:-5] + b"\xff" + text[-4:]
+    datas = {"text": text, "lt": lt, "mixed": mixed, "esc_early": esc_early, "esc_late": esc_late}
+    got = {k: hashlib.sha256(lz.CompressAsync(v)).hexdigest() for k, v in datas.items()}
+    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
+            "datas = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "print(' '.join(k + ':' + hashlib.sha256(lz.CompressAsync(v)).hexdigest() for k, v in sorted(datas.items())))\n" % ROOT)
+    import pickle
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump(datas, f)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=900, env=dict(os.environ, RSN_HOST_SERIAL="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == " ".join(k + ":" + v for k, v in sorted(got.items()))
+    c = lz.CompressAsync(lt)
+    assert lz.Decompress(c) == lt
+    assert c[: 1 << 20] == oracle.lzss_compress(lt[: 3 << 20])[: 1 << 20]        # (and the oracle's, where it can be had in seconds)
