@@ -38,6 +38,10 @@ int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_
 // the same in SECTIONS as the input lands (a host-buffer call, rsn_api.hip): returns 1 when the input is not for it -- something in it needs
 // an escape, or the window is not one the sections take -- and the caller encodes it whole.  slice_bytes = positions per section.
 int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream &st);
+// host buffers of at most 64 KiB, byte alphabets (huff_small.hip): two launches / one launch, no copy command; 1 = not for this path.
+// *out: the result in the context's pinned staging (valid until the thread's next call), for the caller to copy
+int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
+int huff_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
 // exclusive scan of n counts on the stream (huff_encode.hip); *total (may be null) receives the sum; in and out must not overlap

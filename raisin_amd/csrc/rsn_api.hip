@@ -585,8 +585,24 @@ static int huffman_compress_single(const uint8_t *in, size_t n, uint8_t **out, s
                      });
 }
 
+// the small-input codec's result (in pinned staging) into a block of the caller's; 1 stays 1
+static int small_result(Ctx &c, int rc, const uint8_t *p, size_t got, uint8_t **out, size_t *out_n) {
+    if (rc != RSN_OK) return rc;
+    uint8_t *res = (uint8_t *)result_alloc(got);
+    if (!res) return c.fail(RSN_ERR_NOMEM, "allocating %zu result bytes failed", got);
+    memcpy(res, p, got);
+    *out = res; *out_n = got;
+    return RSN_OK;
+}
+
 int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
+    static const bool no_small = getenv("RSN_NO_SMALL") != nullptr;      // A/B switch (tests): inputs up to 64 KiB through the general path too
+    if (!no_small && in && out && out_n && n <= 65536) {
+        Ctx &c = ctx(); const uint8_t *p = nullptr; size_t got = 0;
+        const int rc = small_result(c, huff_small_compress(c, in, n, &p, &got), p, got, out, out_n);
+        if (rc != 1) return rc;
+    }
     // RSN_HUFF_SHARDS=<G> > 1: one stream out of G slices, a worker (and, with RSN_BATCH_DEVICES, a device) each -- same bytes
     static const int env_shards = env_int("RSN_HUFF_SHARDS", 0);
     if (env_shards > 1 && n >= ((size_t)1 << 16)) return rsn_huffman_compress_sharded(in, n, env_shards, out, out_n);
@@ -640,6 +656,12 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
     static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;     // A/B switch (tests): upload, decode, download, one after the other
+    static const bool no_small = getenv("RSN_NO_SMALL") != nullptr;
+    if (!no_small && n <= 65536 + 2048) {
+        const uint8_t *p = nullptr; size_t got = 0;
+        const int rc = small_result(c, huff_small_decompress(c, in, n, &p, &got), p, got, out, out_n);
+        if (rc != 1) return rc;
+    }
     if (!serial) {
         const int rc = huffman_decompress_piped(in, n, out, out_n);
         if (rc != 1) return rc;
