@@ -3,34 +3,47 @@
 // At this size a call is its fixed costs: the general path is ~10 launches, five copy commands and three host round trips for work the
 // device does in a few microseconds (r04: 89 us to compress 64 KiB, 129 us to decompress it).  Here a call is
 //   compress    host memcpy into pinned memory -> k_small_hist (a block per 2 KiB tile reads it over PCIe, keeps a device copy, writes counts
-//               straight back into pinned memory) -> sync -> the Go-exact tree, codes and header on the host (huffman.go:58-127,312-318)
+//               straight back into pinned memory) -> the Go-exact tree, codes and header on the host (huffman.go:58-127,312-318)
 //               -> k_small_emit (code table, header and tile bit positions in the KERNEL ARGUMENTS; a block per 2 KiB tile stores its words
-//               into pinned memory) -> sync -> host memcpy into the result block:          2 launches, 2 syncs, no copy command
-//   decompress  header, tree and lookup table on the host (the stream is in host memory: huffman.go:196-227,261) -> host memcpy of
-//               stream + table into pinned memory -> k_small_dec (one block: self-synchronising subsequences, a lane each, in LDS;
-//               decoded bytes into pinned memory) -> sync -> host memcpy:                   1 launch, 1 sync, no copy command
-// For byte alphabets (every symbol < 0x80) whose stream and output both fit a block's LDS; everything else -- runes, a single symbol,
+//               into pinned memory) -> host memcpy into the result block:                    2 launches, no copy command
+//   decompress  header and tree on the host (the stream is in host memory: huffman.go:196-227,261) -> host memcpy of the stream into pinned
+//               memory -> k_small_dec (up to 32 blocks; the tree in the kernel arguments, every block builds its lookup table; lanes
+//               take subsequences and settle where their codewords start -- see the kernel; decoded bytes into pinned memory)
+//               -> host memcpy:                                                              1 launch, no copy command
+// The host does not wait for the stream either: every block ends by setting a word in pinned memory that the host polls (block_done).
+// 64 KiB of the README's text, host buffer to host buffer: compress 89 -> 32 us, decompress 129 -> 52 us (r05).
+// For byte alphabets (every symbol < 0x80); everything else -- runes, a single symbol,
 // foreign headers, malformed streams and their error texts -- returns 1 and takes the general path, which words the errors.
+#include <atomic>
+#include <chrono>
+
 #include "codecs.h"
 #include "huff_host.h"
 
 namespace rsn {
 namespace {
 
-constexpr int SB = 1024;                        // lanes of the one block
 constexpr uint32_t SMALL_MAX = 65536;           // bytes of input (compress) / of output (decompress)
 constexpr uint32_t HDR_MAX = 1100;              // 128 entries of at most 5 digits + '|' + 2 bytes, + "\\\n" + pad
 constexpr uint32_t DEC_STREAM_MAX = 65536 + 2048;   // bytes of a stream the decoder takes
-constexpr int DEC_K = 11;                       // index bits of the decoder's table, at most
+constexpr int DEC_K = 9;                        // index bits of the decoder's table, at most (every block builds the table: 11 bits cost 2 us more than they save on 64 KiB)
 constexpr int DEC_ROUNDS = 64;                  // rounds of the synchronisation before the general decoder is asked instead
 
 // pinned staging of one call (Ctx::pinned): offsets
 constexpr size_t PIN_IN = 0;                                        // the caller's bytes, zero-padded to 16
-constexpr size_t PIN_TAB = PIN_IN + DEC_STREAM_MAX + 64;           // decoder: lut (2^K words), then the child table
-constexpr size_t PIN_OUT = PIN_TAB + ((size_t)4 << DEC_K) + 1024;   // what the kernel produced
+constexpr size_t PIN_OUT = PIN_IN + DEC_STREAM_MAX + 128;          // what the kernels produced
 constexpr size_t PIN_CNT = PIN_OUT + SMALL_MAX + 64;               // encoder: every tile's 128 counts (u16), then a word per tile: a byte >= 0x80 was seen; decoder: status words
-constexpr size_t PIN_BYTES = PIN_CNT + 32 * 128 * 2 + 32 * 4 + 256;
-static_assert(PIN_TAB % 16 == 0 && PIN_OUT % 16 == 0 && PIN_CNT % 16 == 0, "16-byte stores");
+constexpr size_t PIN_BYTES = PIN_CNT + 32 * 128 * 2 + 2 * 32 * 4 + 256;
+static_assert(PIN_OUT % 16 == 0 && PIN_CNT % 16 == 0, "16-byte stores");
+
+// A block's last act: its stores to host memory made visible, then ONE word the host is polling (the host does not wait for the stream: a
+// hipStreamSynchronize is 5-10 us of wake-up, the kernel is as long).
+constexpr uint32_t FLAG_PENDING = 0xFFFFFFFFu;
+__device__ __forceinline__ void block_done(uint32_t *flag, uint32_t value) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---------------------------------------------------------------- compress, kernel 1: counts (huffman.go:306-311) + a device copy
 // One block per tile of 2 KiB, a 16-byte load per lane straight from the caller's bytes in pinned host memory (one PCIe round trip for the
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(128) void k_small_hist(const uint4 *__restrict__ hi
     }
     __syncthreads();
     tile_hist[blockIdx.x * 128 + tid] = (uint16_t)(s_h[0][tid] + s_h[1][tid]);
-    if (tid == 0) tile_high[blockIdx.x] = s_high;
+    block_done(&tile_high[blockIdx.x], s_high);
 }
 
 // ---------------------------------------------------------------- compress, kernel 2: the stream (huffman.go:229-256,174-191)
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(128) void k_small_hist(const uint4 *__restrict__ hi
 // the word a tile boundary falls into: it belongs to the LATER tile, which works out the earlier one's last few bits itself (from the up to
 // 31 symbols before its first) -- no atomics on memory, no zeroed output, nothing between the blocks.
 struct SmallEmitArgs {
-    const uint8_t *d_copy; uint32_t *hout;
+    const uint8_t *d_copy; uint32_t *hout; uint32_t *done;   // done[tile]: FLAG_PENDING until the tile's words are out
     uint32_t n, H, total;                // input bytes; header bytes incl. "\\\n" and the pad byte; bytes of the stream
     uint32_t P[ST_MAX + 1];              // first code bit of every tile, counted from the stream's first byte (P[0] = 8 H + pad)
     uint32_t tab[128];                   // len << 24 | code (a 64 KiB input cannot produce a code beyond 22 bits)
@@ -155,115 +168,364 @@ __global__ __launch_bounds__(256) void k_small_emit(SmallEmitArgs a) {
     // the words this tile owns: up to, not including, the one the next tile starts in; the last tile: to the stream's end
     const uint32_t own = b + 1 < n_tiles ? (Pn >> 5) - W0 : (a.total + 3) / 4 - W0;
     for (uint32_t i = tid; i < own; i += 256) a.hout[W0 + i] = s_img[i];
+    block_done(&a.done[b], 0);
 }
 
-#define TSTAMP(arr, k) do { if (threadIdx.x == 0) (arr)[k] = (uint32_t)__builtin_readcyclecounter(); } while (0)
-// ---------------------------------------------------------------- decompress: one block (huffman.go:131-153,258-297)
+// ---------------------------------------------------------------- decompress (huffman.go:131-153,258-297)
+// The payload is one bit string without an index: a lane that takes the subsequence [lo, lo + S) does not know where its first codeword
+// starts.  It starts at lo and trusts the code to synchronise; the lane before tells it where it really ended, the lane redoes its
+// subsequence from there, and so on until nothing changes.  On most data two rounds settle it.  On PERIODIC data (the README's samiam.txt
+// repeated to 64 KiB is that) a wrong start can stay a wrong parse for kilobytes -- a second phase the code is just as happy in -- and
+// "redo from the predecessor's exit" then walks the stretch one lane a round (r05, first version: one block, 52 rounds, 48 of its 94 us).
+// So a lane keeps a small MAP instead of one answer: for every start a predecessor might hand it (at most four), where it ends and how many
+// symbols it takes.  A round only adds the starts not seen before -- with two phases every lane has both after two rounds, whoever is
+// right -- and when no lane learns a new start the true path is a composition of the maps along the lanes (a wavefront scan).
+// One CU decodes 64 KiB in 12 us a pass however it is arranged, so the lanes are spread over up to 16 BLOCKS, and the blocks must not wait
+// for each other round by round: a block's FIRST lane answers all 32 starts its subsequence could be entered at (32 lanes, one each), the
+// block composes its lanes into a map "entered at c -> left at c', n symbols", publishes it, and only then looks at the blocks before it
+// (their maps, composed, give its true entry and its first output byte).  One wait per call, behind work that every block does alone.
+constexpr int DL = 256;                          // lanes per block that take a subsequence
+constexpr int DT = DL + 64;                      // ... and a fifth wavefront: the 32 entries of the block's first lane, beside the others' first guesses
+constexpr uint32_t DEC_BLOCKS = 32;
+constexpr uint32_t DEC_S_MAX = 96;               // bits per lane at most: (64 KiB + 2 KiB) * 8 / 8192 lanes, in whole words (at least 64: an exit lies within 32 bits of the next lane's first)
+constexpr uint32_t DEC_PAY_WORDS = DL * DEC_S_MAX / 32 + 8;
+constexpr uint32_t DEC_OUT_CAP = 32768;          // bytes one block may produce (text: 256 lanes * 96 bits / 3 bits = 8 KiB)
+constexpr uint32_t OFF_BAD = 0xFF;               // an exit that is none: the path ran off the payload (or the entry cannot occur)
+
 struct SmallDecArgs {
-    const uint32_t *lut;      // 2^K entries: len << 8 | byte, or 0x80000000 | internal node reached after K bits
-    const uint16_t *child;    // [2 * node + bit]: 0x8000 | byte for a leaf, else the internal node
-    const uint32_t *pay;      // the stream from a 4-byte boundary at or before its first payload byte (pinned; zero behind its end)
-    uint32_t pay_words;       // words to stage
+    const uint32_t *pay;      // the stream from a 4-byte boundary at or before its first payload byte (pinned host memory; zero behind its end)
+    uint32_t pay_words;
     uint32_t p0, end;         // first code bit / the bit behind the last, counted from `pay`
-    uint32_t K, n_child;
-    uint4 *hout; uint32_t *status;    // status[0]: 0 = done, 1 = not for this kernel; status[1]: decoded bytes
+    uint32_t K, root, n_child;  // index bits of the lookup table; the tree's root (an internal node)
+    uint32_t S, T;            // bits per lane; lanes that have a subsequence
+    uint32_t seq;             // this call's number: what a block's flag holds once its map is out
+    uint8_t *hout; uint32_t *status;      // status[b]: FLAG_PENDING, then 0 = block b done, 1 = not for this kernel; status[DEC_BLOCKS]: decoded bytes
+    uint32_t *g_maps, *g_flags;           // device memory: [block][32] (exit << 24 | symbols), [block]
+    uint16_t child[256];      // [2 * node + bit]: 0x8000 | byte for a leaf, else the internal node
 };
 
-struct DecLds {
-    const uint32_t *pay, *lut; const uint16_t *child; uint32_t K, end;
-    __device__ __forceinline__ uint32_t window(uint32_t pos) const {
-        const uint32_t w = pos >> 5, o = pos & 31;
-        const unsigned long long two = ((unsigned long long)pay[w] << 32) | pay[w + 1];
-        return (uint32_t)((two << o) >> 32);
+// a reader of the big-endian words in LDS: the next bits left-aligned in a register, a word fetched for every 32 consumed
+struct BitReader {
+    const uint32_t *pay; unsigned long long buf; uint32_t pos, nextw; int avail;
+    __device__ __forceinline__ void seek(uint32_t p) {
+        const uint32_t w = p >> 5, o = p & 31;
+        buf = (((unsigned long long)pay[w] << 32) | pay[w + 1]) << o;
+        avail = 64 - (int)o; nextw = w + 2; pos = p;
     }
-    // the codeword at `pos`: its byte; pos moves behind it (past `end`: the caller's to notice)
-    __device__ __forceinline__ uint32_t one(uint32_t &pos) const {
-        const uint32_t win = window(pos);
-        const uint32_t e = lut[win >> (32 - K)];
-        if (!(e >> 31)) { pos += e >> 8; return e & 0xFF; }
-        uint32_t node = e & 0xFFFF, q = pos + K;
-        for (;;) {
-            const uint32_t bit = (pay[q >> 5] >> (31 - (q & 31))) & 1;
-            q++;
-            node = child[2 * node + bit];
-            if (node & 0x8000) break;
-            if (q > end + 64) break;                                  // (garbage behind the end: stop)
+    __device__ __forceinline__ void skip(uint32_t l) {
+        buf <<= l; avail -= (int)l; pos += l;
+        if (avail < 32) { buf |= (unsigned long long)pay[nextw++] << (32 - avail); avail += 32; }
+    }
+};
+struct DecTab { const uint32_t *lut; const uint16_t *child; uint32_t K, end; };
+// the codeword at the reader's position: its byte; the reader moves behind it (past `end`: the caller's to notice)
+__device__ __forceinline__ uint32_t dec_one(BitReader &r, const DecTab &t) {
+    const uint32_t e = t.lut[(uint32_t)(r.buf >> (64 - t.K))];
+    if (!(e >> 31)) { r.skip(e >> 8); return e & 0xFF; }
+    uint32_t node = e & 0xFFFF;
+    r.skip(t.K);
+    for (;;) {
+        const uint32_t bit = (uint32_t)(r.buf >> 63);
+        r.skip(1);
+        node = t.child[2 * node + bit];
+        if ((node & 0x8000) || r.pos > t.end + 64) break;             // (garbage behind the end: stop)
+    }
+    return node & 0xFF;
+}
+
+// The kernel is launched for a few microseconds of work on CUs whose instruction caches are cold: its time is its CODE SIZE (r05: the
+// first multi-block version, every loop inlined wherever it was used -- 36 KB of instructions, 56 us; the arithmetic is two).  So the two
+// loops that walk codewords exist ONCE, as functions.
+// the codewords that start in [from, hi): exit offset (from hi; OFF_BAD: the path ran off the payload) << 24 | their number
+__device__ __noinline__ uint32_t run_path(const uint32_t *pay, const uint32_t *lut, const uint16_t *child, uint32_t K, uint32_t end, uint32_t from, uint32_t hi) {
+    const DecTab tab{lut, child, K, end};
+    BitReader r; r.pay = pay; r.seek(from);
+    uint32_t c = 0;
+    while (r.pos < hi) { (void)dec_one(r, tab); c++; if (r.pos > end) break; }
+    return (r.pos > end ? OFF_BAD : r.pos - hi) << 24 | c;
+}
+// `count` codewords from `from`, their bytes to out[0 ..)
+__device__ __noinline__ void emit_path(const uint32_t *pay, const uint32_t *lut, const uint16_t *child, uint32_t K, uint32_t end, uint32_t from, uint32_t count, uint8_t *out) {
+    const DecTab tab{lut, child, K, end};
+    BitReader r; r.pay = pay; r.seek(from);
+    for (uint32_t i = 0; i < count; i++) out[i] = (uint8_t)dec_one(r, tab);
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t packed, uint32_t j) { return (packed >> (8 * j)) & 0xFF; }
+// "entry j of the first lane -> entry to[j] of the lane behind the last, c[j] symbols on the way"; to[j] == 7: no such path
+struct PathMap { uint32_t to, c0, c1, c2, c3; };
+__device__ __forceinline__ uint32_t pm_to(const PathMap &m, uint32_t j) { return j < 4 ? (m.to >> (3 * j)) & 7 : 7u; }
+__device__ __forceinline__ uint32_t pm_c(const PathMap &m, uint32_t j) { return j == 0 ? m.c0 : j == 1 ? m.c1 : j == 2 ? m.c2 : m.c3; }
+__device__ __forceinline__ PathMap pm_then(const PathMap &a, const PathMap &b) {         // a's lanes first, then b's
+    PathMap r;
+    uint32_t t[4], c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const uint32_t mid = pm_to(a, j); t[j] = pm_to(b, mid); c[j] = pm_c(a, j) + (mid < 4 ? pm_c(b, mid) : 0u); }
+    r.to = t[0] | t[1] << 3 | t[2] << 6 | t[3] << 9; r.c0 = c[0]; r.c1 = c[1]; r.c2 = c[2]; r.c3 = c[3];
+    return r;
+}
+constexpr uint32_t PM_ID = 0 | 1 << 3 | 2 << 6 | 3 << 9;
+__device__ __forceinline__ PathMap pm_shfl_up(const PathMap &m, int d) {
+    PathMap r; r.to = __shfl_up(m.to, d, 64); r.c0 = __shfl_up(m.c0, d, 64); r.c1 = __shfl_up(m.c1, d, 64); r.c2 = __shfl_up(m.c2, d, 64); r.c3 = __shfl_up(m.c3, d, 64);
+    return r;
+}
+
+__global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
+    __shared__ uint32_t s_pay[DEC_PAY_WORDS];                 // big-endian words of this block's part of the stream
+    __shared__ uint32_t s_lut[1u << DEC_K];                   // len << 8 | byte, or 0x80000000 | internal node reached after K bits
+    __shared__ uint16_t s_child[256];
+    __shared__ uint32_t s_st[DL], s_ex[DL], s_n[DL];          // per lane: its starts (offsets from its subsequence's first bit, a byte each), the exits that belong to them (offsets from the next subsequence's first bit), their number
+    __shared__ uint32_t s_exmask;                             // ... the exits that occur among them, a bit each
+    __shared__ uint32_t s_ex32[32], s_cn32[32];               // the block's first lane: exit and symbols for every start in its first 32 bits
+    __shared__ uint32_t s_wto[5], s_wc[5][4];                 // the wavefronts' maps
+    __shared__ uint32_t s_blk[4][2];                          // entry j of lane 1 -> (exit of the block's last lane, symbols of lanes 1..)
+    __shared__ uint32_t s_all[DEC_BLOCKS * 32];               // the maps of the blocks before this one
+    __shared__ uint32_t s_true[3];                            // this block's true entry (a start of its first lane), its first output byte, a failure
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_CAP + 32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, n_blk = gridDim.x;
+    const uint32_t S = a.S;
+    const uint32_t blk_lo = a.p0 + b * DL * S;                                   // this block's first bit
+    const uint32_t wlo = blk_lo >> 5;                                           // ... the word it is in: bit positions below are counted from it
+    const uint32_t n_words = DL * S / 32 + 6;
+    {   // every load of the staging in flight at once (the bytes are in host memory, a round trip is microseconds); the table meanwhile
+        constexpr int PER = (DEC_PAY_WORDS + DT - 1) / DT;
+        uint32_t v[PER];
+        const uint32_t ch = tid < a.n_child ? a.child[tid] : 0u;               // (asked for first: the table is built while the stream's words are on their way)
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const uint32_t i = tid + k * DT; v[k] = (i < n_words && wlo + i < a.pay_words) ? a.pay[wlo + i] : 0u; }
+        if (tid < a.n_child) s_child[tid] = (uint16_t)ch;
+        __syncthreads();
+        // window v of K bits: down the tree from the root, two windows a lane at a time (the steps depend on each other, the windows do not)
+        constexpr int G = 2;
+        for (uint32_t v0 = tid * G; v0 < (1u << a.K); v0 += DT * G) {
+            uint32_t node[G], ent[G];
+#pragma unroll
+            for (int q = 0; q < G; q++) { node[q] = a.root; ent[q] = 0; }
+            for (uint32_t d = 0; d < a.K; d++) {
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    if (ent[q]) continue;
+                    const uint32_t bit = ((v0 + q) >> (a.K - 1 - d)) & 1;
+                    node[q] = s_child[2 * node[q] + bit];
+                    if (node[q] & 0x8000) ent[q] = ((d + 1) << 8) | (node[q] & 0xFF);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < G; q++) if (v0 + q < (1u << a.K)) s_lut[v0 + q] = ent[q] ? ent[q] : (0x80000000u | node[q]);
         }
-        pos = q;
-        return node & 0xFF;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const uint32_t i = tid + k * DT; if (i < n_words + 2) s_pay[i] = i < n_words ? __builtin_bswap32(v[k]) : 0u; }
     }
-};
-
-__global__ __launch_bounds__(SB) void k_small_dec(SmallDecArgs a) {
-    extern __shared__ uint32_t s_mem[];
-    uint32_t *s_pay = s_mem;                                  // big-endian words of the stream (+ 4 of zeros)
-    uint32_t *s_lut = s_pay + (DEC_STREAM_MAX / 4 + 4);
-    uint32_t *s_exit = s_lut + (1u << DEC_K);
-    uint32_t *s_wave = s_exit + SB;
-    uint16_t *s_child = reinterpret_cast<uint16_t *>(s_wave + 20);
-    uint8_t *s_out = reinterpret_cast<uint8_t *>(s_child + 512);
-    const uint32_t tid = threadIdx.x;
-    TSTAMP(a.status + 4, 0);
-    for (uint32_t i = tid; i < a.pay_words + 4; i += SB) s_pay[i] = i < a.pay_words ? __builtin_bswap32(a.pay[i]) : 0u;
-    for (uint32_t i = tid; i < (1u << a.K); i += SB) s_lut[i] = a.lut[i];
-    for (uint32_t i = tid; i < a.n_child; i += SB) s_child[i] = a.child[i];
+    if (tid < 32) { s_ex32[tid] = OFF_BAD; s_cn32[tid] = 0; }
+    if (tid == 0) s_exmask = 0;
     __syncthreads();
-    TSTAMP(a.status + 4, 1);
-    const DecLds d{s_pay, s_lut, s_child, a.K, a.end};
-    // subsequences of S bits, a lane each
-    const uint32_t span = a.end - a.p0;
-    const uint32_t S = max(64u, ((span + SB - 1) / SB + 31) / 32 * 32);
-    const uint32_t my_lo = a.p0 + tid * S;                                     // (may lie behind the end: such a lane takes nothing)
-    const uint32_t my_hi = min(a.end, my_lo + S);
-    constexpr uint32_t BAD = 0xFFFFFFFFu;
-    uint32_t start = my_lo, cnt = 0, exit_ = 0;
-    auto run = [&] {                                                           // codewords that START in [start, my_hi)
-        cnt = 0;
-        uint32_t pos = start;
-        if (pos == BAD) { exit_ = BAD; return; }
-        while (pos < my_hi) { (void)d.one(pos); cnt++; if (pos > a.end) { pos = BAD; break; } }
-        exit_ = pos;
+    const uint32_t base_bit = wlo << 5;
+    const uint32_t end = a.end - base_bit;                                      // (all positions from here on: bits from s_pay[0])
+    const uint32_t g = b * DL + tid;                                            // the lane's subsequence
+    const uint32_t L = min((uint32_t)DL, a.T - b * DL);                         // lanes of this block that have one
+    const bool real = tid < L;                                                  // (the fifth wavefront's lanes: none)
+    const uint32_t my_lo = blk_lo - base_bit + tid * S;
+    const uint32_t my_hi = min(end, my_lo + S);                                 // (the next lane's first bit; the stream's last lane: the end)
+    auto run_in = [&](uint32_t lo, uint32_t hi, uint32_t off, uint32_t &exit_off, uint32_t &count) {   // the codewords that start in [lo + off, hi)
+        const uint32_t r = run_path(s_pay, s_lut, s_child, a.K, end, lo + off, hi);
+        exit_off = r >> 24; count = r & 0xFFFFFFu;
     };
-    run();                                                                     // (a lane behind the end takes nothing and hands its start on)
-    s_exit[tid] = exit_;
-    TSTAMP(a.status + 4, 2);
+    // ---- the block's first lane, entered at every bit a codeword could start at (block 0: at the stream's first code bit, nowhere else)
+    if (tid >= DL && tid < DL + 32 && (b == 0 ? tid == DL : true)) {
+        const uint32_t hi0 = min(end, blk_lo - base_bit + S);
+        uint32_t e, c;
+        run_in(blk_lo - base_bit, hi0, tid - DL, e, c);
+        s_ex32[tid - DL] = e; s_cn32[tid - DL] = c;
+        if (e < 32) atomicOr(&s_exmask, 1u << e);
+    }
+    uint32_t st[4] = {0, 0, 0, 0}, ex[4] = {OFF_BAD, OFF_BAD, OFF_BAD, OFF_BAD}, cn[4] = {0, 0, 0, 0}, n_ent = 0;
+    auto add = [&](uint32_t off) {                                              // (n_ent < 4)
+        uint32_t e, c;
+        run_in(my_lo, my_hi, off, e, c);
+#pragma unroll
+        for (int j = 0; j < 4; j++) if ((uint32_t)j == n_ent) { st[j] = off; ex[j] = e; cn[j] = c; }
+        n_ent++;
+    };
+    auto publish = [&] {
+        s_st[tid] = st[0] | st[1] << 8 | st[2] << 16 | st[3] << 24;
+        s_ex[tid] = ex[0] | ex[1] << 8 | ex[2] << 16 | ex[3] << 24;
+        s_n[tid] = n_ent;
+    };
+    const bool chained = real && tid >= 1;                                      // lanes 1.. learn their starts from the lane before
+    if (chained) add(0);                                                        // a first guess: the subsequence's first bit
+    if (tid < DL) publish();
     bool lost = false;
-    int rounds = 0;
     for (int round = 0;; round++) {
         __syncthreads();
-        const uint32_t want = tid == 0 ? a.p0 : s_exit[tid - 1];       // where the lane before stopped is where this one starts
-        const bool redo = want != start;
+        uint32_t fresh[4], n_fresh = 0;
+        bool over = false;
+        auto offer = [&](uint32_t off) {
+            if (off == OFF_BAD) return;
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) seen |= ((uint32_t)k < n_ent && st[k] == off) || ((uint32_t)k < n_fresh && fresh[k] == off);
+            if (seen) return;
+            if (n_ent + n_fresh >= 4) { over = true; return; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((uint32_t)k == n_fresh) fresh[k] = off;
+            n_fresh++;
+        };
+        if (chained && tid == 1) { for (uint32_t mk = s_exmask; mk; mk &= mk - 1) offer((uint32_t)__builtin_ctz(mk)); }
+        else if (chained) {
+            const uint32_t pe = s_ex[tid - 1], pn = s_n[tid - 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) if ((uint32_t)j < pn) offer(byte_of(pe, j));
+        }
         __syncthreads();
-        if (redo) { start = want; run(); s_exit[tid] = exit_; }
-        rounds++;
-        if (!__syncthreads_or(redo ? 1 : 0)) break;
+#pragma unroll 1
+        for (uint32_t k = 0; k < n_fresh; k++) add(k == 0 ? fresh[0] : k == 1 ? fresh[1] : k == 2 ? fresh[2] : fresh[3]);
+        if (n_fresh) publish();                                                  // (only lanes 1 .. L - 1 ever have any)
+        const int flags = __syncthreads_or((n_fresh ? 1 : 0) | (over ? 2 : 0));
+        if (flags & 2) { lost = true; break; }                                  // more than four phases: the general decoder
+        if (!flags) break;
         if (round >= DEC_ROUNDS) { lost = true; break; }
     }
-    // (every lane agrees on `lost`: the loop's exits are block-uniform)
-    TSTAMP(a.status + 4, 3);
-    if (tid == 0) a.status[12] = rounds;
-    const uint32_t last = s_exit[SB - 1];
-    const uint32_t at = block_excl_scan<16>(cnt, s_wave);
-    const uint32_t total = s_wave[16];
-    if (lost || last != a.end || total > SMALL_MAX || total == 0) {           // ends inside a codeword, never synchronised, too large: the general decoder
-        if (tid == 0) { a.status[0] = 1; a.status[1] = 0; }
-        return;
+    // ---- the lanes' maps composed: lane t's entry j leads to the entry of lane t + 1 whose start is j's exit
+    PathMap m; m.to = PM_ID; m.c0 = m.c1 = m.c2 = m.c3 = 0;                     // (lane 0 and lanes without a subsequence: nothing)
+    if (chained) {
+        m.c0 = cn[0]; m.c1 = cn[1]; m.c2 = cn[2]; m.c3 = cn[3];
+        if (tid + 1 < L) {
+            const uint32_t ns = s_st[tid + 1], nn = s_n[tid + 1];
+            m.to = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t to = 7;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if ((uint32_t)j < n_ent && (uint32_t)k < nn && ex[j] != OFF_BAD && byte_of(ns, k) == ex[j]) to = k;
+                m.to |= to << (3 * j);
+            }
+        } else {                                                                // the block's last lane: its entries stay as they are (their exits are read below)
+            m.to = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) m.to |= ((uint32_t)j < n_ent ? (uint32_t)j : 7u) << (3 * j);
+        }
     }
-    TSTAMP(a.status + 4, 4);
-    {
-        uint32_t pos = start, o = at;
-        if (pos != BAD) while (pos < my_hi) s_out[o++] = (uint8_t)d.one(pos);
-    }
-    TSTAMP(a.status + 4, 5);
+    PathMap inc = m;                                                            // this wavefront's lanes up to and including this one
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) { const PathMap o = pm_shfl_up(inc, d); if (lane >= (uint32_t)d) inc = pm_then(o, inc); }
+    if (lane == 63) { s_wto[wave] = inc.to; s_wc[wave][0] = inc.c0; s_wc[wave][1] = inc.c1; s_wc[wave][2] = inc.c2; s_wc[wave][3] = inc.c3; }
     __syncthreads();
-    TSTAMP(a.status + 4, 6);
-    const uint4 *o4 = reinterpret_cast<const uint4 *>(s_out);
-    for (uint32_t i = tid; i < (total + 15) / 16; i += SB) a.hout[i] = o4[i];
-    TSTAMP(a.status + 4, 7);
-    if (tid == 0) { a.status[0] = 0; a.status[1] = total; }
+    if (tid == 0) {
+        PathMap acc; acc.to = PM_ID; acc.c0 = acc.c1 = acc.c2 = acc.c3 = 0;
+#pragma unroll 1
+        for (int w = 0; w < DL / 64; w++) {
+            PathMap t; t.to = s_wto[w]; t.c0 = s_wc[w][0]; t.c1 = s_wc[w][1]; t.c2 = s_wc[w][2]; t.c3 = s_wc[w][3];
+            s_wto[w] = acc.to; s_wc[w][0] = acc.c0; s_wc[w][1] = acc.c1; s_wc[w][2] = acc.c2; s_wc[w][3] = acc.c3;
+            acc = pm_then(acc, t);
+        }
+    }
+    __syncthreads();
+    PathMap before; before.to = s_wto[wave]; before.c0 = s_wc[wave][0]; before.c1 = s_wc[wave][1]; before.c2 = s_wc[wave][2]; before.c3 = s_wc[wave][3];
+    {
+        const PathMap prev = pm_shfl_up(inc, 1);                                // (the lanes before this one, within the wavefront)
+        if (lane) before = pm_then(before, prev);                               // entry j of lane 1 -> (entry of THIS lane, symbols of lanes 1 .. this - 1)
+    }
+    if (real && tid + 1 == L && L > 1) {                                        // the block's last lane: where every entry of lane 1 leaves the block
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t idx = pm_to(before, j);
+            uint32_t e = OFF_BAD, c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((uint32_t)k == idx && idx < n_ent) { e = ex[k]; c = pm_c(before, j) + cn[k]; }
+            s_blk[j][0] = e; s_blk[j][1] = c;
+        }
+    }
+    __syncthreads();
+    // ---- the block's map out, the earlier blocks' maps in
+    auto lane1_index = [&](uint32_t off) -> uint32_t {                          // which entry of lane 1 starts at `off`
+        const uint32_t s1 = s_st[1], n1 = s_n[1];
+        uint32_t j = 7;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((uint32_t)k < n1 && byte_of(s1, k) == off) j = k;
+        return j;
+    };
+    if (tid < 32) {
+        uint32_t e = s_ex32[tid], c = s_cn32[tid];
+        if (L > 1 && e != OFF_BAD) { const uint32_t j = lane1_index(e); if (j < 4) { c += s_blk[j][1]; e = s_blk[j][0]; } else e = OFF_BAD; }
+        if (lost) e = OFF_BAD;
+        a.g_maps[b * 32 + tid] = e << 24 | (c & 0xFFFFFFu);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(&a.g_flags[b], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t i = 0; i < b; i++) while (__hip_atomic_load(&a.g_flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.seq) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < b * 32; i += DT) s_all[i] = __hip_atomic_load(&a.g_maps[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0, base = 0, fail = lost ? 1u : 0u;                        // (block 0 is entered at its first bit)
+        for (uint32_t i = 0; i < b && !fail; i++) {
+            const uint32_t e = s_all[i * 32 + c];
+            if ((e >> 24) == OFF_BAD || (e >> 24) >= 32) { fail = 1; break; }
+            base += e & 0xFFFFFFu; c = e >> 24;
+        }
+        s_true[0] = c; s_true[1] = base; s_true[2] = fail;
+    }
+    __syncthreads();
+    const uint32_t c_in = s_true[0], out_base = s_true[1];
+    bool fail = s_true[2] != 0;
+    // ---- the true path through this block
+    uint32_t my_start = 0, my_cnt = 0, my_at = 0, my_exit = OFF_BAD;            // (my_at: symbols of this block before this lane's)
+    if (!fail) {
+        const uint32_t e0 = s_ex32[c_in];
+        if (tid == 0) { my_start = c_in; my_cnt = s_cn32[c_in]; my_exit = e0; }
+        else if (chained) {
+            const uint32_t j1 = e0 == OFF_BAD ? 7u : lane1_index(e0);
+            const uint32_t idx = pm_to(before, j1);
+            my_at = s_cn32[c_in] + (j1 < 4 ? pm_c(before, j1) : 0u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((uint32_t)k == idx && idx < n_ent) { my_start = st[k]; my_cnt = cn[k]; my_exit = ex[k]; }
+        }
+    }
+    const bool is_last_lane = real && g + 1 == a.T;
+    const bool broken = !fail && real && (my_exit == OFF_BAD || (is_last_lane && my_exit != 0));   // off the payload, or the stream ends inside a codeword
+    const uint32_t blk_cnt_hint = (real && tid + 1 == L) ? my_at + my_cnt : 0u;
+    const int bad = __syncthreads_or((broken || fail) ? 1 : 0);
+    if (real && tid + 1 == L) s_true[0] = blk_cnt_hint;
+    __syncthreads();
+    const uint32_t blk_cnt = s_true[0];
+    if (bad || blk_cnt + 16 > DEC_OUT_CAP || out_base + blk_cnt > SMALL_MAX) { block_done(&a.status[b], 1); return; }
+    const uint32_t shift = out_base & 15;                                       // LDS byte i + shift <-> output byte out_base + i: 16-byte units line up
+    if (real) emit_path(s_pay, s_lut, s_child, a.K, end, my_lo + my_start, my_cnt, s_out + my_at + shift);
+    __syncthreads();
+    {   // whole 16-byte units as they are; the first and the last are shared with the neighbours: their bytes one by one
+        const uint32_t lo = shift, hi = shift + blk_cnt;                        // LDS byte range
+        uint8_t *dst = a.hout + (out_base - shift);
+        for (uint32_t u = tid; u * 16 < hi; u += DT) {
+            const uint32_t u0 = u * 16, u1 = u0 + 16;
+            if (u0 >= lo && u1 <= hi) *reinterpret_cast<uint4 *>(dst + u0) = *reinterpret_cast<const uint4 *>(s_out + u0);
+            else for (uint32_t x = max(u0, lo); x < min(u1, hi); x++) dst[x] = s_out[x];
+        }
+    }
+    if (tid == 0 && b + 1 == n_blk) a.status[DEC_BLOCKS] = out_base + blk_cnt;
+    block_done(&a.status[b], 0);
 }
-constexpr size_t DEC_LDS = (size_t)(DEC_STREAM_MAX / 4 + 4) * 4 + ((size_t)4 << DEC_K) + SB * 4 + 20 * 4 + 512 * 2 + SMALL_MAX + 16;
 
+}  // namespace
+
+namespace {
+// until none of f[0 .. n) is FLAG_PENDING; a kernel that has not answered within 5 ms is waited for the ordinary way
+int wait_flags(Ctx &c, hipStream_t s, const uint32_t *f, uint32_t n) {
+    const volatile uint32_t *vf = f;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; spins++) {
+        uint32_t pending = 0;
+        for (uint32_t i = 0; i < n; i++) pending |= vf[i] == FLAG_PENDING;
+        if (!pending) { std::atomic_thread_fence(std::memory_order_acquire); return RSN_OK; }
+        if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+            RSN_HIP(hipStreamSynchronize(s));
+            for (uint32_t i = 0; i < n; i++) if (vf[i] == FLAG_PENDING) return c.fail(RSN_ERR_DEVICE, "huffman: a small-input kernel finished without its answer");
+            return RSN_OK;
+        }
+        __builtin_ia32_pause();
+    }
+}
 }  // namespace
 
 // 1: not an input for this path (the caller takes the general one)
@@ -279,8 +541,10 @@ int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out
     const uint32_t n_tiles = (uint32_t)ceil_div(n, ST);
     uint16_t *th = (uint16_t *)(pin + PIN_CNT);
     uint32_t *hi = (uint32_t *)(th + ST_MAX * 128);
+    uint32_t *done = hi + ST_MAX;
+    for (uint32_t t = 0; t < n_tiles; t++) { hi[t] = FLAG_PENDING; done[t] = FLAG_PENDING; }
     RSN_LAUNCH("huff_small_hist", k_small_hist, dim3(n_tiles), dim3(128), 0, s, (const uint4 *)(pin + PIN_IN), (uint32_t)n, (uint4 *)dp, th, hi);
-    RSN_HIP(hipStreamSynchronize(s));
+    rc = wait_flags(c, s, hi, n_tiles); if (rc) return rc;
     uint32_t cnt[128] = {0};
     for (uint32_t t = 0; t < n_tiles; t++) {
         if (hi[t]) return 1;                                                    // a byte >= 0x80: runes (huffman.go:309)
@@ -301,7 +565,7 @@ int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out
     const size_t total = H + (size_t)((codes.total_bits + pad) / 8);
     if (H > HDR_MAX || total > SMALL_MAX) return 1;
     SmallEmitArgs a{};
-    a.d_copy = (const uint8_t *)dp; a.hout = (uint32_t *)(pin + PIN_OUT);
+    a.d_copy = (const uint8_t *)dp; a.hout = (uint32_t *)(pin + PIN_OUT); a.done = done;
     a.n = (uint32_t)n; a.H = (uint32_t)H; a.total = (uint32_t)total;
     uint32_t len_of[128] = {0};
     for (uint32_t i = 0; i < tree.n_leaves; i++) { a.tab[tree.rune[i]] = ((uint32_t)codes.len[i] << 24) | (uint32_t)codes.code[i]; len_of[tree.rune[i]] = codes.len[i]; }
@@ -313,7 +577,7 @@ int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out
     }
     memcpy(a.hdr, hdr.data(), H);
     RSN_LAUNCH("huff_small_emit", k_small_emit, dim3(n_tiles), dim3(256), 0, s, a);
-    RSN_HIP(hipStreamSynchronize(s));
+    rc = wait_flags(c, s, done, n_tiles); if (rc) return rc;
     *out = pin + PIN_OUT; *out_n = total;
     return RSN_OK;
 }
@@ -338,55 +602,44 @@ int huff_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **o
     if (codes.max_len > 32 || codes.max_len == 0) return 1;
     int rc = ctx_init(c); if (rc) return rc;
     hipStream_t s = c.own_stream;
-    static thread_local bool lds_set = false;
-    if (!lds_set) { RSN_HIP(hipFuncSetAttribute((const void *)k_small_dec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS)); lds_set = true; }
     void *pp; rc = pinned_buf(c, PIN_BYTES, &pp); if (rc) return rc;
     uint8_t *pin = (uint8_t *)pp;
-    // ---- tables, written where the kernel reads them
+    void *dp; rc = dev_buf(c, 38, (DEC_BLOCKS * 32 + DEC_BLOCKS) * 4, &dp); if (rc) return rc;      // the blocks' maps and flags
+    static thread_local uint32_t seq = 0;                                        // a flag holds the number of the call that set it:
+    static thread_local void *seq_of = nullptr;                                  // nothing to clear between calls on the same buffer
+    if (seq_of != dp || ++seq == 0) { seq = 1; seq_of = dp; RSN_HIP(hipMemsetAsync(dp, 0, (DEC_BLOCKS * 32 + DEC_BLOCKS) * 4, s)); }
+    // ---- the tree as the kernel wants it (every block fills its lookup table from it)
     const int K = (int)std::min<unsigned>(codes.max_len, DEC_K);
-    uint32_t *lut = (uint32_t *)(pin + PIN_TAB);
-    uint16_t *child = (uint16_t *)(lut + ((size_t)1 << K));
+    SmallDecArgs a{};
     const uint32_t A = tree.n_leaves;
     const size_t n_int = tree.freq.size() - A;
     for (size_t i = 0; i < n_int; i++) {
         const int32_t kids[2] = {tree.left[A + i], tree.right[A + i]};
-        for (int b = 0; b < 2; b++) child[2 * i + b] = tree.is_leaf(kids[b]) ? (uint16_t)(0x8000u | tree.rune[kids[b]]) : (uint16_t)(kids[b] - (int32_t)A);
+        for (int b = 0; b < 2; b++) a.child[2 * i + b] = tree.is_leaf(kids[b]) ? (uint16_t)(0x8000u | tree.rune[kids[b]]) : (uint16_t)(kids[b] - (int32_t)A);
     }
-    {
-        struct It { int32_t node; uint32_t prefix; int depth; };
-        It st[300]; int top = 0;
-        st[top++] = {tree.root, 0, 0};
-        while (top) {
-            const It it = st[--top];
-            if (tree.is_leaf(it.node)) {
-                const uint32_t ent = ((uint32_t)it.depth << 8) | tree.rune[it.node];
-                const uint32_t lo = it.prefix << (K - it.depth);
-                for (uint32_t x = 0; x < (1u << (K - it.depth)); x++) lut[lo + x] = ent;
-            } else if (it.depth == K) {
-                lut[it.prefix] = 0x80000000u | (uint32_t)(it.node - (int32_t)A);
-            } else {
-                st[top++] = {tree.right[it.node], (it.prefix << 1) | 1, it.depth + 1};
-                st[top++] = {tree.left[it.node], it.prefix << 1, it.depth + 1};
-            }
-        }
-    }
+    a.root = (uint32_t)(tree.root - (int32_t)A);
     const size_t A0 = pay & ~(size_t)3;
     memcpy(pin + PIN_IN, in + A0, n - A0);
-    memset(pin + PIN_IN + (n - A0), 0, 16);
-    uint32_t *status = (uint32_t *)(pin + PIN_CNT) + 132;
-    status[0] = 2; status[1] = 0;
-    SmallDecArgs a{};
-    a.lut = lut; a.child = child; a.pay = (const uint32_t *)(pin + PIN_IN);
-    a.pay_words = (uint32_t)((n - A0 + 3) / 4);
+    memset(pin + PIN_IN + (n - A0), 0, 64);
+    uint32_t *status = (uint32_t *)(pin + PIN_CNT);
+    a.pay = (const uint32_t *)(pin + PIN_IN);
+    a.pay_words = (uint32_t)((n - A0 + 3) / 4) + 8;
     a.p0 = (uint32_t)(8 * (pay - A0) + diff);
     a.end = (uint32_t)(8 * (pay - A0) + nbits);
     a.K = (uint32_t)K; a.n_child = (uint32_t)(2 * n_int);
-    a.hout = (uint4 *)(pin + PIN_OUT); a.status = status;
-    RSN_LAUNCH("huff_small_dec", k_small_dec, dim3(1), dim3(SB), DEC_LDS, s, a);
-    RSN_HIP(hipStreamSynchronize(s));
-    if (getenv("RSN_DEBUG")) { fprintf(stderr, "dec stamps:"); for (int k = 1; k < 8; k++) fprintf(stderr, " %u", status[4 + k] - status[4]); fprintf(stderr, "  rounds %u\n", status[12]); }
-    if (status[0] != 0) return 1;
-    *out = pin + PIN_OUT; *out_n = status[1];
+    const uint32_t span = a.end - a.p0;
+    a.S = std::max<uint32_t>(64, (uint32_t)round_up(ceil_div(span, DEC_BLOCKS * DL), 32));
+    if (a.S > DEC_S_MAX) return 1;
+    a.T = (uint32_t)ceil_div(span, a.S);
+    const uint32_t n_blk = (uint32_t)ceil_div(a.T, DL);
+    a.seq = seq;
+    a.hout = pin + PIN_OUT; a.status = status;
+    a.g_maps = (uint32_t *)dp; a.g_flags = a.g_maps + DEC_BLOCKS * 32;
+    for (uint32_t b = 0; b <= DEC_BLOCKS; b++) status[b] = FLAG_PENDING;
+    RSN_LAUNCH("huff_small_dec", k_small_dec, dim3(n_blk), dim3(DT), 0, s, a);
+    rc = wait_flags(c, s, status, n_blk); if (rc) return rc;
+    for (uint32_t b = 0; b < n_blk; b++) if (status[b] != 0) return 1;
+    *out = pin + PIN_OUT; *out_n = status[DEC_BLOCKS];
     return RSN_OK;
 }
 

@@ -1,5 +1,6 @@
 """GPU parity: the small-input Huffman path (huff_small.hip: host buffers up to 64 KiB, byte alphabets -- two launches to compress, one to
 decompress) against the CPU oracle, bit-exact, and against the general path (the device-pointer entry points never take the small one)."""
+import os
 import random
 
 import numpy as np
@@ -51,6 +52,11 @@ def _fib(k):
 def _inputs():
     rng = np.random.default_rng(0x5A11)
     yield "samiam-like text 64 KiB", _text(1, 65536)
+    sam = open(os.path.join(os.path.dirname(__file__), "golden", "samiam.txt"), "rb").read()
+    yield "the README's file repeated to 64 KiB (periodic: a wrong parse can last)", (sam * (65536 // len(sam) + 1))[:65536]
+    yield "a period of 7 bytes", (b"abcabda" * 9400)[:65536]
+    yield "uniform over 16 symbols: four phases", rng.integers(65, 81, size=60000, dtype=np.uint8).tobytes()
+    yield "uniform over 32 symbols: five phases (the general decoder's)", rng.integers(65, 97, size=60000, dtype=np.uint8).tobytes()
     for n in (64, 65, 100, 1000, 1023, 1024, 4096, 16384 + 3, 50000, 65535, 65536):
         yield "text %d" % n, _text(n, n)
         yield "uniform ascii %d" % n, rng.integers(0, 128, size=n, dtype=np.uint8).tobytes()
