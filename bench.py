@@ -421,7 +421,8 @@ def config1_and_host_api(torch, device, n, with_host_gib):
                 "cpu_baseline": {"value": round(len(data) / 1e6 / ((oe + od) / 1e3), 2), "unit": "MB/s", "cores": 1, "kind": "port",
                                  "sample": "the whole 64 KiB, single-thread oracle: encode %.3f ms + decode %.3f ms (median of 5)" % (oe, od)},
                 "gpu_faster_than_one_cpu_core": bool(enc + dec < oe + od),
-                "note": "median of 25 calls; a call is ~10 launches and 2-3 host round trips: at this size the fixed cost is the time"}
+                "note": "median of 25 calls; the small-input path (huff_small.hip): compress = 2 launches, decompress = 1, no copy command, "
+                        "the host polls flags in pinned memory instead of waiting for the stream (r04: ~10 launches, 0.087 / 0.128 ms)"}
     if with_host_gib:
         ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, second call (pages mapped, arenas grown); never `value`"}
         src = W.config_input("2a", n, device).cpu().numpy()

@@ -597,8 +597,7 @@ static int small_result(Ctx &c, int rc, const uint8_t *p, size_t got, uint8_t **
 
 int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
-    static const bool no_small = getenv("RSN_NO_SMALL") != nullptr;      // A/B switch (tests): inputs up to 64 KiB through the general path too
-    if (!no_small && in && out && out_n && n <= 65536) {
+    if (in && out && out_n && n <= 65536) {                              // (the general path for the same bytes: the device-pointer entry points, tests/test_gpu_huffman_small.py)
         Ctx &c = ctx(); const uint8_t *p = nullptr; size_t got = 0;
         const int rc = small_result(c, huff_small_compress(c, in, n, &p, &got), p, got, out, out_n);
         if (rc != 1) return rc;
@@ -656,8 +655,7 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
     static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;     // A/B switch (tests): upload, decode, download, one after the other
-    static const bool no_small = getenv("RSN_NO_SMALL") != nullptr;
-    if (!no_small && n <= 65536 + 2048) {
+    if (n <= 65536 + 2048) {
         const uint8_t *p = nullptr; size_t got = 0;
         const int rc = small_result(c, huff_small_decompress(c, in, n, &p, &got), p, got, out, out_n);
         if (rc != 1) return rc;
