@@ -160,6 +160,36 @@ constexpr int ESC_RUN = 8;                  // consecutive 4 KiB chunks per bloc
                                             // previous chunk's, still in the lane's registers -- 1.125 N fetched for the comparison instead of 2 N
 __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ fc, unsigned long long *__restrict__ flag,
                                                 uint32_t Wp, uint8_t *__restrict__ same_blk, uint32_t n_chunks) {
+    if (!fc && same_blk && Wp == (uint32_t)ESC_TILE && blockIdx.x > 0 && (size_t)(blockIdx.x + 1) * ESC_RUN * ESC_TILE <= n) {
+        // The check alone, on whole chunks inside the stream (r05): the run's nine loads -- its eight chunks and the one before -- in flight
+        // together, the chunks' verdicts reduced once (the loop below waits for a load and a barrier per chunk: 3.6 TB/s; this: the read rate).
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + (size_t)blockIdx.x * ESC_RUN * ESC_TILE + threadIdx.x * 16);
+        uint4 v[ESC_RUN + 1];
+#pragma unroll
+        for (int k = 0; k <= ESC_RUN; k++) v[k] = p[(k - 1) * (ESC_TILE / 16)];
+        uint32_t same_bits = 0, special = 0, lt = 0;
+#pragma unroll
+        for (int k = 1; k <= ESC_RUN; k++) {
+            const uint32_t d = (v[k].x ^ v[k - 1].x) | (v[k].y ^ v[k - 1].y) | (v[k].z ^ v[k - 1].z) | (v[k].w ^ v[k - 1].w);
+            same_bits |= (d == 0 ? 1u : 0u) << (k - 1);
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); lt |= bytes_equal(w[j], 0x3Cu); }
+        }
+        __shared__ uint32_t s_and[LB / 64], s_any[LB / 64];
+        uint32_t wave_and = 0;
+#pragma unroll
+        for (int k = 0; k < ESC_RUN; k++) wave_and |= (__ballot((same_bits >> k) & 1u) == ~0ull ? 1u : 0u) << k;
+        const uint32_t wave_any = (__ballot(special != 0) ? 1u : 0u) | (__ballot(lt != 0) ? 2u : 0u);
+        if ((threadIdx.x & 63) == 0) { s_and[threadIdx.x >> 6] = wave_and; s_any[threadIdx.x >> 6] = wave_any; }
+        __syncthreads();
+        uint32_t all = ~0u, any = 0;
+#pragma unroll
+        for (int wv = 0; wv < LB / 64; wv++) { all &= s_and[wv]; any |= s_any[wv]; }
+        if (threadIdx.x < (uint32_t)ESC_RUN) same_blk[blockIdx.x * ESC_RUN + threadIdx.x] = (uint8_t)((all >> threadIdx.x) & 1u);
+        if (threadIdx.x == 0 && (any & ~__atomic_load_n(flag, __ATOMIC_RELAXED))) atomicOr(flag, (unsigned long long)any);
+        return;
+    }
     uint32_t prev[4] = {0, 0, 0, 0};
     int prev_cnt = -1;                                                     // -1: nothing in `prev` (the run's first chunk, or Wp is not a chunk)
     uint32_t seen = 0;                                                     // bit 0: a 5C / FF, bit 1: a '<' -- one look at the flag per BLOCK, at the end (r05: a stream with a '<' in
