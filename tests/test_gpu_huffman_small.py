@@ -156,3 +156,32 @@ def test_foreign_headers_decode_as_the_reference_would(huff, oracle):
     s = doubled + good[sep:]
     want = oracle.huffman_decompress(s)
     assert huff.Decompress(s) == want == _general_decompress(huff, s)
+
+
+def test_small_calls_from_many_threads(huff, oracle):
+    """every thread has its own context: pinned staging, device scratch, the decoder's block flags and call numbers"""
+    from concurrent.futures import ThreadPoolExecutor
+    datas = [_text(100 + k, 3000 + 7919 * k % 60000) for k in range(8)]
+    wants = [oracle.huffman_compress(d) for d in datas]
+
+    def work(k):
+        for _ in range(60):
+            c = huff.Compress(datas[k])
+            if c != wants[k] or huff.Decompress(c) != datas[k]:
+                return False
+        return True
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        assert all(ex.map(work, range(8)))
+
+
+def test_small_and_large_calls_interleave_on_one_thread(huff, oracle):
+    """the small path polls flags instead of waiting for the stream: what follows on the same stream must still see its results in order"""
+    big = _text(9, 3 << 20)
+    small = _text(10, 20000)
+    want_big, want_small = oracle.huffman_compress(big), oracle.huffman_compress(small)
+    for _ in range(5):
+        assert huff.Compress(small) == want_small
+        assert huff.Compress(big) == want_big
+        assert huff.Decompress(want_small) == small
+        assert huff.Decompress(want_big) == big
