@@ -424,42 +424,53 @@ def config1_and_host_api(torch, device, n, with_host_gib):
                 "note": "median of 25 calls; the small-input path (huff_small.hip): compress = 2 launches, decompress = 1, no copy command, "
                         "the host polls flags in pinned memory instead of waiting for the stream (r04: ~10 launches, 0.087 / 0.128 ms)"}
     if with_host_gib:
-        ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, second call (pages mapped, arenas grown); never `value`"}
-        src = W.config_input("2a", n, device).cpu().numpy()
-        for rep in range(2):
-            c, te = _host_call(L.rsn_huffman_compress, src)
-            d, td = _host_call(L.rsn_huffman_decompress, c)
-        ha["huffman_2a"] = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src)),
-                            "encode_GBps": round(n / te / 1e6, 2), "decode_GBps": round(n / td / 1e6, 2)}
-        del c, d
-        src = W.config_input("4", n, device).cpu().numpy()
-        for rep in range(2):
-            c, te = _host_call(L.rsn_lzss_compress, src, 4096)
-            d, td = _host_call(L.rsn_lzss_decompress, c)
-        ha["lzss_text"] = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src)),
-                           "encode_GBps": round(n / te / 1e6, 2), "decode_GBps": round(n / td / 1e6, 2)}
-        # the same calls from a plain C++ process (what a cgo caller is like), pipelined and with RSN_HOST_SERIAL=1: the pipelined Huffman
-        # decode overlaps its two transfers there -- 24.4 against 37 ms -- and, for a reason r05 did not find, not inside a Python
-        # process (36 ms either way); the pipelined LZSS encode hides both transfers under the encoder
-        text_file = "/tmp/rsn_bench_text_%d.bin" % os.getpid()
+        # Host buffer in, library-owned host buffer out (what the cgo shim binds).  The figures are a plain C++ PROCESS's (what a cgo caller
+        # is like; scripts/probes/host_call_probe.cpp on the same bytes, best of three warm calls), pipelined and with RSN_HOST_SERIAL=1;
+        # `python_process` is the same call through ctypes from this process, where two transfers in opposite directions share the
+        # link's one-way rate for a reason r05 did not find.
+        import subprocess
+        ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, warm calls (pages mapped, arenas grown); PCIe included, never `value`; "
+                                  "encode_ms / decode_ms: a C process; python_process: this process through ctypes"}
+        exe = "/tmp/rsn_host_call_probe_%d" % os.getpid()
         try:
-            import subprocess
-            exe = "/tmp/rsn_host_call_probe"
             subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "scripts", "probes", "host_call_probe.cpp"),
                                    "-L" + os.path.join(ROOT, "raisin_amd"), "-lrsn", "-Wl,-rpath," + os.path.join(ROOT, "raisin_amd")])
-            src.tofile(text_file)
-            for key, kind in (("huffman_2a_like_from_a_c_process", "0"), ("lzss_text_from_a_c_process", "@" + text_file)):
-                res = {}
-                for label, env in (("pipelined", {}), ("serial", {"RSN_HOST_SERIAL": "1"})):
-                    r = subprocess.run([exe, str(n >> 20), kind], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-                    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
-                    res[label] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
-                ha[key] = res
         except Exception as e:                              # noqa: BLE001
-            ha["from_a_c_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            if os.path.exists(text_file):
-                os.remove(text_file)
+            exe = None
+            ha["c_process_error"] = "%s: %s" % (type(e).__name__, e)
+        for key, cfg, kind, comp, decomp, extra in (("huffman_2a", "2a", "h@", L.rsn_huffman_compress, L.rsn_huffman_decompress, ()),
+                                                    ("lzss_text", "4", "@", L.rsn_lzss_compress, L.rsn_lzss_decompress, (4096,))):
+            src = W.config_input(cfg, n, device).cpu().numpy()
+            for rep in range(2):
+                c, te = _host_call(comp, src, *extra)
+                d, td = _host_call(decomp, c)
+            py = {"encode_ms": round(te, 2), "decode_ms": round(td, 2), "lossless": bool(np.array_equal(d, src))}
+            del c, d
+            entry = {}
+            if exe:
+                data_file = "/tmp/rsn_bench_%s_%d.bin" % (cfg, os.getpid())
+                try:
+                    src.tofile(data_file)
+                    for label, env in (("pipelined", {}), ("serial", {"RSN_HOST_SERIAL": "1"})):
+                        r = subprocess.run([exe, str(n >> 20), kind + data_file], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+                        line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
+                        res = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+                        if label == "pipelined" and "compress_ms" in res:
+                            entry.update({"encode_ms": res["compress_ms"], "decode_ms": res["decompress_ms"], "lossless": res["lossless"],
+                                          "compressed_bytes": res["compressed"],
+                                          "encode_GBps": round(n / res["compress_ms"] / 1e6, 2), "decode_GBps": round(n / res["decompress_ms"] / 1e6, 2)})
+                        else:
+                            entry[label] = res
+                except Exception as e:                      # noqa: BLE001
+                    entry["c_process_error"] = "%s: %s" % (type(e).__name__, e)
+                finally:
+                    if os.path.exists(data_file):
+                        os.remove(data_file)
+            entry["python_process"] = py
+            ha[key] = entry
+            del src
+        if exe and os.path.exists(exe):
+            os.remove(exe)
         out["host_api"] = ha
         L.rsn_trim()
     return out

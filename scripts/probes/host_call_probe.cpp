@@ -1,6 +1,6 @@
 // the host-buffer calls from a plain C++ process (no Python, no torch): <MiB> <kind>
 //   kind 0: 2a-like bytes (128 equiprobable symbols), Huffman; 1: skewed symbols, Huffman; 2: Zipf text over 4096 words, LZSS (window 4096);
-//   @<file>: the first <MiB> of that file, LZSS (bench.py hands config 4's text over this way)
+//   @<file>: the first <MiB> of that file, LZSS; h@<file>: the same, Huffman (bench.py hands config 4's text and config 2a's bytes over this way)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,8 +13,8 @@
 static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
     const size_t n = (size_t)(argc > 1 ? atoi(argv[1]) : 1024) << 20;
-    const char *file = argc > 2 && argv[2][0] == '@' ? argv[2] + 1 : nullptr;
-    const int skew = file ? 2 : argc > 2 ? atoi(argv[2]) : 0;
+    const char *file = argc > 2 && argv[2][0] == '@' ? argv[2] + 1 : argc > 2 && argv[2][0] == 'h' && argv[2][1] == '@' ? argv[2] + 2 : nullptr;
+    const int skew = file ? (argv[2][0] == 'h' ? 0 : 2) : argc > 2 ? atoi(argv[2]) : 0;
     uint8_t *src = (uint8_t *)malloc(n);
     unsigned long long z = 88172645463325252ull;
     auto next = [&] { z ^= z << 13; z ^= z >> 7; z ^= z << 17; return z; };

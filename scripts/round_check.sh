@@ -15,7 +15,7 @@ j=json.loads(open("gpurun_out/%s_bench.json" % sys.argv[1]).read().strip().split
 print({k:j[k] for k in ("value","ms_per_step","encode_ms","decode_ms","roofline")})
 print({k:(v.get("ms"),v.get("frac_of_hbm_peak")) for k,v in j["kernels"].items()})
 for k,v in j["other_configs"].items():
-    print(k, {x:v.get(x) for x in ("encode_ms","decode_ms","encode_ms_min","decode_ms_min","lossless","bit_exact_vs_oracle_on_sample","encode_frac_of_hbm_peak","decode_frac_of_hbm_peak","error","huffman_2a","lzss_text","huffman_2a_like_from_a_c_process")})
+    print(k, {x:v.get(x) for x in ("encode_ms","decode_ms","encode_ms_min","decode_ms_min","lossless","bit_exact_vs_oracle_on_sample","encode_frac_of_hbm_peak","decode_frac_of_hbm_peak","error","huffman_2a","lzss_text")})
 for k in ("general_path_2a","cold_start"):
     print(k, j.get(k))
 PY
