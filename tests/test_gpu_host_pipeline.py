@@ -89,7 +89,7 @@ def test_pipelined_lzss_compress_is_the_serial_compress(oracle):
     mixed = text[: 40 << 20] + (per * ((50 << 20) // len(per) + 1))[: 50 << 20] + bytes(30 << 20) + text[40 << 20: 56 << 20]
     esc_early = b"\\" + text[1:]
     esc_late = text[:-5] + b"\xff" + text[-4:]
-    datas = {"text": text, "lt": lt, "mixed": mixed, "esc_early": esc_early, "esc_late": esc_late}
+    datas = {"text": text, "lt": lt, "mixed": mixed, "esc_early": esc_early, "esc_late": esc_late, "odd length": text[3:-2]}
     got = {k: hashlib.sha256(lz.CompressAsync(v)).hexdigest() for k, v in datas.items()}
     code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
             "datas = pickle.load(open(sys.argv[1], 'rb'))\n"
