@@ -48,6 +48,7 @@ constexpr int OUT_STAGE_RUNE = 40960; // the same for rune alphabets: a rune is 
 constexpr int CHILD_LDS = 256;      // child[] of a byte alphabet (<= 2 * 127 entries) is staged in LDS
 constexpr int LUT2_LDS = 768;       // second-level entries that fit in LDS (larger second levels are read through L2)
 constexpr uint32_t LUT2_GLOBAL_MAX = 1u << 20;   // entries of a second level kept in device memory (4 MB)
+constexpr int SYNC_ROUNDS = 24;     // rounds of a block's fixed point before it is called stuck (text: two or three; a stretch in a second phase: one per lane)
 constexpr uint32_t BAD_REL = 0xFFFF;
 constexpr uint32_t BAD_POS = 0xFFFFFFFFu;
 
@@ -63,6 +64,7 @@ struct DecArgs {
     uint16_t *exit_rel, *entry_rel, *nbyte;
     unsigned long long *blk_bytes;
     int *changed; int pass;
+    int *stuck;                 // set by a block whose lanes are still handing corrections on after SYNC_ROUNDS rounds: the stream is settled by k_dec_phase instead
     const uint32_t *fix_list, *fix_count;   // pass > 0: the blocks whose first entry is not their predecessor's exit (k_dec_fix_list); null: every block looks for itself
     const unsigned long long *blk_off; uint8_t *out;   // D3
     uint32_t child_n;           // entries of child[]
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
                 if (en != e) { e = en; have = false; changed = true; }
             }
             if (!__syncthreads_or(changed)) break;
+            if (round == SYNC_ROUNDS) { if (tid == 0) *a.stuck = 1; break; }   // (what the lanes hold is then not one parse: the host does not use it)
         }
         if (live) {
             const uint16_t new_exit = x == BAD_POS ? (uint16_t)BAD_REL : (uint16_t)(x - lim);
@@ -402,6 +405,90 @@ __global__ __launch_bounds__(256) void k_dec_fix_list(const uint16_t *__restrict
     if (lane == 0) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (need) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b;
+}
+
+// ---------------------------------------------------------------- the synchronisation when it does not converge: every entry of every lane
+// k_dec_sync's fixed point hands a correction on lane by lane inside a block and block by block from launch to launch.  That is two or
+// three rounds on data whose parses merge -- and as many rounds as a stretch has lanes, as many launches as it has blocks, where they do
+// not: PERIODIC data can be parsed in a second phase for as long as the period lasts, and no guess made inside the stretch ever lands in
+// the true one (r05: 4 MiB of a 20-byte UTF-8 unit repeated took 474 ms, 160 launches of up to 256 rounds; found by
+// scripts/probes/periodic_decode.py).  When the fixing passes have not settled a stream this kernel does, in two launches whatever the
+// length and with nothing left to chance: a codeword that ends in a subsequence begins less than the longest code's length C before it, so
+// a lane can only be entered at one of its first C bits -- the kernel decodes EVERY lane from EVERY one of them (C times a pass's work:
+// the price of a stream that does not synchronise), a table "lane t entered at bit c -> left at x, n bytes" in LDS, 64 lanes at a time;
+//   mode 0  C lanes follow the C possible entries of the block through the table: "block entered at c -> left at x, n bytes" (to the host,
+//           which chains the blocks: block 0 is entered at the stream's first code bit)
+//   mode 2  one lane follows the true entry and writes what k_dec_sync would have left: entry_rel, exit_rel, nbyte, blk_bytes -- the
+//           offsets and the emit pass then run as always
+constexpr uint32_t PH_CAND = 64;      // a code has at most 64 bits (huff_host.cpp refuses longer ones)
+struct PhaseArgs {
+    uint2 *blk_map;                   // [PH_CAND * n_blk]: the block entered at c: (exit, bytes); bytes = 0xFFFFFFFF: no such path
+    const uint8_t *true_c;            // mode 2: the block's true entry; 0xFF: the stream ran off its payload before this block
+    uint32_t cand;                    // C: the longest code's length, at most PH_CAND
+};
+
+template <bool ASCII, bool SHORT, bool MULTI>
+__global__ __launch_bounds__(DB) void k_dec_phase(DecArgs a, PhaseArgs p, uint32_t n_blk, int mode) {
+    __shared__ __attribute__((aligned(1024))) uint32_t s_data[DATA_PHYS];
+    __shared__ uint32_t s_lut[LUT_WORDS];
+    __shared__ int32_t s_child[SHORT ? 1 : CHILD_LDS];
+    __shared__ uint32_t s_lut2[SHORT ? 1 : LUT2_LDS];
+    __shared__ uint32_t s_T[64 * PH_CAND];           // [lane of the group][entry bit]: exit | bytes << 16
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t lane_r = tid & ((1u << a.rep_log2) - 1);
+    stage_lut(a, s_lut);
+    if (!SHORT && a.child_n <= (uint32_t)CHILD_LDS) { for (uint32_t i = tid; i < a.child_n; i += DB) s_child[i] = a.child[i]; a.child = s_child; }
+    const Lut2 l2{s_lut2, a.lut2_n <= (uint32_t)LUT2_LDS};
+    if (!SHORT && l2.in_lds) for (uint32_t i = tid; i < a.lut2_n; i += DB) s_lut2[i] = a.lut2[i];
+    for (uint32_t blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        const unsigned long long blk_bit0 = (unsigned long long)blk * DB * SBITS;
+        const uint32_t L = min((uint32_t)DB, a.n_sub - blk * DB);          // lanes of this block that have a subsequence
+        const uint32_t end_rel = (uint32_t)min(a.end - blk_bit0 + ORG, (unsigned long long)(ORG + DB * SBITS + 4096));
+        const uint32_t C = p.cand;
+        __syncthreads();                                                    // (the previous block of this loop is done with the LDS)
+        stage_data(a, blk, s_data);
+        // the followers: mode 0 lane c < C is the block entered at bit c; mode 2 lane 0 is the block entered at its true bit
+        uint32_t e = mode == 0 ? (uint32_t)tid : (uint32_t)p.true_c[blk];
+        if (mode == 2 && e == 0xFF) e = BAD_REL;
+        if (blk == 0 && mode == 0 && tid > 0) e = 0x10000u;                 // (block 0 has one entry, the stream's first code bit: the table's bit 0 of its lane 0)
+        uint32_t bytes = 0;
+        const bool follower = mode == 0 ? (uint32_t)tid < C : tid == 0;
+        for (uint32_t grp0 = 0; grp0 < L; grp0 += 64) {
+            __syncthreads();                                                // (the followers are done with the table of the group before; the first time: the staging)
+            // ---- the table of lanes grp0 .. grp0 + 63: a wavefront takes every fourth entry bit of all of them
+            const uint32_t t = grp0 + lane;                                 // the lane of the block this thread decodes for
+            if (t < L) {
+                const uint32_t t0 = ORG + t * SBITS, lim = min(t0 + (uint32_t)SBITS, end_rel);
+                const uint32_t first = blk == 0 && t == 0 ? (uint32_t)a.p0 : 0u;   // (the stream begins inside block 0's lane 0)
+                for (uint32_t c0 = wave; c0 < C; c0 += DB / 64) {
+                    uint32_t x = BAD_POS, nbs = 0;
+                    walk<ASCII, SHORT, MULTI>(a, s_data, s_lut, lane_r, l2, t0 + first + c0, lim, t + 1u, end_rel, &x, &nbs);
+                    s_T[lane * PH_CAND + c0] = (x == BAD_POS ? (uint32_t)BAD_REL : x - lim) | nbs << 16;
+                }
+            }
+            __syncthreads();
+            if (follower) {
+                const uint32_t n_here = min(64u, L - grp0);
+                for (uint32_t k = 0; k < n_here; k++) {
+                    const uint32_t g = blk * DB + grp0 + k;
+                    uint32_t x = BAD_REL, nbs = 0;
+                    if (e < C) { const uint32_t v = s_T[k * PH_CAND + e]; x = v & 0xFFFFu; nbs = v >> 16; }
+                    else if (e != BAD_REL) e = 0x10000u;                    // an entry that cannot be: no path (mode 0), an internal error (mode 2)
+                    if (mode == 2) {
+                        a.entry_rel[g] = (uint16_t)(e == BAD_REL || e >= C ? (uint32_t)BAD_REL : (blk == 0 && grp0 + k == 0 ? (uint32_t)a.p0 : e));
+                        a.exit_rel[g] = (uint16_t)x; a.nbyte[g] = (uint16_t)nbs;
+                    }
+                    bytes += nbs;
+                    if (e < C || e == BAD_REL) e = x;                       // (BAD stays BAD: x is BAD_REL then)
+                }
+            }
+        }
+        if (follower) {
+            if (mode == 0) p.blk_map[(size_t)blk * PH_CAND + tid] = make_uint2(e & 0xFFFFu, e > 0xFFFFu ? 0xFFFFFFFFu : bytes);
+            else a.blk_bytes[blk] = bytes;
+        }
+    }
 }
 
 // Per-lane byte sink for the direct (unstaged) path: aligned 8-byte stores, byte stores
@@ -940,6 +1027,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     unsigned long long *d_blk_off = a.blk_bytes + n_blk;
     unsigned long long *d_total = d_blk_off + n_blk;
     int *d_changed = (int *)(d_total + 1);
+    int *d_stuck = (int *)(d_total + 2);
+    a.stuck = d_stuck;
     uint32_t *d_fix_count = (uint32_t *)(d_changed + 1);                 // (zeroed together with `changed`)
     uint32_t *d_fix_list = (uint32_t *)(d_total + 4);
     a.changed = d_changed;
@@ -961,7 +1050,7 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // can run before the host has seen the total; if the fixing pass did hand some block a different exit (rare), everything
     // after it is queued again.
     a.blk_off = d_blk_off; a.out = rout; a.out_cap = rcap;
-    struct Tail { unsigned long long total; uint16_t last_exit; int changed; };
+    struct Tail { unsigned long long total; uint16_t last_exit; int changed; int stuck; };
     Tail *ht = (Tail *)hp;
     auto launch_emit = [&]() -> int {
         // (8-byte table entries with the symbols already spread to bytes measured slower than unpacking the 4-byte ones: 1.19 vs 0.98 ms)
@@ -982,11 +1071,58 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         rc2 = launch_emit(); if (rc2) return rc2;
         RSN_HIP(hipMemcpyAsync(&ht->total, d_total, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipMemcpyAsync(&ht->last_exit, a.exit_rel + (a.n_sub - 1), 2, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipMemcpyAsync(&ht->stuck, d_stuck, 4, hipMemcpyDeviceToHost, s));
+        return RSN_OK;
+    };
+    // ---- the phase solver (k_dec_phase): RSN_OK = the arrays hold the true path; 1 = it gave up (the passes go on)
+    auto phase_solve = [&]() -> int {
+        static const bool dbg2 = getenv("RSN_DEBUG") != nullptr;
+        const size_t nbk = n_blk;
+        void *pp2; int r2 = dev_buf(c, 34, nbk * (PH_CAND * 8 + 1) + 256, &pp2); if (r2) return r2;
+        PhaseArgs ph{};
+        ph.blk_map = (uint2 *)pp2;
+        uint8_t *d_true = (uint8_t *)(ph.blk_map + PH_CAND * nbk);
+        ph.true_c = d_true;
+        ph.cand = std::min<uint32_t>(PH_CAND, std::max<uint32_t>(codes.max_len, 1));
+        auto launch_phase = [&](int mode) -> int {
+            const char *nm = mode == 0 ? "huff_dec_phase" : "huff_dec_phase_write";
+            if (multi && short_codes) RSN_LAUNCH(nm, (k_dec_phase<true, true, true>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            else if (multi) RSN_LAUNCH(nm, (k_dec_phase<true, false, true>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            else if (ascii && short_codes) RSN_LAUNCH(nm, (k_dec_phase<true, true, false>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            else if (ascii) RSN_LAUNCH(nm, (k_dec_phase<true, false, false>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            else if (short_codes) RSN_LAUNCH(nm, (k_dec_phase<false, true, false>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            else RSN_LAUNCH(nm, (k_dec_phase<false, false, false>), dim3(grid_p), dim3(DB), 0, s, a, ph, n_blk, mode);
+            return RSN_OK;
+        };
+        void *hq; r2 = pinned_buf(c, 64 + nbk * PH_CAND * 8, &hq); if (r2) return r2;      // (the pinned block may have moved: `ht` lives at its start)
+        hp = hq;
+        ht = (Tail *)hq;
+        ht->changed = 1;
+        uint2 *hmap = (uint2 *)((uint8_t *)hq + 64);
+        r2 = launch_phase(0); if (r2) return r2;
+        RSN_HIP(hipMemcpyAsync(hmap, ph.blk_map, nbk * PH_CAND * 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        // the blocks chained: block 0 is entered at the stream's first code bit (bit 0 of its table), block b + 1 at the bit b left at
+        std::vector<uint8_t> tc(nbk, 0xFF);
+        uint32_t e = 0;
+        for (size_t b = 0; b < nbk; b++) {
+            if (e == BAD_REL) break;                                          // (the stream ran off its payload: the rest stays 0xFF)
+            if (e >= ph.cand) { if (dbg2) fprintf(stderr, "huffman decode, phases: block %zu is entered at bit %u\n", b, e); return 1; }
+            const uint2 m = hmap[b * PH_CAND + e];
+            if (m.y == 0xFFFFFFFFu) { if (dbg2) fprintf(stderr, "huffman decode, phases: block %zu has no path from bit %u\n", b, e); return 1; }
+            tc[b] = (uint8_t)e;
+            e = m.x;
+        }
+        RSN_HIP(hipMemcpyAsync(d_true, tc.data(), nbk, hipMemcpyHostToDevice, s));
+        r2 = launch_phase(2); if (r2) return r2;
+        RSN_HIP(hipStreamSynchronize(s));                                     // (tc is host memory: the copy has left it)
+        if (dbg2) fprintf(stderr, "huffman decode: settled by every entry of every lane (%u blocks, %u entries a lane)\n", n_blk, ph.cand);
         return RSN_OK;
     };
     a.pass = 0;
+    RSN_HIP(hipMemsetAsync(d_stuck, 0, 4, s));
     rc = launch_sync(); if (rc) return rc;
-    ht->changed = 0;
+    ht->changed = 0; ht->stuck = 0;
     if (n_blk > 1) {                                                  // (a single block starts from the exact entry and iterates to its fixed point in LDS)
         a.pass = 1;
         RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
@@ -997,18 +1133,41 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     }
     rc = offsets_and_bytes(); if (rc) return rc;                      // ... on the assumption that the one fixing pass settled it (it nearly always does)
     RSN_HIP(hipStreamSynchronize(s));
-    if (ht->changed) {
-        // the fixing pass handed some block a different exit: more passes, the synchronisation alone, until nothing changes (a code
-        // that does not self-synchronise -- all lengths even, say -- can take as many passes as there are blocks), then D2 + D3 again
+    if (ht->stuck) {                                                    // some block's lanes did not settle among themselves: every entry of every lane
+        const int prc = phase_solve();
+        if (prc < 0) return prc;
+        if (prc != RSN_OK) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
+        rc = offsets_and_bytes(); if (rc) return rc;
+        RSN_HIP(hipStreamSynchronize(s));
+    } else if (ht->changed) {
+        // the fixing pass handed some block a different exit: more passes, the synchronisation alone, until nothing changes, then D2 + D3
+        // again.  Two more passes settle what one did not; a stream that is still moving then is in more than one PHASE (periodic data,
+        // a code whose lengths are all even): k_dec_phase settles it in a few launches, where the passes take one per block of the stretch.
+        bool by_phases = false;
+        static const bool dbg_p = getenv("RSN_DEBUG") != nullptr;
         for (uint32_t pass = 2; ht->changed; pass++) {
+            if (dbg_p) fprintf(stderr, "huffman decode: pass %u, still moving\n", pass);
+            if (pass == 3) {
+                const int prc = phase_solve();
+                if (prc < 0) return prc;
+                if (prc == RSN_OK) { by_phases = true; break; }
+            }
             if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
             a.pass = (int)pass;
             RSN_HIP(hipMemsetAsync(d_changed, 0, 8, s));
             RSN_LAUNCH("huff_dec_fix_list", k_dec_fix_list, dim3((uint32_t)ceil_div(n_blk, 256)), dim3(256), 0, s, (const uint16_t *)a.exit_rel, (const uint16_t *)a.entry_rel, n_blk, d_fix_list, d_fix_count);
             rc = launch_sync(); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(&ht->changed, d_changed, 4, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipMemcpyAsync(&ht->stuck, d_stuck, 4, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
+            if (ht->stuck) {
+                const int prc = phase_solve();
+                if (prc < 0) return prc;
+                if (prc != RSN_OK) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
+                break;
+            }
         }
+        (void)by_phases;
         rc = offsets_and_bytes(); if (rc) return rc;
         RSN_HIP(hipStreamSynchronize(s));
     }

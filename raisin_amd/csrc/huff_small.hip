@@ -19,6 +19,7 @@
 
 #include "codecs.h"
 #include "huff_host.h"
+#include "huff_pathmap.h"
 
 namespace rsn {
 namespace {
@@ -251,24 +252,6 @@ __device__ __noinline__ void emit_path(const uint32_t *pay, const uint32_t *lut,
     for (uint32_t i = 0; i < count; i++) out[i] = (uint8_t)dec_one(r, tab);
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t packed, uint32_t j) { return (packed >> (8 * j)) & 0xFF; }
-// "entry j of the first lane -> entry to[j] of the lane behind the last, c[j] symbols on the way"; to[j] == 7: no such path
-struct PathMap { uint32_t to, c0, c1, c2, c3; };
-__device__ __forceinline__ uint32_t pm_to(const PathMap &m, uint32_t j) { return j < 4 ? (m.to >> (3 * j)) & 7 : 7u; }
-__device__ __forceinline__ uint32_t pm_c(const PathMap &m, uint32_t j) { return j == 0 ? m.c0 : j == 1 ? m.c1 : j == 2 ? m.c2 : m.c3; }
-__device__ __forceinline__ PathMap pm_then(const PathMap &a, const PathMap &b) {         // a's lanes first, then b's
-    PathMap r;
-    uint32_t t[4], c[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const uint32_t mid = pm_to(a, j); t[j] = pm_to(b, mid); c[j] = pm_c(a, j) + (mid < 4 ? pm_c(b, mid) : 0u); }
-    r.to = t[0] | t[1] << 3 | t[2] << 6 | t[3] << 9; r.c0 = c[0]; r.c1 = c[1]; r.c2 = c[2]; r.c3 = c[3];
-    return r;
-}
-constexpr uint32_t PM_ID = 0 | 1 << 3 | 2 << 6 | 3 << 9;
-__device__ __forceinline__ PathMap pm_shfl_up(const PathMap &m, int d) {
-    PathMap r; r.to = __shfl_up(m.to, d, 64); r.c0 = __shfl_up(m.c0, d, 64); r.c1 = __shfl_up(m.c1, d, 64); r.c2 = __shfl_up(m.c2, d, 64); r.c3 = __shfl_up(m.c3, d, 64);
-    return r;
-}
-
 __global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
     __shared__ uint32_t s_pay[DEC_PAY_WORDS];                 // big-endian words of this block's part of the stream
     __shared__ uint32_t s_lut[1u << DEC_K];                   // len << 8 | byte, or 0x80000000 | internal node reached after K bits

@@ -248,8 +248,9 @@ def test_a_code_that_does_not_self_synchronise(huff, oracle):
     """Code lengths {3 x 7, 6 x 8}: every codeword's length is a multiple of three, so a decode that starts on the wrong residue never
     finds the boundaries again (an all-even code would not do: the pad keeps the payload's parity).  Two lanes in three start their
     warm-up on a wrong residue, the in-block fixed point takes hundreds of rounds, every block's guessed entry is as likely wrong as
-    not and so is its predecessor's first exit: the fixing pass changes exits and the decoder goes through pass after pass -- the
-    loop behind the speculative D2 + D3 -- until the parse has crossed the stream; the bytes are the oracle's."""
+    not and so is its predecessor's first exit: r04 went through pass after pass -- the loop behind the speculative D2 + D3 -- until
+    the parse had crossed the stream (55 passes); r05 calls such a block stuck and decodes the stream from every entry of every lane
+    (k_dec_phase, see test_streams_that_do_not_settle_are_decoded_from_every_entry); the bytes are the oracle's."""
     rng = np.random.default_rng(77)
     syms = np.arange(65, 80, dtype=np.uint8)
     w = np.array([8] * 7 + [1] * 8, dtype=np.float64)
@@ -260,3 +261,36 @@ def test_a_code_that_does_not_self_synchronise(huff, oracle):
         c = oracle.huffman_compress(body)
         assert huff.Compress(body) == c
         assert huff.Decompress(c) == body == oracle.huffman_decompress(c)
+
+
+def test_streams_that_do_not_settle_are_decoded_from_every_entry(huff, oracle):
+    """Periodic data parses in more than one phase for as long as the period lasts, and a code whose lengths share a factor never finds
+    the boundaries again from a wrong residue: the fixed point's rounds then walk the stretch a lane at a time, its passes a block at a
+    time (r05: 474 ms for the first of these inputs).  A block that is still handing corrections on after SYNC_ROUNDS rounds is called
+    stuck and the stream is decoded from every possible entry of every lane (k_dec_phase): the oracle's bytes, in milliseconds."""
+    import time
+    from raisin_amd import _lib
+    unit = b'a\xe4\xb8\x96\xc3\xa8\xe6\x9c\xac\xe4\xb8\x96u\xc3\xb6uuu\xe6\x9c\xac\xc3\xa8\xe6\x9c\xac'
+    rng = np.random.default_rng(2)
+    five = np.repeat(np.arange(63) + 48, [32] * 31 + [1] * 32)                   # code lengths 5 and 10: five residues
+    cases = {"a UTF-8 unit of 13 runes repeated to 4 MiB": (unit * ((4 << 20) // len(unit) + 1))[:4 << 20],
+             "the same, 64 KiB (the small-input decoder declines runes)": ("héllo wörld 世界 " * 5000).encode()[:65536],
+             "lengths 5 and 10, 2 MiB": rng.choice(five, size=2 << 20).astype(np.uint8).tobytes(),
+             "lengths 3 and 6, 1 MiB + 1": np.arange(65, 80, dtype=np.uint8)[rng.choice(15, size=(1 << 20) + 1, p=np.array([8] * 7 + [1] * 8) / 64.0)].tobytes()}
+    settled = 0
+    for name, data in cases.items():
+        c = oracle.huffman_compress(data)
+        assert huff.Compress(data) == c, name
+        want = oracle.huffman_decompress(c)
+        huff.Decompress(c)                                                       # (warm: arenas, the result block)
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        t0 = time.perf_counter()
+        got = huff.Decompress(c)
+        dt = time.perf_counter() - t0
+        p = _lib.prof_get()
+        _lib.prof_enable(False)
+        assert got == want, name
+        assert dt < 0.1, (name, dt)
+        settled += p.get("huff_dec_phase", (0, 0))[0] > 0
+    assert settled >= 2, "no input reached k_dec_phase"
