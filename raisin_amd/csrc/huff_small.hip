@@ -199,6 +199,7 @@ struct SmallDecArgs {
     uint32_t p0, end;         // first code bit / the bit behind the last, counted from `pay`
     uint32_t K, root, n_child;  // index bits of the lookup table; the tree's root (an internal node)
     uint32_t S, T;            // bits per lane; lanes that have a subsequence
+    uint32_t flat;            // every code has this length (0: lengths differ): the boundaries are where the arithmetic says -- as many phases as the code has bits, and none to find
     uint32_t seq;             // this call's number: what a block's flag holds once its map is out
     uint8_t *hout; uint32_t *status;      // status[b]: FLAG_PENDING, then 0 = block b done, 1 = not for this kernel; status[DEC_BLOCKS]: decoded bytes
     uint32_t *g_maps, *g_flags;           // device memory: [block][32] (exit << 24 | symbols), [block]
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
         exit_off = r >> 24; count = r & 0xFFFFFFu;
     };
     // ---- the block's first lane, entered at every bit a codeword could start at (block 0: at the stream's first code bit, nowhere else)
-    if (tid >= DL && tid < DL + 32 && (b == 0 ? tid == DL : true)) {
+    const uint32_t flat0 = a.flat ? (a.flat - (b * DL * S) % a.flat) % a.flat : 0u;      // flat code: the one bit this block can be entered at
+    if (tid >= DL && tid < DL + 32 && (b == 0 ? tid == DL : (a.flat == 0 || (uint32_t)(tid - DL) == flat0))) {
         const uint32_t hi0 = min(end, blk_lo - base_bit + S);
         uint32_t e, c;
         run_in(blk_lo - base_bit, hi0, tid - DL, e, c);
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
         s_n[tid] = n_ent;
     };
     const bool chained = real && tid >= 1;                                      // lanes 1.. learn their starts from the lane before
-    if (chained) add(0);                                                        // a first guess: the subsequence's first bit
+    if (chained) add(a.flat ? (a.flat - (g * S) % a.flat) % a.flat : 0u);        // a first guess: the subsequence's first bit (flat code: the first boundary in it)
     if (tid < DL) publish();
     bool lost = false;
     for (int round = 0;; round++) {
@@ -616,6 +618,7 @@ int huff_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **o
     a.T = (uint32_t)ceil_div(span, a.S);
     const uint32_t n_blk = (uint32_t)ceil_div(a.T, DL);
     a.seq = seq;
+    a.flat = codes.min_len == codes.max_len ? codes.max_len : 0u;
     a.hout = pin + PIN_OUT; a.status = status;
     a.g_maps = (uint32_t *)dp; a.g_flags = a.g_maps + DEC_BLOCKS * 32;
     for (uint32_t b = 0; b <= DEC_BLOCKS; b++) status[b] = FLAG_PENDING;

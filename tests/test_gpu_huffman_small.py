@@ -96,6 +96,15 @@ def test_small_calls_are_two_launches_and_one(huff):
     _lib.prof_enable(False)
     assert {k: v[0] for k, v in enc.items() if v[0]} == {"huff_small_hist": 1, "huff_small_emit": 1}
     assert {k: v[0] for k, v in dec.items() if v[0]} == {"huff_small_dec": 1}
+    # a flat code (128 symbols, seven bits each) has seven phases and none to find: its boundaries are arithmetic
+    flat = np.random.default_rng(4).integers(0, 128, size=65536, dtype=np.uint8).tobytes()
+    c = huff.Compress(flat)
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    assert huff.Decompress(c) == flat
+    dec = _lib.prof_get()
+    _lib.prof_enable(False)
+    assert {k: v[0] for k, v in dec.items() if v[0]} == {"huff_small_dec": 1}
 
 
 def test_what_the_small_path_declines_takes_the_general_one(huff, oracle):
