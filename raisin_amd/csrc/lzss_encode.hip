@@ -1882,10 +1882,13 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
     if (!chain_mode) { rc = need_copy(); if (rc) return rc; }
     auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 on every strip, or on the flagged ones
-        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only};
+        // (r05: a block's time is its (strip + W) / 64 position blocks in a row -- 8 ms for 16384 positions under the engine's window -- so a
+        //  short stream is swept in shorter strips: 1 MiB of a period broken every 100 KB 15.7 -> 4 ms, scripts/probes/periodic_lzss.py)
+        const uint32_t strip = n_strips <= 64 ? 2048u : n_strips <= 1024 ? 4096u : (uint32_t)MATCH_STRIP;
+        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only, strip};
         const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
-        const size_t shmem2 = (size_t)((MATCH_STRIP + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
-        return lzss_launch_match2(c, s, m2, n_strips, shmem2);
+        const size_t shmem2 = (size_t)((strip + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
+        return lzss_launch_match2(c, s, m2, (uint32_t)ceil_div(E, strip), shmem2);
     };
     // E3 buffers (the chain walk fills flags and tile bytes itself when its per-tile chains join up)
     const uint32_t n_pt = (uint32_t)ceil_div(E, PT);

@@ -13,7 +13,8 @@ constexpr uint32_t KEY_UNKNOWN = 0xFFFFFFFFu;                     // chain mode:
 struct MatchArgs {
     const uint8_t *fc; uint32_t E; uint32_t W; uint32_t DW;   // DW = diagonals per wave
     uint32_t *keys;
-    const uint32_t *only;                                      // non-null: sweep only the strips flagged here (k_match_hash's hand-backs)
+    const uint32_t *only;                                      // non-null: sweep only the strips flagged here (k_match_hash's hand-backs), a flag per MATCH_STRIP positions
+    uint32_t strip;                                            // positions per block: MATCH_STRIP, or a smaller multiple of 64 that divides it
 };
 constexpr int MW2 = 4;                  // wavefronts per block of the packed sweep: fewer, longer diagonal ranges (less pipeline fill)
 
@@ -43,7 +44,7 @@ __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint
 #endif
 
 // the launches (lzss_match.hip); shmem2: k_match2's dynamic LDS for this window
-int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_strips, size_t shmem2);
+int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2);
 int lzss_launch_match_hash(Ctx &c, hipStream_t s, const HashArgs &h);
 
 }  // namespace rsn

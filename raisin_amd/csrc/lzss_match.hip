@@ -61,7 +61,9 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t W4 = a.DW * MW2 + 16;                      // lead-in of the staged region (+16: the high half of an odd DW reads one byte further)
     const uint32_t WUB = (a.W + 63) / 64 * 64;
-    const uint32_t RLEN = (MATCH_STRIP + WUB + W4 + 15) & ~15u;
+    const uint32_t STRIP = a.strip;                                   // positions of this block (r05: MATCH_STRIP, or less where the strips are few -- a block's
+                                                                      // time is (STRIP + W) / 64 position blocks in a row, and 64 blocks leave three CUs in four idle)
+    const uint32_t RLEN = (STRIP + WUB + W4 + 15) & ~15u;
     const uint32_t H = (a.DW + 1) / 2;                                // diagonals per half
     uint8_t *s_b = smem;
     uint32_t *s_carry = reinterpret_cast<uint32_t *>(smem + RLEN);    // [MW2][H] packed runs entering from the block above
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.only && !a.only[blockIdx.x]) return;
-    const long long b0 = (long long)blockIdx.x * MATCH_STRIP;
+    if (a.only && !a.only[(size_t)blockIdx.x * STRIP / MATCH_STRIP]) return;   // (the flags are per MATCH_STRIP positions)
+    const long long b0 = (long long)blockIdx.x * STRIP;
     const long long r0 = b0 - (long long)W4;
     for (uint32_t i = tid; i < RLEN; i += MW2 * 64) {
         const long long p = r0 + i;
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
     {   // Shortcut for W-periodic stretches: a match on diagonal W that fills the whole window (or reaches the end of the stream)
         // cannot be beaten -- L <= W, and W is the largest distance, i.e. the leftmost occurrence.  If that holds for every position
         // of the strip (no mismatch fc[q] != fc[q-W] anywhere in [b0, b0+STRIP+W)), the search is skipped.
-        const long long q_end = min(b0 + (long long)MATCH_STRIP + (long long)a.W - 1, (long long)a.E);
+        const long long q_end = min(b0 + (long long)STRIP + (long long)a.W - 1, (long long)a.E);
         bool ok = b0 >= (long long)a.W;
         if (ok) for (long long q = b0 + tid; q < q_end; q += MW2 * 64) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
         if (__syncthreads_and(ok)) {
-            for (long long p = b0 + tid; p < min(b0 + (long long)MATCH_STRIP, (long long)a.E); p += MW2 * 64) {
+            for (long long p = b0 + tid; p < min(b0 + (long long)STRIP, (long long)a.E); p += MW2 * 64) {
                 const uint32_t L = (uint32_t)min((long long)a.W, (long long)a.E - p);
                 a.keys[p] = (L << 16) | a.W;
             }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
     const uint32_t Hk_lo = min(H, DWk), Hk_hi = DWk > H ? DWk - H : 0; // valid local indices in each half
     const uint32_t nsteps = Hk_lo ? Hk_lo + 63 : 0;
     uint32_t *carry = s_carry + wv * H;
-    const int nPB = (int)((MATCH_STRIP + WUB) / 64);
+    const int nPB = (int)((STRIP + WUB) / 64);
 
     for (int pb = nPB - 1; pb >= 0; pb--) {
         const long long P0 = b0 + 64ll * pb;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
         uint32_t *comb = s_comb + (pb & 1) * (MW2 * 64);
         comb[wv * 64 + lane] = max(best2 & 0xFFFFu, best2 >> 16);
         __syncthreads();
-        if (wv == 0 && pb < MATCH_STRIP / 64 && p < (long long)a.E) {
+        if (wv == 0 && pb < (int)(STRIP / 64) && p < (long long)a.E) {
             uint32_t L = comb[lane];
 #pragma unroll
             for (int w = 1; w < MW2; w++) L = max(L, comb[w * 64 + lane]);
@@ -343,13 +345,13 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / HT)] = 1;
 }
 
-int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_strips, size_t shmem2) {
+int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2) {
     static thread_local size_t attr2_set = 0;
     if (shmem2 > attr2_set) {
         RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
         attr2_set = shmem2;
     }
-    RSN_LAUNCH("lzss_match", k_match2, dim3(n_strips), dim3(MW2 * 64), shmem2, s, m2);
+    RSN_LAUNCH("lzss_match", k_match2, dim3(n_blocks), dim3(MW2 * 64), shmem2, s, m2);
     return RSN_OK;
 }
 
