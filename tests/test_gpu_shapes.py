@@ -1,0 +1,64 @@
+"""GPU: no shape of input is out of line.  One MiB of many kinds of data through all four host-buffer calls: the round trip is what the
+oracle's decoder returns, and no call takes more than a bound that the slowest known shape (a period broken every 100 KB: 9 ms to
+LZSS-encode) meets five times over.  The shapes are the ones scripts/probes/size_sweep.py, periodic_decode.py and periodic_lzss.py found
+something with in round 5: periodic data that parses in a second phase (Huffman decode: 474 ms before k_dec_phase), a short period
+repeated (LZSS encode of 64 KiB: 9.1 ms before its stretches were placed by arithmetic), a period broken now and then."""
+import random
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 20
+BOUND_S = 0.05
+
+
+def _shapes():
+    rng = random.Random(5)
+    words = ["".join(rng.choice("etaoinshrdlucmfwypvbgkqjxz") for _ in range(rng.randint(1, 9))) for _ in range(3000)]
+    text = " ".join(rng.choice(words) for _ in range(N // 4)).encode()[:N]
+    yield "text", text
+    yield "zeros", bytes(N)
+    yield "random ascii", np.random.default_rng(1).integers(0, 128, size=N, dtype=np.uint8).tobytes()
+    yield "random bytes", np.random.default_rng(2).integers(0, 256, size=N, dtype=np.uint8).tobytes()
+    for p in (1, 2, 3, 7, 37, 100, 256, 1000, 3461, 4095, 4096, 4097, 5000, 20000):
+        unit = "".join(rng.choices("abcdefghijklmnopqrstuvwxyz ,.\n<>\\", k=p)).encode()
+        yield "period %d" % p, (unit * (N // p + 1))[:N]
+    for p in (37, 256, 1000):
+        unit = "".join(rng.choices("abcdefghijklmnopqrstuvwxyz ,.\n", k=p)).encode()
+        b = bytearray((unit * (N // p + 1))[:N])
+        at = 30000
+        while at < N:
+            b[at] = ord(rng.choice("ABCDEFG"))
+            at += rng.randint(20000, 200000)
+        yield "period %d, broken every 100 KB or so" % p, bytes(b)
+    for unit in (b'a\xe4\xb8\x96\xc3\xa8\xe6\x9c\xac\xe4\xb8\x96u\xc3\xb6uuu\xe6\x9c\xac\xc3\xa8\xe6\x9c\xac', "héllo wörld 世界 ".encode()):
+        yield "UTF-8 unit of %d bytes" % len(unit), (unit * (N // len(unit) + 1))[:N // len(unit) * len(unit)]
+    five = np.repeat(np.arange(63) + 48, [32] * 31 + [1] * 32)
+    yield "code lengths 5 and 10", np.random.default_rng(3).choice(five, size=N).astype(np.uint8).tobytes()
+    yield "text with noise sections", text[: N // 3] + np.random.default_rng(4).integers(0, 256, size=N // 3, dtype=np.uint8).tobytes() + text[: N // 3]
+
+
+@pytest.mark.parametrize("name,data", list(_shapes()), ids=[n for n, _ in _shapes()])
+def test_no_shape_is_out_of_line(oracle, name, data):
+    from raisin_amd import huffman, lz
+
+    def timed(fn, *a):
+        fn(*a)                                              # (warm: arenas, result blocks)
+        t0 = time.perf_counter()
+        r = fn(*a)
+        return r, time.perf_counter() - t0
+
+    c, t_he = timed(huffman.Compress, data)
+    d, t_hd = timed(huffman.Decompress, c)
+    assert d == oracle.huffman_decompress(c)                # (lossy where the reference is: bytes that are not UTF-8)
+    z, t_le = timed(lz.CompressAsync, data)
+    u, t_ld = timed(lz.Decompress, z)
+    assert u == data
+    times = {"huffman encode": t_he, "huffman decode": t_hd, "lzss encode": t_le, "lzss decode": t_ld}
+    import os
+    bound = BOUND_S * (10 if os.environ.get("RSN_LZSS_NO_FUSED_PARSE") or os.environ.get("RSN_LZSS_ALLPOS") else 1)   # (the suites under switches: every position's key)
+    slow = {k: round(v * 1e3, 2) for k, v in times.items() if v > bound}
+    assert not slow, "%s: %r ms" % (name, slow)
