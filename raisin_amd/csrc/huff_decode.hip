@@ -1143,14 +1143,13 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         // the fixing pass handed some block a different exit: more passes, the synchronisation alone, until nothing changes, then D2 + D3
         // again.  Two more passes settle what one did not; a stream that is still moving then is in more than one PHASE (periodic data,
         // a code whose lengths are all even): k_dec_phase settles it in a few launches, where the passes take one per block of the stretch.
-        bool by_phases = false;
         static const bool dbg_p = getenv("RSN_DEBUG") != nullptr;
         for (uint32_t pass = 2; ht->changed; pass++) {
             if (dbg_p) fprintf(stderr, "huffman decode: pass %u, still moving\n", pass);
             if (pass == 3) {
                 const int prc = phase_solve();
                 if (prc < 0) return prc;
-                if (prc == RSN_OK) { by_phases = true; break; }
+                if (prc == RSN_OK) break;
             }
             if (pass > n_blk + 2) return c.fail(RSN_ERR_DEVICE, "huffman: synchronisation did not converge");
             a.pass = (int)pass;
@@ -1167,7 +1166,6 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
                 break;
             }
         }
-        (void)by_phases;
         rc = offsets_and_bytes(); if (rc) return rc;
         RSN_HIP(hipStreamSynchronize(s));
     }

@@ -1998,17 +1998,6 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             rc = scan_u64(c, s, "lzss_scan", d_tbytes, d_toff, n_pt, d_ttot); if (rc) return rc;
             RSN_HIP(hipMemcpyAsync(h64, d_ttot, 32, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
-            static const bool dbg_tiles = getenv("RSN_DEBUG") != nullptr;
-            if (dbg_tiles && n_pt <= 160) {                                    // a short stream's tiles, one by one (diagnostics)
-                std::vector<TileChain> tcs(n_pt); std::vector<uint32_t> stp(n_pt), prd(n_pt, 0);
-                (void)hipMemcpy(tcs.data(), d_tchain, (size_t)n_pt * sizeof(TileChain), hipMemcpyDeviceToHost);
-                (void)hipMemcpy(stp.data(), d_step, (size_t)n_pt * 4, hipMemcpyDeviceToHost);
-                if (with_pred) (void)hipMemcpy(prd.data(), d_pred, (size_t)n_pt * 4, hipMemcpyDeviceToHost);
-                for (uint32_t k = 0; k < n_pt; k++)
-                    fprintf(stderr, "  tile %3u: walked %u pad %u entry %+7lld exit %+7lld step %5u pred %+lld%s\n", k, tcs[k].walked, tcs[k].pad, (long long)tcs[k].entry - (long long)k * PT,
-                            (long long)tcs[k].exit - (long long)(k + 1) * PT, stp[k], with_pred && prd[k] != 0xFFFFFFFFu ? (long long)prd[k] - (long long)k * PT : -1ll,
-                            k && tcs[k - 1].exit != tcs[k].entry ? "   <- does not join" : "");
-            }
             return RSN_OK;
         };
         rc = resolve(false, false); if (rc) return rc;
