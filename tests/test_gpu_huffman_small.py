@@ -194,3 +194,18 @@ def test_small_and_large_calls_interleave_on_one_thread(huff, oracle):
         assert huff.Compress(big) == want_big
         assert huff.Decompress(want_small) == small
         assert huff.Decompress(want_big) == big
+
+
+def test_a_header_that_promises_less_than_the_payload_holds(huff, oracle):
+    """the small-input decoder is offered a stream by its header's counts (at most 64 KiB of symbols); what the payload decodes to is
+    another matter -- more than a block's stage, more than 64 KiB: the kernel says so and the general decoder runs"""
+    import re
+    data = _text(21, 100000)
+    good = oracle.huffman_compress(data)
+    assert len(good) < 65536 + 2048
+    sep = good.index(b"\\\n")
+    halved = re.sub(rb"(\d+)\|", lambda m: str(max(1, int(m.group(1)) // 2)).encode() + b"|", good[:sep])
+    s = halved + good[sep:]
+    want = oracle.huffman_decompress(s)
+    assert len(want) > 65536
+    assert huff.Decompress(s) == want == _general_decompress(huff, s)
