@@ -427,11 +427,12 @@ def config1_and_host_api(torch, device, n, with_host_gib):
     if with_host_gib:
         # Host buffer in, library-owned host buffer out (what the cgo shim binds).  The figures are a plain C++ PROCESS's (what a cgo caller
         # is like; scripts/probes/host_call_probe.cpp on the same bytes, best of three warm calls), pipelined and with RSN_HOST_SERIAL=1;
-        # `python_process` is the same call through ctypes from this process, where two transfers in opposite directions share the
-        # link's one-way rate for a reason r05 did not find.
+        # `python_process` is the same call through ctypes from this process, which has imported torch and therefore runs librsn on
+        # the HIP runtime torch bundles (7.0.2 under the system runtime's SONAME): a download does not start there while an upload
+        # runs (scripts/probes/py_decode_torch_order.py).
         import subprocess
         ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, warm calls (pages mapped, arenas grown); PCIe included, never `value`; "
-                                  "encode_ms / decode_ms: a C process; python_process: this process through ctypes"}
+                                  "encode_ms / decode_ms: a C process; python_process: this process through ctypes (torch imported: its bundled HIP runtime)"}
         exe = "/tmp/rsn_host_call_probe_%d" % os.getpid()
         try:
             subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "scripts", "probes", "host_call_probe.cpp"),
