@@ -221,9 +221,12 @@ struct BitReader {
 };
 struct DecTab { const uint32_t *lut; const uint16_t *child; uint32_t K, end; };
 // the codeword at the reader's position: its byte; the reader moves behind it (past `end`: the caller's to notice)
-__device__ __forceinline__ uint32_t dec_one(BitReader &r, const DecTab &t) {
-    const uint32_t e = t.lut[(uint32_t)(r.buf >> (64 - t.K))];
-    if (!(e >> 31)) { r.skip(e >> 8); return e & 0xFF; }
+// (an entry of the table: one codeword or two, see the kernel's table walk)
+__device__ __forceinline__ uint32_t ent_len1(uint32_t e) { return (e >> 16) & 31u; }
+__device__ __forceinline__ uint32_t ent_len2(uint32_t e) { return (e >> 21) & 31u; }
+__device__ __forceinline__ bool ent_two(uint32_t e) { return (e >> 26) & 1u; }
+// a codeword longer than the table's K bits, from the internal node its first K bits lead to
+__device__ __forceinline__ uint32_t dec_long(BitReader &r, const DecTab &t, uint32_t e) {
     uint32_t node = e & 0xFFFF;
     r.skip(t.K);
     for (;;) {
@@ -243,19 +246,30 @@ __device__ __noinline__ uint32_t run_path(const uint32_t *pay, const uint32_t *l
     const DecTab tab{lut, child, K, end};
     BitReader r; r.pay = pay; r.seek(from);
     uint32_t c = 0;
-    while (r.pos < hi) { (void)dec_one(r, tab); c++; if (r.pos > end) break; }
+    while (r.pos < hi) {
+        const uint32_t e = lut[(uint32_t)(r.buf >> (64 - K))];
+        if (e >> 31) { (void)dec_long(r, tab, e); c++; }
+        else if (ent_two(e) && r.pos + ent_len1(e) < hi) { r.skip(ent_len2(e)); c += 2; }     // (the second one starts in this subsequence too)
+        else { r.skip(ent_len1(e)); c++; }
+        if (r.pos > end) break;
+    }
     return (r.pos > end ? OFF_BAD : r.pos - hi) << 24 | c;
 }
 // `count` codewords from `from`, their bytes to out[0 ..)
 __device__ __noinline__ void emit_path(const uint32_t *pay, const uint32_t *lut, const uint16_t *child, uint32_t K, uint32_t end, uint32_t from, uint32_t count, uint8_t *out) {
     const DecTab tab{lut, child, K, end};
     BitReader r; r.pay = pay; r.seek(from);
-    for (uint32_t i = 0; i < count; i++) out[i] = (uint8_t)dec_one(r, tab);
+    for (uint32_t i = 0; i < count;) {
+        const uint32_t e = lut[(uint32_t)(r.buf >> (64 - K))];
+        if (e >> 31) out[i++] = (uint8_t)dec_long(r, tab, e);
+        else if (ent_two(e) && i + 1 < count) { out[i] = (uint8_t)e; out[i + 1] = (uint8_t)(e >> 8); i += 2; r.skip(ent_len2(e)); }
+        else { out[i++] = (uint8_t)e; r.skip(ent_len1(e)); }
+    }
 }
 __device__ __forceinline__ uint32_t byte_of(uint32_t packed, uint32_t j) { return (packed >> (8 * j)) & 0xFF; }
 __global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
     __shared__ uint32_t s_pay[DEC_PAY_WORDS];                 // big-endian words of this block's part of the stream
-    __shared__ uint32_t s_lut[1u << DEC_K];                   // len << 8 | byte, or 0x80000000 | internal node reached after K bits
+    __shared__ uint32_t s_lut[1u << DEC_K];                   // byte | second byte << 8 | length << 16 | length of both << 21 | two << 26, or 0x80000000 | internal node reached after K bits
     __shared__ uint16_t s_child[256];
     __shared__ uint32_t s_st[DL], s_ex[DL], s_n[DL];          // per lane: its starts (offsets from its subsequence's first bit, a byte each), the exits that belong to them (offsets from the next subsequence's first bit), their number
     __shared__ uint32_t s_exmask;                             // ... the exits that occur among them, a bit each
@@ -278,23 +292,29 @@ __global__ __launch_bounds__(DT) void k_small_dec(SmallDecArgs a) {
         for (int k = 0; k < PER; k++) { const uint32_t i = tid + k * DT; v[k] = (i < n_words && wlo + i < a.pay_words) ? a.pay[wlo + i] : 0u; }
         if (tid < a.n_child) s_child[tid] = (uint16_t)ch;
         __syncthreads();
-        // window v of K bits: down the tree from the root, two windows a lane at a time (the steps depend on each other, the windows do not)
+        // window v of K bits: down the tree from the root, two windows a lane at a time (the steps depend on each other, the windows do
+        // not); a leaf met with bits to spare sends the walk back to the root for a SECOND codeword: an entry holds up to two
         constexpr int G = 2;
         for (uint32_t v0 = tid * G; v0 < (1u << a.K); v0 += DT * G) {
-            uint32_t node[G], ent[G];
+            uint32_t node[G], ent[G], got[G];
 #pragma unroll
-            for (int q = 0; q < G; q++) { node[q] = a.root; ent[q] = 0; }
+            for (int q = 0; q < G; q++) { node[q] = a.root; ent[q] = 0; got[q] = 0; }
             for (uint32_t d = 0; d < a.K; d++) {
 #pragma unroll
                 for (int q = 0; q < G; q++) {
-                    if (ent[q]) continue;
+                    if (got[q] == 2) continue;
                     const uint32_t bit = ((v0 + q) >> (a.K - 1 - d)) & 1;
                     node[q] = s_child[2 * node[q] + bit];
-                    if (node[q] & 0x8000) ent[q] = ((d + 1) << 8) | (node[q] & 0xFF);
+                    if (node[q] & 0x8000) {
+                        if (got[q] == 0) ent[q] = (node[q] & 0xFF) | (d + 1) << 16;                     // byte, length
+                        else ent[q] |= (node[q] & 0xFF) << 8 | (d + 1) << 21 | 1u << 26;             // second byte, length of both, "two"
+                        got[q]++;
+                        node[q] = a.root;
+                    }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < G; q++) if (v0 + q < (1u << a.K)) s_lut[v0 + q] = ent[q] ? ent[q] : (0x80000000u | node[q]);
+            for (int q = 0; q < G; q++) if (v0 + q < (1u << a.K)) s_lut[v0 + q] = got[q] ? ent[q] : (0x80000000u | node[q]);
         }
 #pragma unroll
         for (int k = 0; k < PER; k++) { const uint32_t i = tid + k * DT; if (i < n_words + 2) s_pay[i] = i < n_words ? __builtin_bswap32(v[k]) : 0u; }
