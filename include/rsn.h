@@ -16,7 +16,12 @@
  * Errors: the reference panics (check(e), index out of range); this library
  * returns a negative code and a thread-local message instead and never aborts.
  * The cgo shim turns a non-zero code back into panic() to keep engine behaviour
- * (engine.go:315-328 recovers it into a "failed" row).
+ * (engine.go:315-328 recovers it into a "failed" row).  "Never aborts" includes
+ * the C++ side's own failures: every entry point below runs inside a guard that
+ * turns std::bad_alloc / std::system_error / anything thrown into RSN_ERR_NOMEM
+ * or RSN_ERR_DEVICE, and the helper threads of the pipelined calls come from a
+ * pool that answers "none to be had" (the call then takes its serial form)
+ * instead of throwing -- csrc/rsn_helpers.h, tests/thread_fail_test.cpp.
  */
 #ifndef RSN_H
 #define RSN_H
@@ -59,7 +64,7 @@ RSN_API const char *rsn_version(void);
  * Safe at any time between calls; the next call re-allocates what it needs. */
 RSN_API void rsn_trim(void);
 RSN_API void rsn_free(void *p);           /* releases buffers returned through `out` below (only rsn_free may: they carry a
-                                     library header; large ones are recycled, RSN_HOST_POOL=0 disables that) */
+                                     library header; large ones are recycled for the next result) */
 
 /* ---- host-buffer entry points (what the cgo shim binds) ----------------
  * Input is borrowed for the duration of the call and never modified.  Output
@@ -91,7 +96,7 @@ RSN_API int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size
  * device + w) mod visible.  On each device chunk k+1's upload, chunk k's encode and chunk k-1's
  * download run at once.  Nothing is exchanged between devices.  Each outs[i] equals what
  * rsn_huffman_compress() returns for ins[i]; on any error every outs[i] is NULL.
- * (RSN_BATCH_WORKERS, RSN_BATCH_LANES, RSN_BATCH_KEEP_MIB: see rsn_api.hip / INTEGRATION.md.) */
+ * (RSN_BATCH_WORKERS, RSN_BATCH_KEEP_MIB: see rsn_api.hip / INTEGRATION.md.) */
 RSN_API int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens,
                                uint8_t **outs, size_t *out_lens);
 

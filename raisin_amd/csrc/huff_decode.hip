@@ -28,8 +28,9 @@
 // two (single + multi) is what lets seven blocks share a CU in the counting pass instead of four: the walks
 // are bound by the latency of their own dependent LDS reads, i.e. by how many wavefronts are there to hide it.
 #include <chrono>
-#include <thread>
+#include <optional>
 #include "codecs.h"
+#include "rsn_helpers.h"
 
 namespace rsn {
 
@@ -370,6 +371,11 @@ __global__ __launch_bounds__(DB) void k_dec_sync(DecArgs a, uint32_t n_blk) {
             if (!__syncthreads_or(changed)) break;
             if (round == SYNC_ROUNDS) { if (tid == 0) *a.stuck = 1; break; }   // (what the lanes hold is then not one parse: the host does not use it)
         }
+        // A lane that has just taken a new entry at the stuck break holds the OLD entry's exit and byte count: stored as they are, the emit
+        // pass that is queued before the host has read `stuck` would walk from the new entry and could write more bytes than the scan
+        // reserved for the lane -- past out_cap in the last block of an exact-fit buffer.  Such a lane stores "no entry, no
+        // bytes", which the emit pass skips; k_dec_phase rewrites all three arrays before anything is final.
+        if (live && !have) { e = BAD_POS; x = BAD_POS; nb = 0; }
         if (live) {
             const uint16_t new_exit = x == BAD_POS ? (uint16_t)BAD_REL : (uint16_t)(x - lim);
             // Another pass is needed only if some block hands its successor a different exit than before: a block that decoded
@@ -876,10 +882,10 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     constexpr int k_env = LUT_BITS_MAX;                                 // index bits of the first-level table, at most
     std::vector<uint32_t> lut, lut2; std::vector<int32_t> child;
     const bool prebuilt = tree.n_leaves > 4096;
-    std::thread table_builder;
-    if (prebuilt) table_builder = std::thread([&] { build_tables(tree, k_env, lut, child); build_second_level(child, k_env, false, lut, lut2); });
+    std::optional<SideJob> table_builder;                               // (a pooled helper, rsn_helpers.h; on this thread when none is to be had)
+    if (prebuilt) table_builder.emplace([&] { build_tables(tree, k_env, lut, child); build_second_level(child, k_env, false, lut, lut2); });
     const bool codes_ok = assign_codes(tree, codes, msg, false);
-    if (prebuilt) table_builder.join();
+    if (prebuilt) table_builder->finish();
     if (!codes_ok) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());
     const auto t3 = now();
     if (host_timing) fprintf(stderr, "huffman decode host: header of %zu bytes parsed in %.2f ms, tree %.2f ms, codes %.2f ms, %zu symbols\n", sep, ms(t0, t1), ms(t1, t2), ms(t2, t3), syms.size());

@@ -21,8 +21,9 @@
 #include <chrono>
 #include <cstddef>
 
-#include <thread>
+#include <optional>
 #include "codecs.h"
+#include "rsn_helpers.h"
 
 namespace rsn {
 
@@ -1023,13 +1024,13 @@ int huff_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     HuffTree tree; HuffCodes codes; std::string msg;
     // (rune alphabets of 10^5 symbols -- config 2b: 3 * 10^5 -- spend 2 ms on the header's decimal counts and 20 ms in the Go-exact
     //  heap: the header is written by a second thread meanwhile, from a copy of the table -- build_tree reorders its own)
-    std::thread hdr_writer;
     std::vector<HuffSym> by_rune;
-    if (sl.syms.size() > 4096) { by_rune = sl.syms; hdr_writer = std::thread([&] { emit_header(by_rune, hdr); }); }
+    std::optional<SideJob> hdr_writer;                                  // (a pooled helper, rsn_helpers.h; on this thread when none is to be had)
+    if (sl.syms.size() > 4096) { by_rune = sl.syms; hdr_writer.emplace([&] { emit_header(by_rune, hdr); }); }
     else emit_header(sl.syms, hdr);   // syms is ascending by rune here
     const auto t2 = now();
     const bool tree_ok = build_tree(sl.syms, tree, msg);
-    if (hdr_writer.joinable()) hdr_writer.join();
+    if (hdr_writer) hdr_writer->finish();
     if (!tree_ok) return c.fail(RSN_ERR_EMPTY, "%s", msg.c_str());
     const auto t3 = now();
     if (!assign_codes(tree, codes, msg, codes_out != nullptr)) return c.fail(RSN_ERR_LIMIT, "%s", msg.c_str());

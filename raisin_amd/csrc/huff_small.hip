@@ -610,9 +610,12 @@ int huff_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **o
     void *pp; rc = pinned_buf(c, PIN_BYTES, &pp); if (rc) return rc;
     uint8_t *pin = (uint8_t *)pp;
     void *dp; rc = dev_buf(c, 38, (DEC_BLOCKS * 32 + DEC_BLOCKS) * 4, &dp); if (rc) return rc;      // the blocks' maps and flags
-    static thread_local uint32_t seq = 0;                                        // a flag holds the number of the call that set it:
-    static thread_local void *seq_of = nullptr;                                  // nothing to clear between calls on the same buffer
-    if (seq_of != dp || ++seq == 0) { seq = 1; seq_of = dp; RSN_HIP(hipMemsetAsync(dp, 0, (DEC_BLOCKS * 32 + DEC_BLOCKS) * 4, s)); }
+    // A flag holds the number of the call that set it: nothing to clear between calls on the same ALLOCATION.  Keyed on the allocation's
+    // process-unique number, not its address (rsn_device_set / rsn_trim / the admission gate free the slot, and a later
+    // hipMalloc can hand the same address back with other contents -- a stale flag equal to the current number would pass for this call's).
+    static thread_local uint32_t seq = 0;
+    static thread_local unsigned long long seq_of = 0;
+    if (seq_of != c.bufs[38].gen || ++seq == 0) { seq = 1; seq_of = c.bufs[38].gen; RSN_HIP(hipMemsetAsync(dp, 0, (DEC_BLOCKS * 32 + DEC_BLOCKS) * 4, s)); }
     // ---- the tree as the kernel wants it (every block fills its lookup table from it)
     const int K = (int)std::min<unsigned>(codes.max_len, DEC_K);
     SmallDecArgs a{};

@@ -3,6 +3,7 @@
 // device-resident codecs; there is no CPU compute path.
 #include "codecs.h"
 #include "rsn_common.h"
+#include "rsn_helpers.h"
 
 #include <sys/mman.h>
 
@@ -202,6 +203,8 @@ int dev_buf(Ctx &c, int slot, size_t bytes, void **out) {
         }
         if (e != hipSuccess) { b.p = nullptr; return c.fail(RSN_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
         b.cap = want;
+        static std::atomic<unsigned long long> next_gen{0};
+        b.gen = ++next_gen;
         g_arena_bytes[c.device & 63] += want;
     }
     *out = b.p;
@@ -376,14 +379,18 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
         size_t uploaded = 0;                                              // bytes of the stream on the device
         std::vector<std::pair<size_t, size_t>> ready;                     // decoded ranges not yet asked for by the downloader
         size_t taken = 0; bool decoded_all = false, failed = false; std::string msg;
-        void fail(const char *m) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; msg = m; } cv.notify_all(); }
+        void fail(const char *m) noexcept { try { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; try { msg = m; } catch (...) {} } } catch (...) {} cv.notify_all(); }
     } P;
+    // what runs on a helper: an exception there (a vector that cannot grow) fails the pipe at once -- the other stages wait on P
+    auto stage = [&P](auto body) { return [&P, body] { guarded_call<int>([&] { body(); return 0; }, [&](int, const char *m) { P.fail(m); return 0; }); }; };
     const int device = c.device;
     static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     std::vector<char> in_pinned((n + PIECE - 1) / PIECE + 2, 0);         // the input's pieces that are registered (released below)
-    std::thread uploader([&] {
+    // Both helpers come from the pool (rsn_helpers.h): no thread and no stream is created once a first call has run, and "no thread to be
+    // had" is an answer, not an exception -- the caller then takes the serial call.
+    HelperPool::Handle uploader = HelperPool::run(device, stage([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
         hipStream_t su = ctx().own_stream;
         std::vector<char> &pinned = in_pinned;
@@ -399,8 +406,9 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
             P.cv.notify_all();
         }
         if (timing) { size_t np_ = 0; for (char x : pinned) np_ += x != 0; fprintf(stderr, "piped call: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
-    });
-    std::thread downloader([&] {
+    }));
+    if (!uploader) { result_free(res); return 1; }
+    HelperPool::Handle downloader = HelperPool::run(device, stage([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
         hipStream_t sd = ctx().own_stream;
         const size_t total_out = out_cap;
@@ -439,7 +447,15 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
         }
         if (timing) { size_t np_ = 0; for (size_t k = 0; k < next_pin; k++) np_ += pinned[k] != 0; fprintf(stderr, "piped call: %zu of %zu pieces of the result registered\n", np_, next_pin); }
         for (size_t k = 0; k < next_pin; k++) if (pinned[k]) (void)hipHostUnregister(res + cut(res, total_out, k));
-    });
+    }));
+    if (!downloader) {                                                    // (the uploader is at work on P and d_in: it ends before they do)
+        P.fail("no helper thread for the downloads");
+        HelperPool::wait(uploader);
+        (void)hipSetDevice(c.device);
+        for (size_t k = 0; k < in_pinned.size(); k++) if (in_pinned[k]) (void)hipHostUnregister((void *)(in + cut(in, n, k)));
+        result_free(res);
+        return 1;
+    }
     SliceStream st;
     st.slice_bytes = (size_t)64 << 20;
     st.need_in = [&](size_t bytes) { std::unique_lock<std::mutex> lk(P.mu); P.cv.wait(lk, [&] { return P.failed || P.uploaded >= std::min(bytes, n); }); return !P.failed; };
@@ -451,15 +467,16 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
         return true;
     };
     size_t got = 0;
-    rc = run(c, s, (const uint8_t *)d_in, (uint8_t *)d_out, out_cap, &got, &st);
-    if (rc != RSN_OK) P.fail(c.err.c_str());                              // (stops both threads)
+    // (an exception out of the codec -- a vector that cannot grow -- must not unwind this frame while the helpers work on it)
+    rc = guarded_call<int>([&] { return run(c, s, (const uint8_t *)d_in, (uint8_t *)d_out, out_cap, &got, &st); },
+                           [&](int code, const char *m) { try { c.err = m; } catch (...) {} return code; });
+    if (rc != RSN_OK) P.fail(c.err.c_str());                              // (stops both helpers)
     { std::lock_guard<std::mutex> lk(P.mu); P.decoded_all = true; }
     P.cv.notify_all();
-    uploader.join();
-    downloader.join();
+    HelperPool::wait(uploader);
+    HelperPool::wait(downloader);
     (void)hipSetDevice(c.device);
     for (size_t k = 0; k < in_pinned.size(); k++) if (in_pinned[k]) (void)hipHostUnregister((void *)(in + cut(in, n, k)));
-    trim_parked_excess(c.device);                                         // (the two threads have parked their contexts)
     if (timing) fprintf(stderr, "piped call: the codec returned %d (%s) at +%.2f ms\n", rc, rc > 0 || rc == RSN_OK ? "" : c.err.c_str(), since());
     if (rc == RSN_ERR_CAPACITY || rc == 1) { result_free(res); return 1; }   // more output than the caller allowed for, or not a stream for slices: the serial call
     if (rc != RSN_OK && P.failed && P.msg != c.err) { result_free(res); return c.fail(rc, "%s (%s)", std::string(c.err).c_str(), P.msg.c_str()); }
@@ -487,9 +504,9 @@ int dev_prologue(Ctx &c, void *stream, hipStream_t *s) {
 
 using namespace rsn;
 
-extern "C" {
+// (implementations; the extern "C" wrappers that guard them are at the end of the file)
 
-int rsn_device_set(int device) {
+static int rsn_device_set_impl(int device) {
     Ctx &c = ctx();
     if (device < 0) return c.fail(RSN_ERR_ARG, "negative device");
     if (c.inited && c.device != device) {
@@ -508,7 +525,7 @@ int rsn_device_set(int device) {
     return ctx_init(c);
 }
 
-int rsn_device_count(void) {
+static int rsn_device_count_impl(void) {
     int cnt = 0;
     hipError_t e = hipGetDeviceCount(&cnt);
     if (e != hipSuccess) return ctx().fail(RSN_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
@@ -518,7 +535,7 @@ int rsn_device_count(void) {
 const char *rsn_last_error(void) { return ctx().err.c_str(); }
 const char *rsn_version(void) { return "librsn 0.1 (gfx950)"; }
 
-void rsn_trim(void) {
+static void trim_own_context() {
     Ctx &c = ctx();
     if (c.inited && hipSetDevice(c.device) == hipSuccess) {
         (void)hipStreamSynchronize(c.own_stream);
@@ -526,6 +543,12 @@ void rsn_trim(void) {
         if (c.pinned) (void)hipHostFree(c.pinned);
         c.pinned = nullptr; c.pinned_cap = 0;
     }
+}
+
+static void rsn_trim_impl(void) {
+    Ctx &c = ctx();
+    trim_own_context();
+    HelperPool::on_idle(trim_own_context);                                // the idle helpers of the pipelined calls keep contexts of their own
     std::vector<Parked> parked;
     {
         std::lock_guard<std::mutex> lk(g_park_mu);
@@ -540,12 +563,12 @@ void rsn_trim(void) {
     }
     for (auto &pr : pool) { ((ResHdr *)pr.second)->magic = 0; free(pr.second); }
 }
-void rsn_free(void *p) { result_free(p); }
+static void rsn_free_impl(void *p) { result_free(p); }
 
 size_t rsn_huffman_compress_bound(size_t n) { return huff_compress_bound(n); }
 size_t rsn_lzss_compress_bound(size_t n) { return lzss_compress_bound(n); }
 
-int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+static int rsn_huffman_compress_dev_impl(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if (!d_in || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
     if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
@@ -553,7 +576,7 @@ int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out
     return huff_encode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n, nullptr, nullptr);
 }
 
-int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+static int rsn_huffman_decompress_dev_impl(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if (!d_in || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
     if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
@@ -561,7 +584,7 @@ int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t o
     return huff_decode_dev(c, s, (const uint8_t *)d_in, n, (uint8_t *)d_out, out_cap, out_n);
 }
 
-int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+static int rsn_lzss_compress_dev_impl(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if ((!d_in && n) || !d_out || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
     if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
@@ -569,7 +592,7 @@ int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_ou
     return lzss_encode_dev(c, s, (const uint8_t *)d_in, n, window, (uint8_t *)d_out, out_cap, out_n);
 }
 
-int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
+static int rsn_lzss_decompress_dev_impl(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) {
     Ctx &c = ctx(); hipStream_t s;
     if ((!d_in && n) || !out_n) return c.fail(RSN_ERR_ARG, "null argument");
     if (ranges_overlap(d_in, n, d_out, out_cap)) return c.fail(RSN_ERR_ARG, "input and output ranges overlap");
@@ -595,7 +618,7 @@ static int small_result(Ctx &c, int rc, const uint8_t *p, size_t got, uint8_t **
     return RSN_OK;
 }
 
-int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+static int rsn_huffman_compress_impl(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     if (n == 0) return ctx().fail(RSN_ERR_EMPTY, "huffman: empty input (reference panics in heap.Pop, huffman.go:102)");
     if (in && out && out_n && n <= 65536) {                              // (the general path for the same bytes: the device-pointer entry points, tests/test_gpu_huffman_small.py)
         Ctx &c = ctx(); const uint8_t *p = nullptr; size_t got = 0;
@@ -650,7 +673,7 @@ static int huffman_decompress_piped(const uint8_t *in, size_t n, uint8_t **out, 
                       });
 }
 
-int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+static int rsn_huffman_decompress_impl(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     Ctx &c = ctx();
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
@@ -667,7 +690,7 @@ int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *o
     return huffman_decompress_serial(in, n, out, out_n);
 }
 
-int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+static int rsn_lzss_compress_impl(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
     // From 128 MiB up, with the engine's kind of window: the pipeline (piped_call) -- sections of a quarter of the input (at most 256 MiB),
     // each encoded as soon as its bytes are up, its tokens on their way down while the next is encoded.  The upload (19 ms per GiB) and the
     // download (12) disappear under the encoder's 31; what does not: the first section's upload and the last one's download.  For inputs in
@@ -692,7 +715,7 @@ int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out
                      });
 }
 
-int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+static int rsn_lzss_compress_legacy_impl(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
     Ctx &c = ctx();
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
@@ -712,7 +735,7 @@ int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_
     return RSN_OK;
 }
 
-int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+static int rsn_lzss_decompress_impl(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
     // (the decoder asks for 4 bytes per escaped byte from 64 MiB of them up, lzss_decode.hip: stated for an expansion of two -- text is 1.5;
     //  a stream that expands further decodes inside this admission all the same)
     return host_call(in, n, out, out_n, 8 * n + (1 << 16), n < ((size_t)32 << 20) ? 0 : 8 * n,
@@ -733,7 +756,6 @@ int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_
 //   RSN_BATCH_DEVICES=<d>|all  use up to d devices, starting at the caller's (default 1: the caller's device only)
 //   RSN_BATCH_WORKERS=<w>  number of pipelines (default: one per device used); more workers than devices share
 //                          devices round-robin -- how the split is exercised on a one-GPU box
-//   RSN_BATCH_LANES=1      no pipeline: each worker is a serial loop of rsn_huffman_compress calls (A/B; any other value = pipeline)
 //   RSN_BATCH_KEEP_MIB=<m> ring buffers above m MiB per worker (default 1024) are released when the batch ends instead of
 //                          staying with the worker's (parked) context for the next batch
 namespace {
@@ -744,7 +766,7 @@ struct BatchPipe {
     int rc = RSN_OK; std::string msg;
     void *d_in[RING] = {}, *d_out[RING] = {}, *d_tmp[RING] = {};
     size_t got[RING] = {};
-    void fail(int code, const char *m) { std::lock_guard<std::mutex> lk(mu); if (rc == RSN_OK) { rc = code; msg = m; } cv.notify_all(); }
+    void fail(int code, const char *m) noexcept { try { std::lock_guard<std::mutex> lk(mu); if (rc == RSN_OK) { rc = code; try { msg = m; } catch (...) {} } } catch (...) {} cv.notify_all(); }
     // waits until `counter` has passed `want` chunks; false when another stage failed
     bool wait(const size_t &counter, size_t want) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return rc != RSN_OK || counter >= want; }); return rc == RSN_OK; }
     void done(size_t &counter) { { std::lock_guard<std::mutex> lk(mu); counter++; } cv.notify_all(); }
@@ -755,14 +777,16 @@ struct BatchPipe {
 static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
     const size_t m = idx.size();
     if (m == 0) return RSN_OK;
-    if (m < 2) {
+    auto one_by_one = [&] {                                              // no pipeline: a single chunk, or no helper threads to be had
         for (size_t j = 0; j < m; j++) {
             const size_t i = idx[j];
+            if (outs[i]) { rsn_free(outs[i]); outs[i] = nullptr; out_lens[i] = 0; }
             const int rc = rsn_huffman_compress(ins[i], lens[i], &outs[i], &out_lens[i]);
             if (rc != RSN_OK) return rc;
         }
-        return RSN_OK;
-    }
+        return (int)RSN_OK;
+    };
+    if (m < 2) return one_by_one();
     size_t max_len = 0;
     for (size_t i : idx) max_len = std::max(max_len, lens[i]);
     BatchPipe P;
@@ -775,7 +799,8 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
     static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
     auto stamp = [] { return fmod(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), 100000.0); };
 
-    std::thread encoder([&] {
+    auto stage = [&P](auto body) { return [&P, body] { guarded_call<int>([&] { body(); return 0; }, [&](int code, const char *msg) { P.fail(code, msg); return 0; }); }; };
+    HelperPool::Handle encoder = HelperPool::run(device, stage([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(RSN_ERR_DEVICE, rsn_last_error()); return; }
         Ctx &ce = ctx(); hipStream_t s = ce.own_stream;
         for (size_t j = 0; j < m; j++) {
@@ -794,8 +819,9 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
             if (timing) fprintf(stderr, "batch dev %d chunk %zu encoded at %.2f ms\n", device, i, stamp());
             P.done(P.encoded);
         }
-    });
-    std::thread downloader([&] {
+    }));
+    if (!encoder) return one_by_one();
+    HelperPool::Handle downloader = HelperPool::run(device, stage([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(RSN_ERR_DEVICE, rsn_last_error()); return; }
         hipStream_t s = ctx().own_stream;
         for (size_t j = 0; j < m; j++) {
@@ -813,7 +839,12 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
             if (timing) fprintf(stderr, "batch dev %d chunk %zu down at %.2f ms\n", device, i, stamp());
             P.done(P.downloaded);
         }
-    });
+    }));
+    if (!downloader) {                                                    // (the encoder waits for the first upload: told to stop, it ends)
+        P.fail(RSN_ERR_NOMEM, "no helper thread");
+        HelperPool::wait(encoder);
+        return one_by_one();
+    }
     // this thread uploads
     for (size_t j = 0; j < m; j++) {
         if (j >= BatchPipe::RING && !P.wait(P.downloaded, j + 1 - BatchPipe::RING)) break;   // the ring slot is free once its segment is down
@@ -827,8 +858,8 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
         if (timing) fprintf(stderr, "batch dev %d chunk %zu up at %.2f ms\n", device, i, stamp());
         P.done(P.uploaded);
     }
-    encoder.join();
-    downloader.join();
+    HelperPool::wait(encoder);
+    HelperPool::wait(downloader);
     for (int r = 0; r < BatchPipe::RING; r++) if (P.d_tmp[r]) (void)hipFree(P.d_tmp[r]);
     if ((in_cap + out_cap) * BatchPipe::RING > ((size_t)std::max(0, env_int("RSN_BATCH_KEEP_MIB", 1024)) << 20))
         for (int k = 28; k < 28 + 2 * BatchPipe::RING; k++) { if (c.bufs[k].p) { (void)hipFree(c.bufs[k].p); scratch_forget(c, c.bufs[k].cap); } c.bufs[k].p = nullptr; c.bufs[k].cap = 0; }
@@ -837,7 +868,7 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
 }
 }  // namespace
 
-int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+static int rsn_huffman_compress_batch_impl(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
     Ctx &c = ctx();
     if (!ins || !lens || !outs || !out_lens) return c.fail(RSN_ERR_ARG, "null argument");
     for (size_t i = 0; i < n_chunks; i++) { outs[i] = nullptr; out_lens[i] = 0; }
@@ -868,12 +899,11 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
     // chunk k -> worker k mod G; worker w -> device (caller's + w mod n_dev) mod visible
     std::vector<int> rcs(n_workers, RSN_OK);
     std::vector<std::string> msgs(n_workers);
-    std::vector<std::thread> workers;
+    std::vector<HelperPool::Handle> workers(n_workers);
     const int base = c.device;
-    for (size_t w = 0; w < n_workers; w++)
-        workers.emplace_back([&, w] {
-            const int dev = (base + (int)(w % (size_t)n_dev)) % visible;
-            int rc = rsn_device_set(dev);
+    auto share = [&](size_t w, bool own_thread) {                         // worker w's chunks; on the caller's thread they stay on the caller's device
+        guarded_call<int>([&] {
+            int rc = own_thread ? rsn_device_set((base + (int)(w % (size_t)n_dev)) % visible) : RSN_OK;
             if (rc == RSN_OK) {
                 std::vector<size_t> idx;
                 for (size_t k = w; k < n_chunks; k += n_workers) idx.push_back(k);
@@ -881,8 +911,12 @@ int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const
             }
             rcs[w] = rc;
             if (rc != RSN_OK) msgs[w] = rsn_last_error();
-        });
-    for (auto &t : workers) t.join();
+            return 0;
+        }, [&](int code, const char *m) { rcs[w] = code; try { msgs[w] = m; } catch (...) {} return 0; });
+    };
+    for (size_t w = 0; w < n_workers; w++) workers[w] = HelperPool::run((base + (int)(w % (size_t)n_dev)) % visible, [&share, w] { share(w, true); });
+    for (size_t w = 0; w < n_workers; w++) if (!workers[w]) share(w, false);   // no thread to be had for that worker: its chunks on this one
+    for (auto &t : workers) HelperPool::wait(t);
     (void)hipSetDevice(c.device);
     for (size_t w = 0; w < n_workers; w++) if (rcs[w] != RSN_OK) return undo(rcs[w], msgs[w].c_str());
     return RSN_OK;
@@ -902,7 +936,7 @@ struct ShardSync {
     size_t arrived = 0, generation = 0, parties;
     int rc = RSN_OK; std::string msg;
     explicit ShardSync(size_t p) : parties(p) {}
-    void fail(int code, const char *m) { std::lock_guard<std::mutex> lk(mu); if (rc == RSN_OK) { rc = code; msg = m; } cv.notify_all(); }
+    void fail(int code, const char *m) noexcept { try { std::lock_guard<std::mutex> lk(mu); if (rc == RSN_OK) { rc = code; try { msg = m; } catch (...) {} } } catch (...) {} cv.notify_all(); }
     // all parties meet; `last` runs on the last one to arrive, before the others go on.  false: somebody failed
     bool meet(const std::function<void()> &last) {
         std::unique_lock<std::mutex> lk(mu);
@@ -915,7 +949,7 @@ struct ShardSync {
 };
 }  // namespace
 
-int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_t **out, size_t *out_n) {
+static int rsn_huffman_compress_sharded_impl(const uint8_t *in, size_t n, int shards, uint8_t **out, size_t *out_n) {
     Ctx &c = ctx();
     if (!out || !out_n || (!in && n)) return c.fail(RSN_ERR_ARG, "null argument");
     *out = nullptr; *out_n = 0;
@@ -1018,16 +1052,17 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
         if (e != hipSuccess) sync.fail(RSN_ERR_DEVICE, hipGetErrorString(e));
     };
 
-    std::vector<std::thread> threads;
-    try {
-        for (size_t w = 1; w < S; w++) threads.emplace_back(worker, w);
-    } catch (const std::exception &ex) {                                  // std::system_error must not leave an extern "C" entry point: the workers that did start stop at the barrier
-        sync.fail(RSN_ERR_NOMEM, (std::string("huffman: starting a slice's thread failed: ") + ex.what()).c_str());
+    // a slice whose thread cannot be had, or whose worker throws, fails the call: the workers that did start stop at the barrier
+    auto safely = [&](size_t w) { guarded_call<int>([&] { worker(w); return 0; }, [&](int code, const char *m) { sync.fail(code, m); return 0; }); };
+    std::vector<HelperPool::Handle> threads;
+    threads.reserve(S);
+    for (size_t w = 1; w < S; w++) {
+        threads.push_back(HelperPool::run((base_dev + (int)(w % (size_t)n_dev)) % visible, [&safely, w] { safely(w); }));
+        if (!threads.back()) { sync.fail(RSN_ERR_NOMEM, "huffman: no helper thread for a slice of the sharded stream"); break; }
     }
-    worker(0);                                                            // the caller is worker 0, on its own context
-    for (auto &t : threads) t.join();
+    safely(0);                                                            // the caller is worker 0, on its own context
+    for (auto &t : threads) HelperPool::wait(t);
     (void)hipSetDevice(c.device);
-    trim_parked_excess(c.device);                                         // the workers have parked their contexts: no more of them than the limit stay
     if (sync.rc != RSN_OK) { if (res) result_free(res); return c.fail(sync.rc, "%s", sync.msg.c_str()); }
     for (auto &x : sl) if (x.has) { res[x.first] = 0; res[x.last] = 0; }
     for (auto &x : sl) if (x.has) { res[x.first] |= x.edge[0]; if (x.last != x.first) res[x.last] |= x.edge[1]; }
@@ -1035,13 +1070,13 @@ int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_
     return RSN_OK;
 }
 
-void rsn_prof_enable(int on) { ctx().prof = on != 0; }
-void rsn_prof_reset(void) {
+static void rsn_prof_enable_impl(int on) { ctx().prof = on != 0; }
+static void rsn_prof_reset_impl(void) {
     Ctx &c = ctx();
     prof_collect(c);
     for (auto &s : c.slots) { s.launches = 0; s.total_ms = 0; }
 }
-int rsn_prof_get(rsn_prof_entry *entries, int cap) {
+static int rsn_prof_get_impl(rsn_prof_entry *entries, int cap) {
     Ctx &c = ctx();
     prof_collect(c);
     int k = 0;
@@ -1057,7 +1092,7 @@ int rsn_prof_get(rsn_prof_entry *entries, int cap) {
     return k;
 }
 
-int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs, uint64_t *codes, uint8_t *lens, size_t cap) {
+static int64_t rsn_huffman_table_impl(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs, uint64_t *codes, uint8_t *lens, size_t cap) {
     Ctx &c = ctx();
     if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input");
     int rc = ctx_init(c); if (rc) return rc;
@@ -1075,7 +1110,7 @@ int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t
     return (int64_t)hc.dfs.size();
 }
 
-int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms, uint32_t *out_runes, uint64_t *out_codes,
+static int64_t rsn_huffman_plan_impl(const uint32_t *runes, const uint64_t *counts, size_t n_syms, uint32_t *out_runes, uint64_t *out_codes,
                          uint8_t *out_lens, uint8_t *header, size_t header_cap, size_t *header_len) {
     Ctx &c = ctx();
     std::vector<HuffSym> syms(n_syms);
@@ -1095,7 +1130,7 @@ int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n
     return (int64_t)hc.dfs.size();
 }
 
-int64_t rsn_huffman_slice_cuts(const uint8_t *in, size_t n, int shards, size_t *cuts, size_t cap) {
+static int64_t rsn_huffman_slice_cuts_impl(const uint8_t *in, size_t n, int shards, size_t *cuts, size_t cap) {
     Ctx &c = ctx();
     if ((!in && n) || !cuts) return c.fail(RSN_ERR_ARG, "null argument");
     if (n == 0) return c.fail(RSN_ERR_EMPTY, "huffman: empty input");
@@ -1106,12 +1141,62 @@ int64_t rsn_huffman_slice_cuts(const uint8_t *in, size_t n, int shards, size_t *
     return (int64_t)cut.size() - 1;
 }
 
-int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap) {
+static int64_t rsn_huffman_parse_header_impl(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap) {
     Ctx &c = ctx();
     std::vector<HuffSym> syms; std::string msg;
     if (!parse_header(header, n, syms, msg)) return c.fail(RSN_ERR_FORMAT, "%s", msg.c_str());
     for (size_t i = 0; i < syms.size() && i < cap; i++) { runes[i] = syms[i].rune; counts[i] = syms[i].freq; }
     return (int64_t)syms.size();
 }
+
+
+// ---- the entry points of rsn.h: each runs its implementation inside guarded_call (rsn_helpers.h) -- a std::bad_alloc, a
+// std::system_error or anything else thrown on this side becomes a negative code and a message, never std::terminate in the host
+// (engine.go:315-328 can recover a panic the shim raises from a code; nothing recovers a dead process).  A host-buffer call that
+// ends that way hands out nothing: *out stays NULL.
+namespace {
+int boundary_error(int code, const char *m) noexcept { try { ctx().err = m; } catch (...) {} return code; }
+}  // namespace
+
+extern "C" {
+int rsn_device_set(int device) { return guarded_call<int>([&] { return rsn_device_set_impl(device); }, boundary_error); }
+int rsn_device_count(void) { return guarded_call<int>([&] { return rsn_device_count_impl(); }, boundary_error); }
+void rsn_trim(void) { guarded_call<int>([&] { rsn_trim_impl(); return 0; }, boundary_error); }
+void rsn_free(void *p) { guarded_call<int>([&] { rsn_free_impl(p); return 0; }, boundary_error); }
+int rsn_huffman_compress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) { return guarded_call<int>([&] { return rsn_huffman_compress_dev_impl(d_in, n, d_out, out_cap, out_n, stream); }, boundary_error); }
+int rsn_huffman_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) { return guarded_call<int>([&] { return rsn_huffman_decompress_dev_impl(d_in, n, d_out, out_cap, out_n, stream); }, boundary_error); }
+int rsn_lzss_compress_dev(const void *d_in, size_t n, int64_t window, void *d_out, size_t out_cap, size_t *out_n, void *stream) { return guarded_call<int>([&] { return rsn_lzss_compress_dev_impl(d_in, n, window, d_out, out_cap, out_n, stream); }, boundary_error); }
+int rsn_lzss_decompress_dev(const void *d_in, size_t n, void *d_out, size_t out_cap, size_t *out_n, void *stream) { return guarded_call<int>([&] { return rsn_lzss_decompress_dev_impl(d_in, n, d_out, out_cap, out_n, stream); }, boundary_error); }
+int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_huffman_compress_impl(in, n, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+int rsn_huffman_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_huffman_decompress_impl(in, n, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+int rsn_lzss_compress(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_lzss_compress_impl(in, n, window, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+int rsn_lzss_compress_legacy(const uint8_t *in, size_t n, int64_t window, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_lzss_compress_legacy_impl(in, n, window, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+int rsn_lzss_decompress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_lzss_decompress_impl(in, n, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+int rsn_huffman_compress_batch(size_t n_chunks, const uint8_t *const *ins, const size_t *lens, uint8_t **outs, size_t *out_lens) {
+    return guarded_call<int>([&] { return rsn_huffman_compress_batch_impl(n_chunks, ins, lens, outs, out_lens); }, [&](int code, const char *m) {
+        if (outs && out_lens) for (size_t k = 0; k < n_chunks; k++) { if (outs[k]) result_free(outs[k]); outs[k] = nullptr; out_lens[k] = 0; }
+        return boundary_error(code, m);
+    });
+}
+int rsn_huffman_compress_sharded(const uint8_t *in, size_t n, int shards, uint8_t **out, size_t *out_n) {
+    return guarded_call<int>([&] { return rsn_huffman_compress_sharded_impl(in, n, shards, out, out_n); }, [&](int code, const char *m) { if (out && *out) { result_free(*out); *out = nullptr; } if (out_n) *out_n = 0; return boundary_error(code, m); });
+}
+void rsn_prof_enable(int on) { guarded_call<int>([&] { rsn_prof_enable_impl(on); return 0; }, boundary_error); }
+void rsn_prof_reset(void) { guarded_call<int>([&] { rsn_prof_reset_impl(); return 0; }, boundary_error); }
+int rsn_prof_get(rsn_prof_entry *entries, int cap) { return guarded_call<int>([&] { return rsn_prof_get_impl(entries, cap); }, boundary_error); }
+int64_t rsn_huffman_table(const uint8_t *in, size_t n, uint32_t *runes, uint64_t *freqs, uint64_t *codes, uint8_t *lens, size_t cap) { return guarded_call<int64_t>([&] { return rsn_huffman_table_impl(in, n, runes, freqs, codes, lens, cap); }, boundary_error); }
+int64_t rsn_huffman_plan(const uint32_t *runes, const uint64_t *counts, size_t n_syms, uint32_t *out_runes, uint64_t *out_codes, uint8_t *out_lens, uint8_t *header, size_t header_cap, size_t *header_len) { return guarded_call<int64_t>([&] { return rsn_huffman_plan_impl(runes, counts, n_syms, out_runes, out_codes, out_lens, header, header_cap, header_len); }, boundary_error); }
+int64_t rsn_huffman_slice_cuts(const uint8_t *in, size_t n, int shards, size_t *cuts, size_t cap) { return guarded_call<int64_t>([&] { return rsn_huffman_slice_cuts_impl(in, n, shards, cuts, cap); }, boundary_error); }
+int64_t rsn_huffman_parse_header(const uint8_t *header, size_t n, uint32_t *runes, uint64_t *counts, size_t cap) { return guarded_call<int64_t>([&] { return rsn_huffman_parse_header_impl(header, n, runes, counts, cap); }, boundary_error); }
 
 }  // extern "C"

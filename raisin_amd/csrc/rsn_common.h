@@ -35,7 +35,7 @@ struct Ctx {
     std::vector<ProfSlot> slots;
     std::vector<hipEvent_t> free_events;
 
-    struct Buf { void *p = nullptr; size_t cap = 0; };
+    struct Buf { void *p = nullptr; size_t cap = 0; unsigned long long gen = 0; };   // gen: process-unique number of this allocation (dev_buf) -- an address can come back with other contents
     enum { N_BUFS = 39 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words; 35: k_esc_try's block flags; 36: an LZSS section's stream (encoder: the aligned copy; decoder: the escaped bytes in front + the section's tokens); 37, 38: the small-input Huffman path's device copy / its decoder's block maps
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;

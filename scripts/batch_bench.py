@@ -1,4 +1,4 @@
-"""rsn_huffman_compress_batch on 8 x 256 MiB host buffers: the upload / encode / download pipeline vs the serial loop (run twice: RSN_BATCH_LANES=1)."""
+"""rsn_huffman_compress_batch on 8 x 256 MiB host buffers: the upload / encode / download pipeline, and the same chunks as a loop of single calls."""
 import ctypes
 import os
 import sys
@@ -23,4 +23,12 @@ for rep in range(3):
     t = time.perf_counter() - t0
     for i in range(k):
         L.rsn_free(outs[i])
-    print("%s batch of %d x %d MiB: %.1f ms (%.2f GB/s)" % ("serial loop" if os.environ.get("RSN_BATCH_LANES") == "1" else "pipelined", k, n >> 20, t * 1e3, k * n / t / 1e9))
+    print("pipelined batch of %d x %d MiB: %.1f ms (%.2f GB/s)" % (k, n >> 20, t * 1e3, k * n / t / 1e9))
+one, one_n = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t()
+for rep in range(3):
+    t0 = time.perf_counter()
+    for i in range(k):
+        _lib.check(L.rsn_huffman_compress(ins[i], n, ctypes.byref(one), ctypes.byref(one_n)))
+        L.rsn_free(one)
+    t = time.perf_counter() - t0
+    print("loop of single calls, %d x %d MiB: %.1f ms (%.2f GB/s)" % (k, n >> 20, t * 1e3, k * n / t / 1e9))

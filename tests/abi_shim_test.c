@@ -8,8 +8,14 @@
  *   engine:   eight goroutines = eight OS threads calling concurrently (engine.go:235-244), each through its own
  *             per-thread context, with results that must not depend on the interleaving.
  * Exit code 0 = every check passed.  `abi_shim_test nodev` runs only the part that needs no device (symbols link,
- * the host-only entry points work, device entry points fail cleanly with RSN_ERR_DEVICE).
+ * the host-only entry points work, device entry points fail cleanly with RSN_ERR_DEVICE, an allocation that cannot be had is a
+ * code and not an abort).  `abi_shim_test threadfail` (under LD_PRELOAD=pthread_fail_shim.so, on a GPU): the calls that use helper
+ * threads -- the pipelined host calls, the batch, the sharded stream, the side jobs of large alphabets -- while the system refuses
+ * every new thread: each returns its bytes by its serial form or a negative code, none ends the process (engine.go:315-328 recovers
+ * a panic; nothing recovers std::terminate).
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,8 +77,52 @@ static void *worker(void *p) {                               /* one goroutine of
     return NULL;
 }
 
+/* every call that asks the library for helper threads, once; `refuse` = the system hands out no thread meanwhile */
+static void helper_thread_calls(void (*fail_threads)(int), int refuse, uint8_t **keep, size_t *keep_n) {
+    int rc; size_t n;
+    const size_t big = (size_t)160 << 20;
+    uint8_t *text = make_text(big, 99u);
+    /* a stream large enough for the pipelined decode (>= 32 MiB), produced with threads available */
+    size_t cn; uint8_t *c = rsn_call(rsn_huffman_compress, text, (size_t)48 << 20, &cn, &rc); CHECK(rc == 0 && cn > ((size_t)32 << 20));
+    fail_threads(refuse);
+    uint8_t *d = rsn_call(rsn_huffman_decompress, c, cn, &n, &rc);               /* piped_call -> no helper -> the serial call */
+    CHECK(rc == 0 && n == ((size_t)48 << 20) && memcmp(d, text, n) == 0); free(d);
+    uint8_t *l = rsn_call(lz_c, text, big, &n, &rc);                               /* the sectioned encode (>= 128 MiB) -> the serial call */
+    CHECK(rc == 0 && n > 0 && n < big);
+    if (keep[0]) CHECK(n == keep_n[0] && memcmp(l, keep[0], n) == 0); else { keep[0] = l; keep_n[0] = n; l = NULL; }
+    free(l);
+    enum { NC = 4 };
+    const uint8_t *ins[NC]; size_t lens[NC]; uint8_t *outs[NC]; size_t out_lens[NC];
+    for (int i = 0; i < NC; i++) { ins[i] = text + ((size_t)i << 20); lens[i] = 700000 + 1111 * (size_t)i; }
+    CHECK(rsn_huffman_compress_batch(NC, ins, lens, outs, out_lens) == 0);       /* no pipeline: chunk after chunk */
+    for (int i = 0; i < NC; i++) {
+        size_t sn; uint8_t *single = rsn_call(rsn_huffman_compress, ins[i], lens[i], &sn, &rc);
+        CHECK(rc == 0 && sn == out_lens[i] && memcmp(single, outs[i], sn) == 0);
+        free(single); rsn_free(outs[i]);
+    }
+    /* one stream from four slices: every slice but the caller's needs a thread -- refused: a code and a message, *out NULL */
+    uint8_t *so = (uint8_t *)1; size_t son = 1;
+    rc = rsn_huffman_compress_sharded(text, (size_t)8 << 20, 4, &so, &son);
+    if (refuse) CHECK(rc == RSN_ERR_NOMEM && so == NULL && son == 0 && strstr(rsn_last_error(), "helper"));
+    else { CHECK(rc == 0 && so != NULL); rsn_free(so); }
+    /* 20 000 distinct runes: the header's text and the decoder's tables are side jobs -- on the caller's thread when refused */
+    {
+        enum { NR = 20000 };
+        uint8_t *wide = malloc(6 * NR);
+        for (int i = 0; i < 2 * NR; i++) { const unsigned r = 0x800u + (unsigned)(i % NR); wide[3 * i] = 0xE0 | (r >> 12); wide[3 * i + 1] = 0x80 | ((r >> 6) & 63); wide[3 * i + 2] = 0x80 | (r & 63); }
+        size_t wn; uint8_t *w = rsn_call(rsn_huffman_compress, wide, 6 * NR, &wn, &rc); CHECK(rc == 0);
+        if (keep[1]) CHECK(wn == keep_n[1] && memcmp(w, keep[1], wn) == 0);
+        size_t bn; uint8_t *b = rsn_call(rsn_huffman_decompress, w, wn, &bn, &rc); CHECK(rc == 0 && bn == 6 * NR && memcmp(b, wide, bn) == 0);
+        if (!keep[1]) { keep[1] = w; keep_n[1] = wn; w = NULL; }
+        free(w); free(b); free(wide);
+    }
+    fail_threads(0);
+    free(c); free(text);
+}
+
 int main(int argc, char **argv) {
     const int nodev = argc > 1 && strcmp(argv[1], "nodev") == 0;
+    const int threadfail = argc > 1 && strcmp(argv[1], "threadfail") == 0;
     int rc; size_t n;
     CHECK(strlen(rsn_version()) > 0);
     /* host-only entry point: README.md:165's 21-byte answer of the legacy encoder, no device needed */
@@ -90,6 +140,25 @@ int main(int argc, char **argv) {
             uint8_t *x = rsn_call(lz_legacy, zeros, 100, &n, &rc); CHECK(x != NULL && rc == 0); free(x);   /* the next call on the thread is unaffected */
         }
         free(zeros);
+    }
+    /* an allocation the host cannot make is RSN_ERR_NOMEM with this thread's message, not an exception through the C boundary
+     * (2^60 symbols: the table's vector refuses before it reads a single one) */
+    CHECK(rsn_huffman_plan(NULL, NULL, (size_t)1 << 60, NULL, NULL, NULL, NULL, 0, NULL) == RSN_ERR_NOMEM && strlen(rsn_last_error()) > 0);
+    if (threadfail) {
+        void (*fail_threads)(int) = (void (*)(int))dlsym(RTLD_DEFAULT, "rsn_test_fail_threads");
+        long (*refused)(void) = (long (*)(void))dlsym(RTLD_DEFAULT, "rsn_test_threads_refused");
+        CHECK(fail_threads && refused);                      /* LD_PRELOAD=pthread_fail_shim.so */
+        uint8_t *keep[2] = {NULL, NULL}; size_t keep_n[2] = {0, 0};
+        uint8_t *w = rsn_call(rsn_huffman_compress, (const uint8_t *)"warm", 4, &n, &rc); CHECK(rc == 0); free(w);   /* the device is up */
+        helper_thread_calls(fail_threads, 1, keep, keep_n);  /* no thread to be had */
+        const long r1 = refused();
+        CHECK(r1 >= 5);                                      /* (the library did ask) */
+        helper_thread_calls(fail_threads, 0, keep, keep_n);  /* helpers available: the same bytes */
+        helper_thread_calls(fail_threads, 1, keep, keep_n);  /* refused again: the helpers that exist by now serve where they are idle */
+        free(keep[0]); free(keep[1]);
+        rsn_trim();
+        printf("abi shim (threads refused %ld times): ok\n", refused());
+        return 0;
     }
     if (nodev) {
         if (rsn_device_count() <= 0) {                       /* no GPU: every codec call fails loudly, none computes on the CPU */

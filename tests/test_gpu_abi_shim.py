@@ -14,8 +14,36 @@ def _build(tmp_path):
     exe = str(tmp_path / "abi_shim_test")
     subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "abi_shim_test.c"), "-o", exe,
-                           "-L", os.path.join(ROOT, "raisin_amd"), "-lrsn", "-Wl,-rpath," + os.path.join(ROOT, "raisin_amd")])
+                           "-L", os.path.join(ROOT, "raisin_amd"), "-lrsn", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "raisin_amd")])
     return exe
+
+
+def _build_thread_shim(tmp_path):
+    so = str(tmp_path / "pthread_fail_shim.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", os.path.join(ROOT, "tests", "pthread_fail_shim.c"), "-o", so, "-ldl"])
+    return so
+
+
+def test_helper_pool_when_the_system_refuses_threads(tmp_path):
+    """No GPU needed: rsn_helpers.h -- the pool every helper thread of the library comes from, and the guard
+    every entry point runs in -- under a pthread_create that fails with EAGAIN (`ulimit -u` is not enforced for root and counts a
+    whole user's threads): "no helper" is an answer, side jobs run on the caller, existing helpers serve, exceptions become
+    RSN_ERR_NOMEM / RSN_ERR_DEVICE.  Never std::terminate (engine.go:315-328 recovers a panic, not a dead process)."""
+    exe = str(tmp_path / "thread_fail_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-I", os.path.join(ROOT, "raisin_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "thread_fail_test.cpp"), "-o", exe, "-ldl"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, LD_PRELOAD=_build_thread_shim(tmp_path)))
+    assert out.returncode == 0 and "thread fail test ok" in out.stdout, (out.stdout, out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_abi_shim_with_threads_refused(tmp_path):
+    """The library's own calls that use helper threads (pipelined Huffman decode and LZSS encode, the batch, the sharded stream,
+    the side jobs of 20 000-rune alphabets) while pthread_create fails: bytes by the serial form or a negative code + message."""
+    exe = _build(tmp_path)
+    out = subprocess.run([exe, "threadfail"], capture_output=True, text=True, timeout=900, env=dict(os.environ, LD_PRELOAD=_build_thread_shim(tmp_path)))
+    assert out.returncode == 0, (out.stdout, out.stderr[-3000:])
+    assert "threads refused" in out.stdout
 
 
 def test_abi_shim_compiles_and_host_only_part_runs(tmp_path):
