@@ -510,24 +510,27 @@ def config5_dealt(torch, dist, device, n, rank, world, backend, k=8):
     ok = all(bool(torch.equal(huffman.decompress_tensor(segs[j], out=dec), srcs[j])) for j in range(len(mine)))
     ok_all = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if backend == "nccl" else cpu)
     dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-    # gather: round j moves every rank's j-th segment (ranks with fewer chunks send an empty one)
+    # gather: round j moves every rank's j-th segment (ranks with fewer chunks send an empty one); an untimed 1-byte round first --
+    # RCCL's lazy channel set-up must not be what gather_ms measures (shard.warm_gather)
     fence()
-    g0 = time.perf_counter()
-    total = 0
-    rounds = (k + world - 1) // world
-    for j in range(rounds):
-        seg = segs[j] if j < len(segs) else torch.empty(0, dtype=torch.uint8, device=device)
-        if backend != "nccl":
-            seg = seg.cpu()
-        got = _shard.gather_segments(dist, seg, 0)
-        if rank == 0:
-            total += sum(int(x.numel()) for x in got)
-        del got
-    torch.cuda.synchronize(device)
-    gather_ms = (time.perf_counter() - g0) * 1e3
+    n_rounds = (k + world - 1) // world
+    rounds = [segs[j] if j < len(segs) else torch.empty(0, dtype=torch.uint8, device=device) for j in range(n_rounds)]
+    if backend != "nccl":
+        rounds = [x.cpu() for x in rounds]
+    g = _shard.timed_gather(dist, rounds, device if backend == "nccl" else cpu, 0, sync=lambda: torch.cuda.synchronize(device))
+    total = g["gathered_bytes"]
+    g.pop("segments")
+    C_mine = sum(int(x.numel()) for x in segs)
+    ranks = _shard.per_rank(dist, [mine_s * 1e3, len(mine), (2 * len(mine) * n + C_mine) / max(mine_s, 1e-9) / 1e9 / HBM_PEAK_GBPS],
+                            device if backend == "nccl" else cpu)
     return {"chunks": k, "chunks_per_rank": [len(_shard.chunks_for_rank(k, r, world)) for r in range(world)], "bytes": k * n,
             "encode_ms": round(t_max * 1e3, 3), "encode_MBps": round(k * n / 1e6 / t_max, 1), "scaling": "strong",
-            "gather_ms": round(gather_ms, 3), "gathered_bytes": total, "lossless": bool(int(ok_all.item()) == 1),
+            "encode_frac_of_hbm_peak": round((2 * k * n + total) / t_max / 1e9 / (world * HBM_PEAK_GBPS), 5) if total else None,
+            "per_rank": {"encode_ms": [round(r[0], 3) for r in ranks], "chunks": [int(r[1]) for r in ranks],
+                         "encode_frac_of_hbm_peak": [round(r[2], 5) for r in ranks]},
+            "gather_ms": round(g["gather_ms"], 3), "gather_warmup_ms": round(g["gather_warmup_ms"], 3),
+            "gather_GBps": round(total / 1e6 / g["gather_ms"], 2) if g["gather_ms"] > 0 else None,
+            "gathered_bytes": total, "lossless": bool(int(ok_all.item()) == 1),
             "note": "8 x %d MiB chunks, chunk i -> rank i mod %d; encode only (what CompressFiles does per file); time = max over ranks" % (n >> 20, world)}
 
 
@@ -700,8 +703,16 @@ def main():
     _lib.prof_enable(False)
 
     t_max = elapsed
+    ranks = None
     if dist is not None:
-        t_max = _shard.max_over_ranks(dist, elapsed, device if args.dist_backend == "nccl" else torch.device("cpu"))
+        cdev = device if args.dist_backend == "nccl" else torch.device("cpu")
+        t_max = _shard.max_over_ranks(dist, elapsed, cdev)
+        # every rank's own figures (north_star: MB/s AND fraction of the HBM peak at 1/2/4/8 GPUs); the line's `value` is the whole job's
+        K_ = max(args.steps, 1)
+        e_ms, d_ms = t_enc / K_ * 1e3, (elapsed - t_enc) / K_ * 1e3
+        C_ = int(c.numel())
+        ranks = _shard.per_rank(dist, [elapsed / K_ * 1e3, e_ms, d_ms, (2 * n + C_) / (e_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                       (C_ + n) / (d_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, n / (e_ms / 1e3) / 1e9 / HBM_PEAK_GBPS], cdev)
 
     lossless = bool(d.numel() == n and torch.equal(d, src))   # checked BEFORE anything else touches dec_buf
     comp_n = int(c.numel())
@@ -743,10 +754,9 @@ def main():
 
         def _gather():
             torch.cuda.set_device(device)
-            g0 = time.perf_counter()
-            got = _shard.gather_segments(dist, seg, 0)
-            torch.cuda.synchronize(device)
-            box["ms"] = (time.perf_counter() - g0) * 1e3
+            g = _shard.timed_gather(dist, [seg], seg.device, 0, sync=lambda: torch.cuda.synchronize(device))   # (an untimed 1-byte round first)
+            box["ms"], box["warm_ms"], box["bytes"] = g["gather_ms"], g["gather_warmup_ms"], g["gathered_bytes"]
+            got = g["segments"][0] if rank == 0 else None
             box["ok"] = rank != 0 or (len(got) == world and got[0].numel() == comp_n)
 
         th = threading.Thread(target=_gather, daemon=True)
@@ -800,8 +810,20 @@ def main():
             "hbm_calibration_GBps": {"torch_copy_read_plus_write": round(copy_gbps, 1), "torch_read_only_sum": round(read_gbps, 1)},
             "roofline": roofline, "kernels": kernels,
         }
+        if ranks is not None:
+            out["per_rank"] = {"ms_per_step": [round(r[0], 4) for r in ranks], "encode_ms": [round(r[1], 4) for r in ranks],
+                               "decode_ms": [round(r[2], 4) for r in ranks],
+                               "encode_frac_of_hbm_peak_2N_plus_C": [round(r[3], 4) for r in ranks],
+                               "decode_frac_of_hbm_peak_C_plus_N": [round(r[4], 4) for r in ranks],
+                               "encode_input_read_frac_of_hbm_peak": [round(r[5], 4) for r in ranks]}
+            # the whole job against N GPUs' peak: algorithmic bytes of all ranks' steps / the slowest rank's time / (N x 8 TB/s)
+            out["frac_of_hbm_peak_all_gpus"] = round(world * K * ((2 * n + C) + (C + n)) / t_max / 1e9 / (world * HBM_PEAK_GBPS), 4)
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 3)
+            out["gather_warmup_ms"] = round(box.get("warm_ms", 0.0), 3)
+            out["gather_GBps"] = round(box.get("bytes", 0) / 1e6 / gather_ms, 2) if gather_ms > 0 else None
+            out["gather_note"] = ("one untimed 1-byte round first (RCCL sets peer-to-peer channels up on first use: gather_warmup_ms), then "
+                                  "all_gather of sizes + grouped send/recv of one segment per rank to rank 0")
         if dealt is not None:
             out["config5_dealt"] = dealt
         if dist is not None and gather_ms is None:

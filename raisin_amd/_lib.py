@@ -10,6 +10,13 @@ LIB_PATH = os.environ.get("RSN_LIB_PATH") or os.path.join(_HERE, "librsn.so")   
 RSN_OK = 0
 RSN_ERR_CAPACITY = -7
 
+# RSN_NO_TORCH=1: this package never imports torch -- bytes, numpy and ctypes only.  librsn then runs on the HIP runtime it is linked
+# against (the system's /opt/rocm, ROCm 7.2), which is the runtime a C or Go (cgo) host gets; with torch imported first the process
+# resolves libamdhip64.so.7 to the copy torch bundles (ROCm 7.0.2, same SONAME) and librsn runs on THAT one -- the two differ in
+# behaviour (under torch's, a download does not start while an upload runs: DESIGN 0, INTEGRATION.md "Which HIP runtime").  The
+# parity suites that only need the host-buffer API run once in each mode (tests/test_gpu_no_torch.py).
+NO_TORCH = os.environ.get("RSN_NO_TORCH") == "1"
+
 
 class RsnError(RuntimeError):
     """Raised where the reference would panic (check(e) / index out of range)."""
@@ -43,17 +50,19 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("raisin_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C raisin_amd/csrc`; there is no fallback path" % LIB_PATH)
-    # librsn links the system ROCm runtime (/opt/rocm); PyTorch bundles its own
-    # copy.  Both can live in one process (device memory is shared by address),
-    # but only if PyTorch's copy initialises first -- so import it here when it
-    # is installed.  Stream/event HANDLES are never exchanged between the two
-    # runtimes: librsn always runs on its own stream (see tensor helpers).
-    try:
-        import torch  # noqa: F401
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except ImportError:
-        pass
+    # librsn is LINKED against the system ROCm runtime (/opt/rocm, libamdhip64.so.7); PyTorch bundles a copy of an older release
+    # under the same SONAME.  A process holds ONE library per SONAME: whichever is loaded first serves both, so with torch imported
+    # first (below: the tensor helpers and bench.py need it, and torch must initialise its own copy) librsn runs on torch's runtime,
+    # not on the one it was linked against (hipRuntimeGetVersion 70051831 against 70226015, r05).  Device memory is shared by
+    # address either way; stream / event HANDLES are never exchanged (librsn always runs on its own stream, see the tensor helpers).
+    # RSN_NO_TORCH=1 skips the import: the runtime a C / Go host gets.
+    if not NO_TORCH:
+        try:
+            import torch  # noqa: F401
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     vp, sz, szp = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)
@@ -121,6 +130,66 @@ def call_dev(fn, d_in, n, d_out, cap, stream, *extra):
         err.needed = got.value
         raise err
     return got.value
+
+
+_hip = None
+
+
+def hip():
+    """The HIP runtime this process's librsn runs on, through ctypes (the SONAME librsn links: already loaded, so this is the same
+    library object) -- device memory without torch: the torch-free mode's way to the device-pointer entry points."""
+    global _hip
+    if _hip is None:
+        lib()
+        H = ctypes.CDLL("libamdhip64.so.7")
+        H.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        H.hipFree.argtypes = [ctypes.c_void_p]
+        H.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        H.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        H.hipRuntimeGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        _hip = H
+    return _hip
+
+
+def runtime_info():
+    """(hipRuntimeGetVersion, path of the libamdhip64 mapped into this process) -- which of the two runtimes librsn is running on."""
+    v = ctypes.c_int(0)
+    hip().hipRuntimeGetVersion(ctypes.byref(v))
+    paths = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+    return v.value, paths
+
+
+def dev_codec(fn, data, cap, *extra):
+    """bytes -> device buffer -> a device-pointer entry point (`fn`: rsn_*_dev) -> bytes, without torch: hipMalloc / hipMemcpy of the
+    runtime librsn runs on.  The general path for inputs the host-buffer entry points would route to the small-input codec."""
+    H, L = hip(), lib()
+    data = bytes(data)
+    n = len(data)
+    check(L.rsn_device_set(0))
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+
+    def ok(e):
+        if e != 0:
+            raise RuntimeError("HIP error %d" % e)
+    ok(H.hipMalloc(ctypes.byref(d_in), n + 64))
+    try:
+        ok(H.hipMemset(d_in, 0, n + 64))
+        ok(H.hipMemcpy(d_in, data, n, 1))
+        for attempt in range(2):
+            ok(H.hipMalloc(ctypes.byref(d_out), cap + 64))
+            try:
+                got = call_dev(fn, d_in, n, d_out, cap, None, *extra)
+                buf = ctypes.create_string_buffer(max(got, 1))
+                ok(H.hipMemcpy(buf, d_out, got, 2))
+                return buf.raw[:got]
+            except RsnError as e:
+                if e.code != RSN_ERR_CAPACITY or attempt:
+                    raise
+                cap = e.needed
+            finally:
+                H.hipFree(d_out)
+    finally:
+        H.hipFree(d_in)
 
 
 def prof_enable(on=True):

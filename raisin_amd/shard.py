@@ -40,6 +40,54 @@ def gather_segments(dist, segment, dst=0):
     return bufs
 
 
+def warm_gather(dist, device, dst=0):
+    """One UNTIMED round of the gather with a 1-byte segment per rank, to be run before a gather that is timed: RCCL sets a peer-to-peer
+    channel up lazily, on the first send/recv between two ranks (and its rings on the first collective), and that set-up -- tens of
+    milliseconds per peer -- would otherwise land inside the first timed round, against ~6 ms of xGMI time for a 0.9 GB segment
+    (VERDICT r5 #2).  The warm-up uses the same two calls in the same order as gather_segments, so every channel the timed gather
+    needs exists afterwards.  Returns the warm-up's wall time in ms (reported next to gather_ms, never inside it)."""
+    import time
+
+    import torch
+    t0 = time.perf_counter()
+    gather_segments(dist, torch.zeros(1, dtype=torch.uint8, device=device), dst)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def timed_gather(dist, rounds, device, dst=0, sync=None):
+    """The gather of the finished segments to `dst` as bench.py times it: warm_gather (untimed), then every round's segment
+    (rounds: one tensor per round on this rank; ranks with fewer chunks pass an empty one), wall time from a barrier to the last byte
+    having landed.  Returns {"gather_ms", "gather_warmup_ms", "gathered_bytes", "segments": dst's list of lists (None elsewhere)}."""
+    import time
+    sync = sync or (lambda: None)
+    warm_ms = warm_gather(dist, device, dst)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    total, segs = 0, []
+    for seg in rounds:
+        got = gather_segments(dist, seg, dst)
+        if got is not None:
+            total += sum(int(x.numel()) for x in got)
+            segs.append(got)
+    sync()
+    ms = (time.perf_counter() - t0) * 1e3
+    return {"gather_ms": ms, "gather_warmup_ms": warm_ms, "gathered_bytes": total, "segments": segs if dist.get_rank() == dst else None}
+
+
+def per_rank(dist, values, device):
+    """Every rank's list of floats, in rank order, on every rank (north_star: throughput AND fraction of the HBM peak at 1/2/4/8 GPUs --
+    the line's `value` is the whole job's, these are each rank's own)."""
+    import torch
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]
+
+
 def max_over_ranks(dist, seconds, device):
     """The job's time is the slowest rank's time."""
     import torch

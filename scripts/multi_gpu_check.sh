@@ -16,7 +16,7 @@ for N in 2 4 8; do
   python3 - $N <<'PY'
 import json, sys
 j = json.loads(open("gpurun_out/multi_bench_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
-print({k: j.get(k) for k in ("value", "n_gpus", "ms_per_step", "lossless", "gather_ms")}, j.get("config5_dealt"))
+print({k: j.get(k) for k in ("value", "n_gpus", "ms_per_step", "lossless", "frac_of_hbm_peak_all_gpus", "per_rank", "gather_ms", "gather_warmup_ms", "gather_GBps")}, j.get("config5_dealt"))
 PY
 done
 timeout 900 python3 -m pytest tests/test_gpu_full_size.py -q -k over_rccl 2>&1 | tail -3

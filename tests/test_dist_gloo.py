@@ -24,6 +24,25 @@ def _worker(rank, world, port, q):
         got = shard.gather_segments(dist, seg, 0)
         t = shard.max_over_ranks(dist, 1.0 + rank, torch.device("cpu"))
         out = {"rank": rank, "chunks": mine, "tmax": t, "sizes": [int(x.numel()) for x in got] if got else None}
+        # the gather as bench.py times it: a channel's first use is slow (RCCL sets peer-to-peer channels up lazily) --
+        # simulated here by a first gather_segments call that takes 0.4 s -- and must land in gather_warmup_ms, not in gather_ms
+        import time
+        real, calls = shard.gather_segments, []
+
+        def slow_first(d, seg_, dst=0):
+            calls.append(int(seg_.numel()))
+            if len(calls) == 1:
+                time.sleep(0.4)
+            return real(d, seg_, dst)
+        shard.gather_segments = slow_first
+        try:
+            rounds = [seg, torch.empty(0, dtype=torch.uint8) if rank == 1 else seg[:10]]     # a rank with fewer chunks sends an empty segment
+            g = shard.timed_gather(dist, rounds, torch.device("cpu"), 0)
+        finally:
+            shard.gather_segments = real
+        out["timed"] = {"calls": calls, "gather_ms": g["gather_ms"], "gather_warmup_ms": g["gather_warmup_ms"], "gathered_bytes": g["gathered_bytes"],
+                        "segments": [[int(x.numel()) for x in r] for r in g["segments"]] if g["segments"] is not None else None}
+        out["per_rank"] = shard.per_rank(dist, [10.0 + rank, 0.5 * (rank + 1)], torch.device("cpu"))
         if rank == 0:
             ok = True
             for r in range(world):
@@ -53,6 +72,13 @@ def test_two_rank_gather_and_timing():
     assert res[0]["chunks"] == [0, 2, 4] and res[1]["chunks"] == [1, 3]
     assert res[0]["sizes"] == [1000, 1777] and res[0]["ok"] is True and res[1]["sizes"] is None
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0
+    for r in (0, 1):
+        t = res[r]["timed"]
+        assert t["calls"][0] == 1 and len(t["calls"]) == 3                      # the untimed 1-byte round, then the two timed ones
+        assert t["gather_warmup_ms"] >= 400 and t["gather_ms"] < 300, t         # the slow first use is NOT inside gather_ms
+        assert res[r]["per_rank"] == [[10.0, 0.5], [11.0, 1.0]]                 # every rank's figures, in rank order, on every rank
+    assert res[0]["timed"]["segments"] == [[1000, 1777], [10, 0]] and res[0]["timed"]["gathered_bytes"] == 2787
+    assert res[1]["timed"]["segments"] is None
 
 
 @pytest.mark.timeout(300)

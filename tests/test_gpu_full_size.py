@@ -259,6 +259,14 @@ def test_bench_two_ranks_control_flow():
     d5 = j["config5_dealt"]                              # configs[4]'s eight chunks dealt over the two ranks, then gathered
     assert d5["chunks"] == 8 and d5["chunks_per_rank"] == [4, 4] and d5["lossless"] is True and d5["scaling"] == "strong"
     assert d5["gathered_bytes"] > 8 * (64 << 20) * 7 // 8 and d5["encode_ms"] > 0
+    # north_star: absolute MB/s and fraction of the HBM peak per GPU count -- every rank's own figures ride in the line, and both
+    # gathers are preceded by an untimed round that is reported on its own
+    pr = j["per_rank"]
+    for key in ("ms_per_step", "encode_ms", "decode_ms", "encode_frac_of_hbm_peak_2N_plus_C", "decode_frac_of_hbm_peak_C_plus_N"):
+        assert len(pr[key]) == 2 and all(x > 0 for x in pr[key]), key
+    assert 0 < j["frac_of_hbm_peak_all_gpus"] < 1 and j["gather_warmup_ms"] > 0 and j["gather_ms"] > 0
+    assert len(d5["per_rank"]["encode_ms"]) == 2 and d5["per_rank"]["chunks"] == [4, 4] and d5["gather_warmup_ms"] > 0
+    assert all(0 < x < 1 for x in d5["per_rank"]["encode_frac_of_hbm_peak"]) and 0 < d5["encode_frac_of_hbm_peak"] < 1
 
 
 def test_bench_two_ranks_over_rccl():
@@ -275,7 +283,8 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["lossless"] is True and j["value"] > 0
-    assert j["gather_ms"] is not None and j["gather_ms"] > 0
+    assert j["gather_ms"] is not None and j["gather_ms"] > 0 and j["gather_warmup_ms"] > 0
+    assert len(j["per_rank"]["encode_frac_of_hbm_peak_2N_plus_C"]) == 2
     assert j["config5_dealt"]["chunks"] == 8 and j["config5_dealt"]["lossless"] is True
 
 

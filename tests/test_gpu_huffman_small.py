@@ -16,12 +16,18 @@ def huff():
 
 
 def _general_compress(huff, data):
+    from raisin_amd import _lib
+    if _lib.NO_TORCH:                                       # (tests/test_gpu_no_torch.py: this suite on the runtime a Go host gets)
+        return _lib.dev_codec(_lib.lib().rsn_huffman_compress_dev, data, len(data) + len(data) // 8 + (1 << 16))
     import torch
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     return huff.compress_tensor(src).cpu().numpy().tobytes()
 
 
 def _general_decompress(huff, stream):
+    from raisin_amd import _lib
+    if _lib.NO_TORCH:
+        return _lib.dev_codec(_lib.lib().rsn_huffman_decompress_dev, stream, 8 * len(stream) + (1 << 16))
     import torch
     src = torch.frombuffer(bytearray(stream), dtype=torch.uint8).cuda()
     return huff.decompress_tensor(src).cpu().numpy().tobytes()
