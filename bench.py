@@ -97,14 +97,47 @@ def workload_traffic(workload, prof_name):
     return None
 
 
+VALU_BOUND_FROM = 0.6     # a kernel whose vector instructions alone account for this share of its duration is priced as issue-bound
+
+
+def valu_issue(workload, prof_name):
+    """Vector-issue share of one kernel in the workload's newest committed SQ-counter summary (profiles/<tag>_valu_<label>.txt,
+    scripts/pmc_valu.sh: SQ_INSTS_VALU of the kernel's largest launch x 3.5 cycles / 1024 SIMDs / its duration; a wave64 integer
+    VALU instruction holds its SIMD 3.4-5.0 cycles, scripts/valu_probe.cpp): (share, file) or None.  A constant of that profile."""
+    import glob
+    label = PMC_LABEL.get(workload, workload)
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_%s.txt" % label)), reverse=True):
+        try:
+            rows = open(p).read().splitlines()[1:]
+        except Exception:
+            continue
+        for cand in TRACE_CANDIDATES.get(prof_name, ["k_" + prof_name.split("_", 1)[-1]]):
+            for row in rows:
+                if row.startswith(cand):
+                    try:
+                        return float(row.split()[-1]), os.path.basename(p)
+                    except ValueError:
+                        pass
+    return None
+
+
 def roofline_of(workload, prof_name, alg_bytes, ms):
     """The bench line's roofline object for one kernel of one workload: achieved = ALGORITHMIC bytes / the kernel's average launch
-    duration (HIP events on librsn's stream, this run); traffic = that kernel's PMC bytes in the workload's committed profile."""
+    duration (HIP events on librsn's stream, this run); traffic = that kernel's PMC bytes in the workload's committed profile.
+    SURVEY 8(d): LZSS encode is VALU / LDS-compare-bound -- a kernel whose committed SQ counters say vector issue fills its time is
+    labelled "valu", with that share, and keeps its fraction of the HBM peak beside it."""
     tr = workload_traffic(workload, prof_name)
+    vi = valu_issue(workload, prof_name)
     ach = alg_bytes / ms / 1e6 if ms > 0 else 0.0
-    return {"kernel": prof_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": tr[0] if tr else None,
-            "traffic_source": ("profiles/" + tr[1]) if tr else None, "algorithmic_bytes": int(alg_bytes)}
+    out = {"kernel": prof_name, "bound": "valu" if vi and vi[0] >= VALU_BOUND_FROM else "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": tr[0] if tr else None,
+           "traffic_source": ("profiles/" + tr[1]) if tr else None, "algorithmic_bytes": int(alg_bytes)}
+    if vi:
+        out["valu_issue_frac"] = vi[0]
+        out["valu_source"] = "profiles/" + vi[1]
+        if out["bound"] == "valu":
+            out["note"] = "vector-issue-bound: `frac` is the algorithmic bytes against the HBM peak, which is not what limits this kernel"
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines
@@ -432,7 +465,9 @@ def config1_and_host_api(torch, device, n, with_host_gib):
         # runs (scripts/probes/py_decode_torch_order.py).
         import subprocess
         ha = {"bytes": n, "note": "host buffer in, library-owned host buffer out, warm calls (pages mapped, arenas grown); PCIe included, never `value`; "
-                                  "encode_ms / decode_ms: a C process; python_process: this process through ctypes (torch imported: its bundled HIP runtime)"}
+                                  "encode_ms / decode_ms: the second ctypes call in THIS process, as in r01-r04 (torch imported: its bundled HIP runtime); "
+                                  "c_process.pipelined / .serial: a freshly compiled C process (scripts/probes/host_call_probe.cpp, the runtime a cgo host "
+                                  "gets), best of three warm calls, the second with RSN_HOST_SERIAL=1 (r05 reported the C process under encode_ms / decode_ms)"}
         exe = "/tmp/rsn_host_call_probe_%d" % os.getpid()
         try:
             subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "scripts", "probes", "host_call_probe.cpp"),
@@ -457,18 +492,17 @@ def config1_and_host_api(torch, device, n, with_host_gib):
                         r = subprocess.run([exe, str(n >> 20), kind + data_file], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
                         line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
                         res = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
-                        if label == "pipelined" and "compress_ms" in res:
-                            entry.update({"encode_ms": res["compress_ms"], "decode_ms": res["decompress_ms"], "lossless": res["lossless"],
-                                          "compressed_bytes": res["compressed"],
-                                          "encode_GBps": round(n / res["compress_ms"] / 1e6, 2), "decode_GBps": round(n / res["decompress_ms"] / 1e6, 2)})
-                        else:
-                            entry[label] = res
+                        if "compress_ms" in res:
+                            res = {"encode_ms": res["compress_ms"], "decode_ms": res["decompress_ms"], "lossless": res["lossless"],
+                                   "compressed_bytes": res["compressed"],
+                                   "encode_GBps": round(n / res["compress_ms"] / 1e6, 2), "decode_GBps": round(n / res["decompress_ms"] / 1e6, 2)}
+                        entry.setdefault("c_process", {"method": "best of three warm calls in a C process"})[label] = res
                 except Exception as e:                      # noqa: BLE001
                     entry["c_process_error"] = "%s: %s" % (type(e).__name__, e)
                 finally:
                     if os.path.exists(data_file):
                         os.remove(data_file)
-            entry["python_process"] = py
+            entry.update(py)
             ha[key] = entry
             del src
         if exe and os.path.exists(exe):
