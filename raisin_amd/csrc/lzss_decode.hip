@@ -1285,6 +1285,115 @@ int lzss_unescape(Ctx &c, hipStream_t s, const uint8_t *d_esc, size_t E, bool ha
 }
 
 int lzss_decode_sections(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
+int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, uint8_t *esc_dst);
+
+// ---------------------------------------------------------------- a stream that ends in ONE token repeated (r06)
+// What CompressAsync writes for data that repeats with the window's length (BASELINE configs[2]: one 4096-byte block over and over) is a
+// short head, then "<4096,4096>" a quarter of a million times, then one last item (lzss.go:134-151).  A token <P,P> copies the P bytes
+// before it: behind the head the output repeats with period P, whatever the bytes are (lzss.go:349-353).  r05 decoded such a stream like
+// any other -- run tiles, 0.95 ms per GiB of output, of which writing the gigabyte is 0.3.  Now the host reads the stream's last 64 bytes
+// (with the counting pass's results: no extra round trip), and when they end in "<P,P><P,P>" + at most one more item, a kernel finds where
+// that token's run begins in the COMPRESSED stream (the last byte that differs from the byte |token| before it: 3 MB to look at, not a
+// gigabyte); the counting pass has accepted every token as well-formed, so a '<' is never inside one and the run's first '<' is an item
+// boundary of the true parse.  The head in front of it is decoded by the ordinary decoder, the run is written by arithmetic --
+// out[q] = out[q - P] -- and the last item by a block of its own.  Only for streams without a 5C (nothing to unescape but FF -> '<', which
+// the head's emit pass has applied to the bytes the run copies); everything else about the stream is checked as always.
+__global__ __launch_bounds__(256) void k_lzd_run_start(const uint8_t *__restrict__ in, unsigned long long t_end, uint32_t tl, unsigned long long *__restrict__ last_break) {
+    // *last_break = 1 + the largest i in [tl, t_end) with in[i] != in[i - tl]   (0: none)
+    const unsigned long long i0 = tl + ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16;
+    unsigned long long m = 0;
+    for (int k = 0; k < 16; k++) { const unsigned long long i = i0 + k; if (i < t_end && in[i] != in[i - tl]) m = i + 1; }
+    for (int d = 32; d; d >>= 1) m = max(m, (unsigned long long)__shfl_down(m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(last_break, m);
+}
+constexpr uint32_t RUN_P_MAX = 8192;                                     // periods the fill kernel keeps in LDS
+struct RunFill { uint8_t *out; uint32_t lo, hi, P; };                    // out[q] = out[q - P] for q in [lo, hi); out[lo - P, lo) is in place
+__global__ __launch_bounds__(256) void k_lzd_run_fill(RunFill a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pat[RUN_P_MAX + 32];   // the period, and its first 16 bytes once more behind it
+    const uint8_t *src = a.out + (a.lo - a.P);
+    for (uint32_t i = threadIdx.x; i < a.P + 16; i += 256) s_pat[i] = src[i % a.P];
+    __syncthreads();
+    constexpr uint32_t CHUNK = 256 * 16 * 16;                             // output bytes per block
+    const unsigned long long u_first = a.lo >> 4;
+    for (int it = 0; it < 16; it++) {
+        const unsigned long long u = u_first + (unsigned long long)blockIdx.x * (CHUNK / 16) + (unsigned)it * 256 + threadIdx.x;
+        const unsigned long long b0 = u << 4;
+        if (b0 >= a.hi) break;
+        if (b0 >= a.lo && b0 + 16 <= a.hi) {
+            const uint32_t ph = (uint32_t)(b0 - a.lo) % a.P;
+            uint4 v;
+            __builtin_memcpy(&v, s_pat + ph, 16);
+            *reinterpret_cast<uint4 *>(a.out + b0) = v;
+        } else for (int k = 0; k < 16; k++) { const unsigned long long q = b0 + k; if (q >= a.lo && q < a.hi) a.out[q] = s_pat[(uint32_t)(q - a.lo) % a.P]; }
+    }
+}
+// the stream's last item behind the run: a token (out[x + k] = out[x - d + k], k < r <= d) or r literal bytes (FF -> '<': DecodeOpeningSymbols, lzss.go:391-406)
+__global__ __launch_bounds__(256) void k_lzd_run_last(uint8_t *__restrict__ out, uint32_t x, uint32_t d, uint32_t r, const uint8_t *__restrict__ lit) {
+    for (uint32_t k = threadIdx.x; k < r; k += 256) { const uint8_t b = lit ? lit[k] : out[x - d + k]; out[x + k] = lit && b == 0xFF ? (uint8_t)0x3C : b; }
+}
+
+// 1 = not a stream for this path (the caller decodes it as always); otherwise the call's result.
+// tail: the stream's last min(n, 64) bytes (host copy); E: its decoded length (the counting pass's); d_brk: a device word for k_lzd_run_start
+static int lzss_decode_run_tail(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, const uint8_t *tail, uint32_t E, unsigned long long *d_brk,
+                                unsigned long long *h_brk, uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    const size_t k = std::min<size_t>(n, 64), base = n - k;
+    auto token_at = [&](size_t i, uint32_t *d, uint32_t *l) -> size_t {   // the length of the well-formed token at tail[i], 0 if there is none
+        if (i >= k || tail[i] != '<') return 0;
+        size_t j = i + 1; unsigned long long v = 0; int nd = 0;
+        while (j < k && nd < 10 && tail[j] >= '0' && tail[j] <= '9') { v = v * 10 + (tail[j] - '0'); j++; nd++; }
+        if (!nd || j >= k || tail[j] != ',' || v > 0xFFFFFFFFull) return 0;
+        *d = (uint32_t)v; j++; v = 0; nd = 0;
+        while (j < k && nd < 10 && tail[j] >= '0' && tail[j] <= '9') { v = v * 10 + (tail[j] - '0'); j++; nd++; }
+        if (!nd || j >= k || tail[j] != '>' || v > 0xFFFFFFFFull) return 0;
+        *l = (uint32_t)v;
+        return j + 1 - i;
+    };
+    // the last token <P,P> of the tail, one more of it right in front, and behind it nothing, one token, or literals
+    size_t ti = k; uint32_t P = 0, tl = 0;
+    for (size_t i = k; i-- > 0;) {
+        uint32_t d = 0, l = 0;
+        const size_t len = token_at(i, &d, &l);
+        if (len && d == l && d >= 1) { ti = i; P = d; tl = (uint32_t)len; break; }
+    }
+    if (ti == k || P > RUN_P_MAX || ti < tl || memcmp(tail + ti - tl, tail + ti, tl) != 0) return 1;
+    const size_t ri = ti + tl;                                            // the rest: [ri, k)
+    uint32_t rd = 0, rr = 0; bool rest_lit = false;
+    if (ri < k) {
+        if (tail[ri] == '<') { if (token_at(ri, &rd, &rr) != k - ri || rr > rd) return 1; }
+        else { for (size_t i = ri; i < k; i++) if (tail[i] == '<') return 1; rest_lit = true; rr = (uint32_t)(k - ri); }
+    }
+    const unsigned long long t_end = base + ri;
+    // ---- where the run begins
+    RSN_HIP(hipMemsetAsync(d_brk, 0, 8, s));
+    if (t_end > tl) RSN_LAUNCH("lzss_dec_run_start", k_lzd_run_start, dim3((uint32_t)ceil_div((size_t)(t_end - tl), (size_t)4096)), dim3(256), 0, s, d_in, t_end, tl, d_brk);
+    RSN_HIP(hipMemcpyAsync(h_brk, d_brk, 8, hipMemcpyDeviceToHost, s));
+    RSN_HIP(hipStreamSynchronize(s));
+    const unsigned long long brk = *h_brk;
+    unsigned long long a0 = std::max<unsigned long long>(brk, tl) - tl;   // [a0, t_end) repeats with the token's length and ends in the token
+    a0 += (t_end - a0) % tl;                                              // ... and from here it is whole tokens
+    const unsigned long long m = (t_end - a0) / tl;
+    if (a0 == 0 || m * P < E / 2 || m * P + rr > E) return 1;            // (nothing in front of the run: its first token points before the data -- the ordinary path words that)
+    // ---- the head
+    static thread_local int depth = 0;
+    if (depth) return 1;
+    size_t e_head = 0;
+    depth++;
+    int rc = lzss_decode_impl(c, s, d_in, (size_t)a0, d_out, out_cap, &e_head, nullptr);
+    depth--;
+    if (rc == RSN_ERR_CAPACITY) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
+    if (rc) return rc;
+    if (e_head + m * P + rr != E) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: a token run of %llu x %u behind %zu bytes in a stream of %u", m, P, e_head, E);
+    if (P > e_head || (!rest_lit && rr && rd > e_head + m * P))
+        return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+    *out_n = E;
+    if (E > out_cap) { *out_n = round_up((size_t)E, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %u bytes, buffer holds %zu", E, out_cap); }
+    RunFill rf{d_out, (uint32_t)e_head, (uint32_t)(e_head + m * P), P};
+    const unsigned long long units = (((unsigned long long)rf.hi + 15) >> 4) - (rf.lo >> 4);
+    RSN_LAUNCH("lzss_dec_run_fill", k_lzd_run_fill, dim3((uint32_t)ceil_div((size_t)units, (size_t)4096)), dim3(256), 0, s, rf);
+    if (rr) RSN_LAUNCH("lzss_dec_run_fill", k_lzd_run_last, dim3(1), dim3(256), 0, s, d_out, rf.hi, rd, rr, rest_lit ? d_in + (size_t)t_end : (const uint8_t *)nullptr);
+    RSN_HIP(hipStreamSynchronize(s));
+    return RSN_OK;
+}
 
 // One stream of less than 4 GiB, compressed and decoded.  esc_dst == nullptr: the decoder proper (-> d_out).  Otherwise only the token
 // expansion (L1 .. L3): the ESCAPED stream goes to esc_dst (16-byte aligned, room for the whole of it plus 64 bytes: the caller knows
@@ -1298,11 +1407,13 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
     if (n >= (1ull << 32) - 65536) return c.fail(RSN_ERR_LIMIT, "lzss: compressed input too large for one call");
     void *p; int rc;
     const uint32_t n_cb = (uint32_t)ceil_div(n, ZTILE);
-    rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 4) * 8, &p); if (rc) return rc;   // ... + flags: [0] error, [1] changed, [2] largest back-pointer, [3] tile path gave up
+    rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 5) * 8, &p); if (rc) return rc;   // ... + flags: [0] error, [1] changed, [2] largest back-pointer, [3] tile path gave up
     unsigned long long *d_blen = (unsigned long long *)p, *d_boff = d_blen + n_cb, *d_btot = d_boff + n_cb;
     int *d_flag = (int *)(d_btot + 1);
-    void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
+    unsigned long long *d_brk = d_btot + 4;                             // (k_lzd_run_start's word)
+    void *hp; rc = pinned_buf(c, 192, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
+    uint8_t *h_tail = (uint8_t *)(h64 + 8);                             // the stream's last 64 bytes, read with the counting pass's results; h64[16]: k_lzd_run_start's answer
     volatile int *hflag = (volatile int *)(h64 + 1);
     RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));                          // ... [4] the stream holds a 5C byte, [5] a span produces 65535 bytes or more
     uint16_t *d_span = nullptr; unsigned long long *d_need = nullptr;
@@ -1312,6 +1423,9 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
     rc = scan_u64(c, s, "lzss_dec_scan", d_blen, d_boff, n_cb, d_btot); if (rc) return rc;
     RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
+    static const bool no_run_tail = getenv("RSN_LZSS_DEC_NO_RUN_TAIL") != nullptr;   // A/B switch (tests): a stream that ends in one token repeated through the ordinary decoder
+    const bool run_cand = !esc_dst && d_out && !no_run_tail && n >= ((size_t)1 << 16);
+    if (run_cand) RSN_HIP(hipMemcpyAsync(h_tail, d_in + (n - 64), 64, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     if (hflag[0] & 1) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
     if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
@@ -1322,6 +1436,11 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
     const bool one_pass = hflag[5] == 0;                 // the counting pass left everything k_lzd_tiles would work out again
     const uint32_t E = (uint32_t)h64[0];
     if (E == 0) return RSN_OK;
+    if (run_cand && one_pass && hflag[4] == 0 && E >= (1u << 20)) {      // (no 5C: what is left of DecodeOpeningSymbols is bytewise)
+        rc = lzss_decode_run_tail(c, s, d_in, n, h_tail, E, d_brk, h64 + 16, d_out, out_cap, out_n);
+        if (rc != 1) return rc;
+        *out_n = 0;
+    }
     DecGate gate(c);
     if (!esc_dst && d_out) gate.admit(E);                               // (a section is admitted by lzss_decode_sections; the size query allocates nothing)
     if (!d_out && !esc_dst) {   // the size query: the escaped length is known here, and unescaping only ever shortens it -- a capacity that suffices, one pass over the tokens

@@ -38,6 +38,7 @@ constexpr int ESC_TILE = LB * 16;       // input bytes per escape block
 constexpr int PT = 8192;                // positions per parse tile
 constexpr uint32_t MAX_WINDOW = 8192;
 constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
+constexpr uint32_t PERIODIC_TAIL_MIN_TILES = 16;   // a W-periodic rest of at least this many tiles is placed by arithmetic (lzss_encode_admitted)
 
 // ------------------------------------------------------------------ E1: escape
 __device__ __forceinline__ uint32_t count_special16(const uint32_t w[4]) {
@@ -2108,6 +2109,63 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
 
 static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
+// ---- a stream that is W-periodic from some chunk on (BASELINE configs[2] is nothing else: one 4096-byte block repeated; r06).
+// k_esc_try's flags say which 4 KiB chunks repeat the W bytes before them.  When every chunk behind chunk k_last does, the key of EVERY
+// position p >= R0 = (k_last + 1) * 4096 is (min(W, E - p), W) whatever the bytes are (k_tile_periodic's argument: the farthest distance
+// there is matches as far as a match may reach, lzss.go:166-184,418-421), so from the first position e >= R0 the greedy chain lands on
+// (lzss.go:134-151) the output is arithmetic: floor((E - e) / W) times the text "<W,W>", then one item for the remainder.  r05 ran the
+// whole pipeline over such a stream -- 131 072 blocks of k_match_chain that return at once, two tail kernels, a placement kernel and an
+// emit kernel per tile: 0.94 ms of which the one pass that has to read the input (the check) is 0.25.  Now: the check, the ordinary
+// encoder on the head [0, S + W) stopped in front of tile S / 8192 (the sections' mechanism: what the items before that tile emit, and
+// where the chain goes on), and one kernel that writes the rest.
+__global__ __launch_bounds__(256) void k_last_unlike(const uint8_t *__restrict__ same_blk, uint32_t n_chunks, unsigned long long *__restrict__ out) {
+    // 1 + the index of the last chunk that does not repeat (chunk 0 never does): sixteen flags per thread, one atomic per wavefront that
+    // has anything to say (a periodic stream: block 0's first; text: every one of them -- 256 atomics per MiB of flags = per 4 GiB of input)
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    uint32_t m = 0;
+    if (i0 + 16 <= n_chunks) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(same_blk + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t z = ~bytes_equal(w[j], 1u);                    // 0xFF where the flag is not 1
+            if (z) m = i0 + 4u * j + (31u - (uint32_t)__builtin_clz(z)) / 8u + 1u;
+        }
+    } else for (uint32_t i = i0; i < n_chunks; i++) if (!same_blk[i]) m = i + 1;
+    for (int d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+struct PeriodicTail {
+    uint8_t *out;                       // the output's base (16-byte aligned)
+    unsigned long long at, n_rep;       // the tail begins at out[at]: n_rep times the token `rep`, then `last` (a token's text, or raw bytes from `raw`)
+    const uint8_t *raw;                 // the remainder's input bytes when they go out as they are ('<' -> FF, lzss.go:373-377); null: `last` is text
+    uint32_t rep_len, last_len;
+    uint8_t rep[12], last[12];
+};
+__global__ __launch_bounds__(256) void k_periodic_tail(PeriodicTail a) {
+    const uint8_t *arg = (const uint8_t *)__builtin_amdgcn_kernarg_segment_ptr();   // (the texts by address: indexing the by-value copy would spill it)
+    const uint8_t *rep = arg + offsetof(PeriodicTail, rep), *last = arg + offsetof(PeriodicTail, last);
+    const unsigned long long body = a.n_rep * a.rep_len, total = body + a.last_len;
+    const unsigned long long u0 = (a.at >> 4) + (unsigned long long)blockIdx.x * 256 + threadIdx.x;     // this thread's 16-byte unit of the output
+    const unsigned long long b0 = u0 << 4;
+    if (b0 >= a.at + total) return;
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t ph = b0 >= a.at ? (uint32_t)((b0 - a.at) % a.rep_len) : 0u;
+    bool whole = b0 >= a.at && b0 + 16 <= a.at + total;
+    for (int k = 0; k < 16; k++) {
+        const unsigned long long j = b0 + k;                              // byte j of the output
+        uint32_t v = 0;
+        if (j >= a.at && j < a.at + total) {
+            const unsigned long long t = j - a.at;
+            if (t < body) { v = rep[ph]; ph = ph + 1 == a.rep_len ? 0u : ph + 1; }
+            else { const uint32_t q = (uint32_t)(t - body); v = a.raw ? a.raw[q] : last[q]; if (a.raw && v == 0x3Cu) v = 0xFFu; }
+        }
+        w[k >> 2] |= v << (8 * (k & 3));
+    }
+    if (whole) *reinterpret_cast<uint4 *>(a.out + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (int k = 0; k < 16; k++) { const unsigned long long j = b0 + k; if (j >= a.at && j < a.at + total) a.out[j] = (uint8_t)(w[k >> 2] >> (8 * (k & 3))); }
+}
+
 int lzss_encode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int64_t window, uint8_t *d_out, size_t out_cap, size_t *out_n) {
     *out_n = 0;
     if (n == 0) return RSN_OK;                                        // CompressAsync(empty) == empty
@@ -2126,8 +2184,8 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     void *p; int rc;
     // ---- E1
     const uint32_t n_eb = (uint32_t)ceil_div(n, ESC_TILE);
-    rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 2) * 8, &p); if (rc) return rc;
-    unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;
+    rc = dev_buf(c, 8, ((size_t)n_eb * 2 + 3) * 8, &p); if (rc) return rc;
+    unsigned long long *d_extra = (unsigned long long *)p, *d_eoff = d_extra + n_eb, *d_etot = d_eoff + n_eb;   // d_etot[1]: the check's flags; [2]: 1 + the last chunk that does not repeat
     void *hp; rc = pinned_buf(c, 64, &hp); if (rc) return rc;
     unsigned long long *h64 = (unsigned long long *)hp;
     bool copied = false;                                              // nothing in the input needs an escape: E = n, every byte keeps its place
@@ -2139,11 +2197,15 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     // which the chain walk and the token emitter can do where they load it.  The copy (r04 wrote it here, N bytes out and N back in for
     // one byte value in 254: half of config 3's traffic) is written only if a kernel that wants the stream in memory has to run.
     if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
-    RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 8, s));
+    RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 16, s));
     RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)nullptr, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
-    RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 8, hipMemcpyDeviceToHost, s));
+    static const bool no_tail = getenv("RSN_LZSS_NO_PERIODIC_TAIL") != nullptr;   // A/B switch (tests): a W-periodic stream through the whole pipeline
+    const bool tail_cand = d_same && !no_tail && (uint64_t)window == Wp && n >= ((size_t)PERIODIC_TAIL_MIN_TILES + 2) * PT;
+    if (tail_cand) RSN_LAUNCH("lzss_last_unlike", k_last_unlike, dim3((uint32_t)ceil_div(n_eb, 4096)), dim3(256), 0, s, (const uint8_t *)d_same, n_eb, d_etot + 2);
+    RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 16, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     copied = (h64[0] & 1ull) == 0;
+    const size_t unlike_end = tail_cand ? (size_t)h64[1] * ESC_TILE : n;   // every 4 KiB chunk from this byte on repeats the W bytes before it
     h64[0] = 0;
     if (!copied) {
         RSN_LAUNCH("lzss_esc_count", k_esc_count, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_extra);
@@ -2153,14 +2215,48 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     }
     const size_t E64 = n + (size_t)h64[0];
     uint8_t *d_fc = nullptr;
-    auto write_stream = [&]() -> int {                                // the escaped stream in memory (slot 9), zeroed padding behind it
-        void *q; int r2 = dev_buf(c, 9, E64 + 64, &q); if (r2) return r2;
+    auto write_stream = [&](size_t upto = 0) -> int {                 // the escaped stream in memory (slot 9), zeroed padding behind it (upto: a prefix of a stream that needs no escape)
+        const size_t len = upto ? upto : E64;
+        void *q; int r2 = dev_buf(c, 9, len + 64, &q); if (r2) return r2;
         d_fc = (uint8_t *)q;
-        RSN_HIP(hipMemsetAsync(d_fc + E64, 0, 64, s));
-        if (copied) RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, d_fc, d_etot + 1, 0u, (uint8_t *)nullptr, n_eb);
+        RSN_HIP(hipMemsetAsync(d_fc + len, 0, 64, s));
+        const uint32_t n_b = (uint32_t)ceil_div(len, ESC_TILE);
+        if (copied) RSN_LAUNCH("lzss_esc_write", k_esc_try, dim3((uint32_t)ceil_div(n_b, ESC_RUN)), dim3(LB), 0, s, d_in, len, d_fc, d_etot + 1, 0u, (uint8_t *)nullptr, n_b);
         else RSN_LAUNCH("lzss_esc_write", k_esc_write, dim3(n_eb), dim3(LB), 0, s, d_in, n, d_eoff, d_fc);
         return RSN_OK;
     };
+    // ---- W-periodic from some chunk on (see k_periodic_tail): the head through the encoder, the rest by arithmetic
+    if (tail_cand && copied) {
+        const size_t S = round_up(std::max(unlike_end, (size_t)1), PT);               // the head's tiles: everything that does not repeat, rounded up to tiles
+        if (S + (size_t)PERIODIC_TAIL_MIN_TILES * PT <= n && S + Wp < (((size_t)1 << 31) - ((size_t)1 << 24))) {
+            const uint32_t Es = (uint32_t)(S + Wp), stop_tile = (uint32_t)(S / PT);  // (W bytes of look-ahead behind the last head position: a match that begins in the head may end there)
+            size_t got = 0; uint32_t e = 0;
+            rc = lzss_encode_stream(c, s, d_in, Es, Wp, d_same, Wp, true, false, stop_tile, d_out, out_cap, &got, &e,
+                                    [&](const uint8_t **fcp) -> int { const int r2 = write_stream(Es); *fcp = d_fc; return r2; });
+            if (rc != RSN_OK && rc != RSN_ERR_CAPACITY) return rc;
+            if (rc == RSN_OK) {
+                if ((size_t)e < S || e > Es) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: the head's chain left it at %u", e);
+                auto text = [](uint8_t *dst, uint32_t d, uint32_t l) { char t[24]; const int k = snprintf(t, sizeof t, "<%u,%u>", d, l); memcpy(dst, t, (size_t)k); return (uint32_t)k; };   // lzss.go:318-320
+                PeriodicTail pt{};
+                pt.out = d_out; pt.at = got;
+                const unsigned long long rem = (unsigned long long)n - e, r = rem % Wp;
+                pt.n_rep = rem / Wp;
+                pt.rep_len = text(pt.rep, Wp, Wp);
+                if (r) {                                                  // the last item: L = E - p < W (lzss.go:143: a token only if it is shorter than what it stands for)
+                    pt.last_len = text(pt.last, Wp, (uint32_t)r);
+                    if (pt.last_len >= r) { pt.last_len = (uint32_t)r; pt.raw = d_in + (n - (size_t)r); }
+                }
+                const unsigned long long tail = pt.n_rep * pt.rep_len + pt.last_len, total = got + tail;
+                *out_n = (size_t)total;
+                if (total > out_cap) { *out_n = round_up((size_t)total, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: output needs %llu bytes, buffer holds %zu", total, out_cap); }
+                const unsigned long long units = ((pt.at + tail + 15) >> 4) - (pt.at >> 4);
+                if (tail) RSN_LAUNCH("lzss_periodic_tail", k_periodic_tail, dim3((uint32_t)ceil_div((size_t)units, 256)), dim3(256), 0, s, pt);
+                RSN_HIP(hipStreamSynchronize(s));
+                return RSN_OK;
+            }
+            d_fc = nullptr;                                               // (the head alone outgrew the buffer: the whole call reports what it needs)
+        }
+    }
     // One pass takes a stream of up to SEC_MAX positions (32-bit positions, and ~10 bytes of scratch per position); a longer one goes
     // section by section (RSN_LZSS_SECTION_MIB: a smaller section, for the tests).
     static const size_t sec_env = [] { const char *e = getenv("RSN_LZSS_SECTION_MIB"); return e && atoi(e) > 0 ? (size_t)atoi(e) << 20 : (size_t)0; }();

@@ -82,11 +82,14 @@ static void helper_thread_calls(void (*fail_threads)(int), int refuse, uint8_t *
     int rc; size_t n;
     const size_t big = (size_t)160 << 20;
     uint8_t *text = make_text(big, 99u);
-    /* a stream large enough for the pipelined decode (>= 32 MiB), produced with threads available */
-    size_t cn; uint8_t *c = rsn_call(rsn_huffman_compress, text, (size_t)48 << 20, &cn, &rc); CHECK(rc == 0 && cn > ((size_t)32 << 20));
+    /* a stream large enough for the pipelined decode (>= 32 MiB), produced with threads available: 48 MiB of 7-bit noise -> 42 MiB */
+    const size_t nr = (size_t)48 << 20;
+    uint8_t *noise = malloc(nr);
+    { unsigned long long x = 0x9E3779B97F4A7C15ull; for (size_t i = 0; i < nr; i++) { x = x * 6364136223846793005ull + 1442695040888963407ull; noise[i] = (uint8_t)(x >> 57); } }
+    size_t cn; uint8_t *c = rsn_call(rsn_huffman_compress, noise, nr, &cn, &rc); CHECK(rc == 0 && cn > ((size_t)32 << 20));
     fail_threads(refuse);
     uint8_t *d = rsn_call(rsn_huffman_decompress, c, cn, &n, &rc);               /* piped_call -> no helper -> the serial call */
-    CHECK(rc == 0 && n == ((size_t)48 << 20) && memcmp(d, text, n) == 0); free(d);
+    CHECK(rc == 0 && n == nr && memcmp(d, noise, n) == 0); free(d); free(noise);
     uint8_t *l = rsn_call(lz_c, text, big, &n, &rc);                               /* the sectioned encode (>= 128 MiB) -> the serial call */
     CHECK(rc == 0 && n > 0 && n < big);
     if (keep[0]) CHECK(n == keep_n[0] && memcmp(l, keep[0], n) == 0); else { keep[0] = l; keep_n[0] = n; l = NULL; }
@@ -100,11 +103,16 @@ static void helper_thread_calls(void (*fail_threads)(int), int refuse, uint8_t *
         CHECK(rc == 0 && sn == out_lens[i] && memcmp(single, outs[i], sn) == 0);
         free(single); rsn_free(outs[i]);
     }
-    /* one stream from four slices: every slice but the caller's needs a thread -- refused: a code and a message, *out NULL */
+    /* one stream from four slices: every slice but the caller's needs a thread -- refused: a code and a message, *out NULL (helpers that
+     * are idle from an earlier round need no new thread: then the stream comes out, and is the single call's) */
     uint8_t *so = (uint8_t *)1; size_t son = 1;
     rc = rsn_huffman_compress_sharded(text, (size_t)8 << 20, 4, &so, &son);
-    if (refuse) CHECK(rc == RSN_ERR_NOMEM && so == NULL && son == 0 && strstr(rsn_last_error(), "helper"));
-    else { CHECK(rc == 0 && so != NULL); rsn_free(so); }
+    if (rc != 0) CHECK(refuse && rc == RSN_ERR_NOMEM && so == NULL && son == 0 && strstr(rsn_last_error(), "helper"));
+    else {
+        size_t sn; uint8_t *single = rsn_call(rsn_huffman_compress, text, (size_t)8 << 20, &sn, &rc);
+        CHECK(rc == 0 && so != NULL && sn == son && memcmp(single, so, sn) == 0);
+        free(single); rsn_free(so);
+    }
     /* 20 000 distinct runes: the header's text and the decoder's tables are side jobs -- on the caller's thread when refused */
     {
         enum { NR = 20000 };

@@ -7,8 +7,10 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <errno.h>
+#include <execinfo.h>
 #include <pthread.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 static volatile int g_fail = -1;
 static volatile long g_refused = 0;
@@ -22,4 +24,14 @@ int pthread_create(pthread_t *t, const pthread_attr_t *a, void *(*fn)(void *), v
     if (g_fail < 0) { const char *e = getenv("RSN_TEST_FAIL_THREADS"); g_fail = e && *e == '1'; }
     if (g_fail) { __sync_fetch_and_add(&g_refused, 1); return EAGAIN; }
     return real(t, a, fn, arg);
+}
+
+/* RSN_TEST_TRACE_THROW=1: where a C++ exception is thrown (the guard at the C boundary turns it into a code; this shows its origin) */
+void __cxa_throw(void *obj, void *tinfo, void (*dest)(void *)) {
+    static void (*real)(void *, void *, void (*)(void *)) __attribute__((noreturn));
+    if (!real) real = (void (*)(void *, void *, void (*)(void *)))dlsym(RTLD_NEXT, "__cxa_throw");
+    const char *e = getenv("RSN_TEST_TRACE_THROW");
+    if (e && *e == '1') { void *bt[32]; const int k = backtrace(bt, 32); backtrace_symbols_fd(bt, k, 2); }
+    real(obj, tinfo, dest);
+    abort();
 }

@@ -769,3 +769,72 @@ def test_a_storm_of_large_calls_queues_instead_of_failing(oracle):
     import re
     needs = [float(x) for x in re.findall(r"needs ([0-9.]+) GiB of scratch", r.stderr)]
     assert needs and max(needs) >= 1.10, needs
+
+
+def _periodic_cases():
+    rng = np.random.default_rng(606)
+    blk = bytes(rng.integers(0, 254, size=4096, dtype=np.uint8).tolist())
+    blk = blk.replace(b"\\", b"a").replace(b"\xff", b"b")               # (config 3's block: nothing that needs an escape; '<' may occur)
+    blk = blk[:100] + b"<" + blk[101:2000] + b"<<" + blk[2002:]
+    assert len(blk) == 4096
+    small = bytes(rng.integers(97, 123, size=256, dtype=np.uint8).tolist())
+    return {
+        "config 3's shape": (blk * 700, 4096),
+        "a remainder that goes out as a token": (blk * 300 + blk[:1234], 4096),
+        "a remainder of three raw bytes, one of them a '<'": (blk * 300 + blk[:99] + b"<ab", 4096),
+        "a remainder of one byte": (blk * 260 + blk[:1], 4096),
+        "text in front of the period": (text(9, 200000) + blk * 400, 4096),
+        "a head that ends inside a tile": (text(10, 70001) + blk * 400 + blk[:77], 4096),
+        "window 256, period 256": (small * 9000, 256),
+        "window 1024, period 256 (the period divides the window)": (small * 9000, 1024),
+        "the period breaks in the last quarter (no tail there)": (blk * 300 + b"!" + blk * 100, 4096),
+        "two periods, the second to the end": (blk * 100 + blk[::-1] * 300, 4096),
+        "period 4096 under window 2048 (nothing repeats inside the window)": (blk * 60, 2048),
+    }
+
+
+def test_periodic_tail_is_the_oracles_stream(lz, oracle):
+    """r06: a stream that repeats with the window's length from some chunk on is encoded as its head + arithmetic (k_periodic_tail)
+    and decoded as its head + out[q] = out[q - P] (k_lzd_run_fill).  Both against the oracle, byte for byte, over the shapes the
+    arithmetic has to get right: remainders that become a token / raw bytes / nothing, '<' in the repeated block, heads of text,
+    other windows, a break late in the stream, a second period."""
+    for name, (data, w) in _periodic_cases().items():
+        want = oracle.lzss_compress(data, w)
+        got = lz.CompressAsync(data, False, w)
+        assert got == want, name
+        assert lz.Decompress(got) == data, name
+
+
+def test_periodic_tail_switches_give_the_same_bytes(oracle):
+    """... and the same streams through the whole pipeline / the ordinary decoder (RSN_LZSS_NO_PERIODIC_TAIL, RSN_LZSS_DEC_NO_RUN_TAIL:
+    read once per process), plus hand-written streams that end in a token run only a foreign encoder writes: periods that are not
+    the window, a run in front of which nothing stands (an error either way), a last item that is a token with another distance."""
+    import hashlib
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    cases = _periodic_cases()
+    rng = np.random.default_rng(33)
+    lit = bytes(rng.integers(97, 123, size=70000, dtype=np.uint8).tolist())
+    foreign = [lit + b"<5,5>" * 300000, lit + b"<4096,4096>" * 400 + b"<777,700>", lit + b"<8192,8192>" * 300 + b"tail\xff!",
+               lit[:3000] + b"<3000,3000>" * 500, lit + b"<7,7>" * 10 + lit[:50] + b"<100,100>" * 20000 + b"<100,3>",
+               lit + b"<9000,9000>" * 200]                                 # (a period above what the fill kernel keeps: the ordinary path)
+    bad = [b"<4096,4096>" * 100000, lit[:100] + b"<4096,4096>" * 100000]  # the run's first token points before the data (lzss.go:350)
+    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import lz, RsnError\n"
+            "datas, streams, bad = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "out = [hashlib.sha256(lz.CompressAsync(d, False, w)).hexdigest() for d, w in datas] + [hashlib.sha256(lz.Decompress(c)).hexdigest() for c in streams]\n"
+            "for b in bad:\n"
+            "    try:\n        lz.Decompress(b); out.append('no error')\n"
+            "    except RsnError as e:\n        out.append('error %%d' %% e.code)\n"
+            "print('|'.join(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    streams = [oracle.lzss_compress(d, w) for d, w in cases.values()] + foreign
+    want = [hashlib.sha256(c).hexdigest() for c in streams[:len(cases)]] + [hashlib.sha256(oracle.lzss_decompress(c)).hexdigest() for c in streams]
+    want += ["error -3"] * len(bad)
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump((list(cases.values()), streams, bad), f)
+        f.flush()
+        for env in ({}, {"RSN_LZSS_NO_PERIODIC_TAIL": "1", "RSN_LZSS_DEC_NO_RUN_TAIL": "1"}):
+            out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            assert out.returncode == 0, out.stderr[-2000:]
+            assert out.stdout.strip().splitlines()[-1].split("|") == want, (env, out.stdout[-600:])
