@@ -243,7 +243,7 @@ struct TileChain { uint32_t entry, exit, walked, pad; };   // where the block's 
 // 80 SGPRs (it has 58): above that a CU holds one of its 16-wavefront blocks instead of two, and the walk halves
 // in speed -- which is also why the in-tile parse is a kernel of its own (k_chain_tail) and not this one's epilogue.
 struct ChainTail { uint32_t *heavy, *dense; TileChain *tchain; uint8_t *dump; const uint32_t *redo_list; uint32_t *n_dense; uint32_t *step; const uint32_t *redo_start; uint32_t *ckeys, *ckn; };   // ckeys / ckn: the keys of a tile's claimed positions, in position order, and how many (k_chain_serial's input; may be null)   // redo_list: the tiles of a partial launch (ChainArgs::redo & 2); n_dense: counts the tiles that gave up as dense (may be null)
-struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; unsigned long long *stats; ChainTail tail; };   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
+struct ChainArgs { const uint8_t *fc; uint32_t E; uint32_t W; uint32_t *keys; uint32_t redo; uint32_t pfrom; unsigned long long *stats; ChainTail tail; };   // pfrom: every position from here on repeats the W bytes before it as far as a match may reach (the head of a W-periodic input, lzss_encode_admitted): its key is arithmetic; 0xFFFFFFFF: none   // redo: bit 0 = no density test (second look), bit 1 = tiles from tail.redo_list
 // k_match_chain's record of a claimed position: .x its key, .y = next record (14 bits) | position from t0 - CH (14 bits) << 14
 // (what the position puts into the output -- a token's text or the bytes themselves -- is worked out by the reader: here it would cost
 //  the walk's kernel what it saves the reader)
@@ -565,6 +565,14 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     mine = row_ballot<LW>(leader && ((old >> (kp & 31)) & 1), lane) == 0;
                 }
                 if (!mine) kp = 0xFFFFFFFFu;
+            }
+            // a position in the W-periodic rest of the head's stream (r06): key (min(W, E - p), W) whatever the bytes are -- k_tile_periodic's
+            // argument, position by position (searched, each start in config 3's second half-tile verifies a 4 KiB match through memory)
+            if (mine && (uint32_t)(t0 - CH) + kp >= a.pfrom) {
+                const uint32_t ipos = (uint32_t)(t0 - CH) + kp, L = min(W, E - ipos);
+                if (leader) a.keys[ipos] = (L << 16) | W;
+                next = kp + L; visits++;
+                mine = false;
             }
             // (what 3. needs of the position it works out again from kp: fewer registers live across the rounds -- the kernel has 64)
             uint32_t nrows = 0, irel = 0, capE = 0, tag = 0, lo = 0, hi = 0;
@@ -1857,7 +1865,7 @@ size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
 // time one of them is about to run the callback writes that copy and returns it.
 static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32_t E, uint32_t W, const uint8_t *d_same, uint32_t Wp, bool copied,
                               bool halo, uint32_t stop_tile, uint8_t *d_out, size_t out_cap, size_t *out_n, uint32_t *exit_pos,
-                              const std::function<int(const uint8_t **)> &materialize = {}) {
+                              const std::function<int(const uint8_t **)> &materialize = {}, uint32_t pfrom = 0xFFFFFFFFu) {
     void *p; int rc;
     bool raw = (bool)materialize;
     auto need_copy = [&]() -> int { if (!raw) return RSN_OK; raw = false; return materialize(&d_fc); };
@@ -1935,7 +1943,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
         RSN_HIP(hipMemsetAsync(d_ttot, 0, 32, s));
         RSN_LAUNCH("lzss_sample", k_sample_tiles, dim3(1), dim3(SAMPLE_TILES), 0, s, d_redo_list, SAMPLE_TILES, n_pt);
-        ChainArgs hs{d_fc, E, W, d_keys, 2u | halo_bit | (raw ? 8u : 0u), nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
+        ChainArgs hs{d_fc, E, W, d_keys, 2u | halo_bit | (raw ? 8u : 0u), pfrom, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, d_redo_list, (uint32_t *)(d_ttot + 3), d_step, d_redo_start, nullptr, nullptr}};
         rc = launch_chain("lzss_sample", SAMPLE_TILES, hs); if (rc) return rc;
         RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
@@ -1957,7 +1965,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
             if (!no_ckeys && (n_pt >= 32768 || tail_serial)) d_ckn = d_ccnt + n_pt;
         }
-        ChainArgs ha{d_fc, E, W, d_keys, halo_bit | (raw ? 8u : 0u), nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
+        ChainArgs ha{d_fc, E, W, d_keys, halo_bit | (raw ? 8u : 0u), pfrom, nullptr, ChainTail{d_heavy, d_dense, d_tchain, d_dump, nullptr, nullptr, d_step, d_redo_start, d_ckn ? d_clist : nullptr, d_ckn}};
         rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
         static_assert(CC::CT == PT, "the chain walk's tiles are the parse tiles");
         static const bool no_fused = getenv("RSN_LZSS_NO_FUSED_PARSE") != nullptr;   // A/B switch: always the general parse
@@ -2232,7 +2240,8 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
             const uint32_t Es = (uint32_t)(S + Wp), stop_tile = (uint32_t)(S / PT);  // (W bytes of look-ahead behind the last head position: a match that begins in the head may end there)
             size_t got = 0; uint32_t e = 0;
             rc = lzss_encode_stream(c, s, d_in, Es, Wp, d_same, Wp, true, false, stop_tile, d_out, out_cap, &got, &e,
-                                    [&](const uint8_t **fcp) -> int { const int r2 = write_stream(Es); *fcp = d_fc; return r2; });
+                                    [&](const uint8_t **fcp) -> int { const int r2 = write_stream(Es); *fcp = d_fc; return r2; },
+                                    (uint32_t)std::max(unlike_end, (size_t)ESC_TILE));
             if (rc != RSN_OK && rc != RSN_ERR_CAPACITY) return rc;
             if (rc == RSN_OK) {
                 if ((size_t)e < S || e > Es) return c.fail(RSN_ERR_DEVICE, "lzss: internal error: the head's chain left it at %u", e);
