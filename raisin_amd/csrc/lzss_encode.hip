@@ -497,7 +497,10 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     if (list_entry >> 31) kp_first = chain_tail().redo_start[blockIdx.x] - (uint32_t)(t0 - CH);   // the true entry as k_chain_verify worked it out: the tile before's exit, or a whole-distance stretch's arithmetic
     // (a tile of a whole-distance stretch walked from its predicted entry: the chain is two or three visits long, and the other 64
     //  starts would each verify a 4 KiB match for nothing -- should the prediction be wrong, the one chain walks the tile alone)
-    const uint32_t nitems = (list_entry & 0x40000000u) ? 1u : 1 + (npos + CS - 1) / CS;
+    // (the head of a W-periodic input -- pfrom set -- is two or three tiles that a whole call waits for, the first of them incompressible:
+    //  a start every 32 positions there, so that every row of the block has a stretch of it to walk -- config 3's head 0.22 -> ? ms)
+    const uint32_t cs = a.pfrom != 0xFFFFFFFFu ? 32u : (uint32_t)CS;
+    const uint32_t nitems = (list_entry & 0x40000000u) ? 1u : 1 + (npos + cs - 1) / cs;
     // a wavefront that gives up (s_heavy) also pushes the start counter past every item: the others
     // finish the chain they are on (at most CS-odd positions) and find nothing more to start
     constexpr uint32_t GIVE_UP = 0x40000000u;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     if (leader) kq = atomicAdd(&s_next, 1u);
                     kq = row_read<LW>(kq, 0, lane);
                     alive = kq < nitems;
-                    kp = kq == 0 ? kp_first : CH + (kq - 1) * CS;
+                    kp = kq == 0 ? kp_first : CH + (kq - 1) * cs;
                     visits = 0; from_kp = kp;
                 }
                 if (alive) {
