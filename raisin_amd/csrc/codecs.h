@@ -42,6 +42,9 @@ int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int
 // *out: the result in the context's pinned staging (valid until the thread's next call), for the caller to copy
 int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
 int huff_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
+// host buffers of at most 2 KiB (lzss_small.hip): one launch of one block each way, no copy command; 1 = not for this path
+int lzss_small_compress(Ctx &c, const uint8_t *in, size_t n, int64_t window, const uint8_t **out, size_t *out_n);
+int lzss_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
 // exclusive scan of n counts on the stream (huff_encode.hip); *total (may be null) receives the sum; in and out must not overlap

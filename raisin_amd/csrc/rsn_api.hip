@@ -697,6 +697,12 @@ static int rsn_lzss_compress_impl(const uint8_t *in, size_t n, int64_t window, u
     // which nothing needs an escape (so the output is at most the input): the encoder checks the input as it lands and lets the first output
     // byte go only when it has seen the last input byte (the upload is done well before the encoder is); an input with a 5C or an FF in it,
     // and every call under RSN_HOST_SERIAL=1, takes the serial call.
+    if (in && out && out_n && n <= 1024) {                                // (the reference's own table is files of 13-25 bytes, README.md:153-167: one launch, lzss_small.hip)
+        Ctx &c = ctx(); const uint8_t *p = nullptr; size_t got = 0;
+        *out = nullptr; *out_n = 0;
+        const int rc = small_result(c, lzss_small_compress(c, in, n, window, &p, &got), p, got, out, out_n);
+        if (rc != 1) return rc;
+    }
     static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;
     if (!serial && in && out && out_n && n >= ((size_t)128 << 20) && window > 0 && window <= 4096) {
         const size_t sec = std::min((size_t)256 << 20, n / 4);            // (eight sections instead of four: the same 46 ms per GiB -- half a millisecond of fixed cost per section)
@@ -736,6 +742,12 @@ static int rsn_lzss_compress_legacy_impl(const uint8_t *in, size_t n, int64_t wi
 }
 
 static int rsn_lzss_decompress_impl(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    if (in && out && out_n && n <= 2048) {                                // (lzss_small.hip: one launch; what it does not take -- malformed, large output -- goes on below)
+        Ctx &c = ctx(); const uint8_t *p = nullptr; size_t got = 0;
+        *out = nullptr; *out_n = 0;
+        const int rc = small_result(c, lzss_small_decompress(c, in, n, &p, &got), p, got, out, out_n);
+        if (rc != 1) return rc;
+    }
     // (the decoder asks for 4 bytes per escaped byte from 64 MiB of them up, lzss_decode.hip: stated for an expansion of two -- text is 1.5;
     //  a stream that expands further decodes inside this admission all the same)
     return host_call(in, n, out, out_n, 8 * n + (1 << 16), n < ((size_t)32 << 20) ? 0 : 8 * n,
