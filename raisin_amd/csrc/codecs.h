@@ -47,6 +47,10 @@ int lzss_small_compress(Ctx &c, const uint8_t *in, size_t n, int64_t window, con
 int lzss_small_decompress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n);
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n);
 
+// the decoder in SLICES as the stream lands (a host-buffer call, rsn_api.hip): 1 = not a stream for it (a 5C, huge tokens): the caller decodes it whole;
+// RSN_ERR_CAPACITY: it expands beyond out_cap (what the caller's sample promised)
+int lzss_decode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream &st);
+
 // exclusive scan of n counts on the stream (huff_encode.hip); *total (may be null) receives the sum; in and out must not overlap
 int scan_u64(Ctx &c, hipStream_t s, const char *name, const unsigned long long *in, unsigned long long *out, uint32_t n, unsigned long long *total);
 

@@ -443,17 +443,18 @@ __global__ __launch_bounds__(ZB) void k_lzd_tiles(const uint8_t *__restrict__ in
 //     ONE span -- k_lzd_tilemap, one wavefront per tile.
 // A span that produces 65535 bytes or more (a foreign stream with huge tokens) raises flags[5]: the host then runs k_lzd_tiles as before.
 __global__ __launch_bounds__(ZB) void k_lzd_count2(const uint8_t *__restrict__ in, size_t n, unsigned long long *__restrict__ blk_len, uint16_t *__restrict__ span_out,
-                                                   unsigned long long *__restrict__ need, uint32_t *__restrict__ maxptr, int *__restrict__ flags) {
+                                                   unsigned long long *__restrict__ need, uint32_t *__restrict__ maxptr, int *__restrict__ flags, uint32_t b0 = 0) {
+    const uint32_t bx = blockIdx.x + b0;                                  // (b0: the first block of a slice of the stream, lzss_decode_sliced)
     __shared__ __attribute__((aligned(16))) uint32_t sw[(ZTILE + 2 * ZPAD) / 4 + 8];
     __shared__ uint32_t masks[ZB + 3], cdm[ZB + 3];
     __shared__ unsigned long long wsum[ZB / 64], wneed[ZB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     Span r;
-    const int valid = stage_block(in, n, (size_t)blockIdx.x * ZTILE, sw, masks, cdm, r);
+    const int valid = stage_block(in, n, (size_t)bx * ZTILE, sw, masks, cdm, r);
     unsigned long long mine = 0;
     int e = 0;
     if (valid) { span_parse(sw, masks, cdm, tid, ZPAD + 16 * tid, valid, r); mine = r.out; if (r.err) e = 1; }
-    span_out[(size_t)blockIdx.x * ZB + tid] = (uint16_t)min(mine, 0xFFFFull);
+    span_out[(size_t)bx * ZB + tid] = (uint16_t)min(mine, 0xFFFFull);
     if (mine >= 0xFFFFull) e |= 4;
     if (__ballot(valid && mask_5c(r.w) != 0) && lane == 0 && __atomic_load_n(&flags[4], __ATOMIC_RELAXED) == 0) atomicOr(&flags[4], 1);
     unsigned long long incl = mine;
@@ -485,8 +486,8 @@ __global__ __launch_bounds__(ZB) void k_lzd_count2(const uint8_t *__restrict__ i
     if (e & 4) atomicOr(&flags[5], 1);
     __syncthreads();
     if (tid == 0) {
-        blk_len[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        need[blockIdx.x] = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
+        blk_len[bx] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        need[bx] = max(max(wneed[0], wneed[1]), max(wneed[2], wneed[3]));
     }
 }
 
@@ -1650,6 +1651,108 @@ int lzss_decode_sections(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, u
 
 int lzss_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n) {
     return lzss_decode_impl(c, s, d_in, n, d_out, out_cap, out_n, nullptr);
+}
+
+// ---------------------------------------------------------------- a host-buffer decode in SLICES as the stream lands (r06)
+// rsn_lzss_decompress was upload (12 ms per GiB of text's 0.7 GB stream), decoder (5), download (19), one after the other.  PCIe is full
+// duplex: here the stream is decoded slice by slice as its pieces land, each slice's bytes on their way down while the next ones come up
+// and decode.  A slice is what lzss_decode_sections calls a section -- the escaped bytes in front of it, as many as the largest back-pointer
+// so far reaches, then its tokens: the escaped stream holds no '<' (lzss.go:373-377), so the prefix parses as literals and every pointer
+// finds what it points at -- expanded by the ordinary decoder into the escaped stream's buffer, then mapped FF -> '<' into the output
+// (all DecodeOpeningSymbols does in a stream without a 5C, lzss.go:391-406).  What the slices cannot know is the TOTAL: the caller sizes
+// the output from a sample of the stream (rsn_api.hip: the first 256 KiB, parsed on the host) and takes the serial call when a slice would overflow it (RSN_ERR_CAPACITY) -- or when a 5C turns
+// up (returns 1: bytes already announced were announced unescaped).  Cuts fall on item boundaries behind 4 KiB block starts.
+__global__ __launch_bounds__(256) void k_lzd_map_ff(const uint8_t *__restrict__ esc, uint8_t *__restrict__ out, unsigned long long lo, unsigned long long hi) {
+    const unsigned long long b0 = ((lo >> 4) + (unsigned long long)blockIdx.x * 256 + threadIdx.x) << 4;   // this thread's 16-byte unit (both buffers are 16-byte aligned)
+    if (b0 >= hi) return;
+    if (b0 >= lo && b0 + 16 <= hi) {
+        uint4 v = *reinterpret_cast<const uint4 *>(esc + b0);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                                     // FF -> 3C: clear bits 0, 1, 6, 7 of every byte that is FF
+            const uint32_t t = ~w[k], z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 where the byte of w is FF
+            w[k] &= ~((z >> 7) * 0xC3u);
+        }
+        *reinterpret_cast<uint4 *>(out + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else for (int k = 0; k < 16; k++) { const unsigned long long q = b0 + k; if (q >= lo && q < hi) { const uint8_t b = esc[q]; out[q] = b == 0xFF ? (uint8_t)0x3C : b; } }
+}
+
+int lzss_decode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_t *d_out, size_t out_cap, size_t *out_n, const SliceStream &st) {
+    *out_n = 0;
+    if (n == 0 || n >= (1ull << 32) - 65536 || out_cap >= (1ull << 32) - 65536) return 1;
+    void *p; int rc;
+    const uint32_t n_cb = (uint32_t)ceil_div(n, (size_t)ZTILE);
+    const size_t SL = std::max<size_t>(st.slice_bytes / ZTILE, 16) * ZTILE;
+    rc = dev_buf(c, 15, out_cap + 64, &p); if (rc) return rc;
+    uint8_t *d_esc = (uint8_t *)p;
+    void *hp; rc = pinned_buf(c, 256, &hp); if (rc) return rc;
+    size_t c0 = 0, e0 = 0, hmax = 0, sec_buf = 0;
+    uint32_t b0 = 0;
+    uint8_t *d_v = nullptr;
+    while (b0 < n_cb) {
+        const uint32_t b1 = (uint32_t)std::min<size_t>(n_cb, (size_t)b0 + SL / ZTILE);
+        const size_t q1 = b1 == n_cb ? n : (size_t)b1 * ZTILE, avail = std::min(n, q1 + 64);   // (a token that begins in front of q1 ends before q1 + 24)
+        if (!st.need_in(avail)) return c.fail(RSN_ERR_DEVICE, "lzss: the upload of a sliced call failed");
+        // ---- the slice's counts: its escaped length, its largest back-pointer, is there a 5C (the decoder below validates the tokens itself)
+        rc = dev_buf(c, 13, ((size_t)n_cb * 2 + 5) * 8, &p); if (rc) return rc;
+        unsigned long long *d_blen = (unsigned long long *)p, *d_boff = d_blen + n_cb, *d_btot = d_boff + n_cb;
+        int *d_flag = (int *)(d_btot + 1);
+        rc = dev_buf(c, 27, (size_t)n_cb * ZB * 2 + (size_t)n_cb * 8 + 64, &p); if (rc) return rc;
+        unsigned long long *d_need = (unsigned long long *)p; uint16_t *d_span = (uint16_t *)(d_need + n_cb);
+        RSN_HIP(hipMemsetAsync(d_flag, 0, 24, s));
+        RSN_LAUNCH("lzss_dec_count", k_lzd_count2, dim3(b1 - b0), dim3(ZB), 0, s, d_in, avail, d_blen, d_span, d_need, (uint32_t *)(d_flag + 2), d_flag, b0);
+        rc = scan_u64(c, s, "lzss_dec_scan", d_blen + b0, d_boff + b0, b1 - b0, d_btot); if (rc) return rc;
+        unsigned long long *h64 = (unsigned long long *)hp;
+        volatile int *hflag = (volatile int *)(h64 + 1);
+        uint8_t *hcut = (uint8_t *)(h64 + 8);
+        const size_t cut_lo = q1 >= (size_t)MAXTOK ? q1 - MAXTOK : 0, cut_hi = std::min(n, q1 + MAXTOK);
+        RSN_HIP(hipMemcpyAsync(h64, d_btot, 8, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipMemcpyAsync((void *)hflag, d_flag, 24, hipMemcpyDeviceToHost, s));
+        if (b1 < n_cb) RSN_HIP(hipMemcpyAsync(hcut, d_in + cut_lo, cut_hi - cut_lo, hipMemcpyDeviceToHost, s));
+        RSN_HIP(hipStreamSynchronize(s));
+        if (hflag[0] & 1) return c.fail(RSN_ERR_FORMAT, "lzss: malformed \"<ptr,len>\" token");
+        if (hflag[0] & 2) return c.fail(RSN_ERR_FORMAT, "lzss: back-reference outside the decoded data (reference: slice bounds out of range, lzss.go:350)");
+        if (hflag[4] || hflag[5]) return 1;                               // a 5C: the stream needs DecodeOpeningSymbols' pass; a huge token: the serial decoder's other front end
+        const size_t e1 = e0 + (size_t)h64[0];
+        hmax = std::max(hmax, (size_t)(uint32_t)hflag[2]);
+        if (e1 > out_cap) { *out_n = round_up(e1, 16) + 16; return c.fail(RSN_ERR_CAPACITY, "lzss: the stream expands beyond the %zu bytes its sample promised", out_cap); }
+        if (hmax + 16 > ((size_t)1 << 30)) return 1;
+        // the first item that starts at or after q1 (lzss_decode_sections' item_start, from the bytes around the cut)
+        size_t c1 = q1;
+        if (b1 < n_cb) {
+            for (size_t k = q1; k-- > cut_lo;) {
+                if (hcut[k - cut_lo] == '>') break;
+                if (hcut[k - cut_lo] == '<') {
+                    size_t e = k + 1;
+                    while (e < cut_hi && hcut[e - cut_lo] != '>') e++;
+                    if (e >= cut_hi) return c.fail(RSN_ERR_DEVICE, "lzss: a token without its end at a slice cut");
+                    c1 = std::max(q1, e + 1);
+                    break;
+                }
+            }
+        }
+        // ---- the slice as a stream of its own: the escaped bytes in front (16-byte aligned destination), then its items
+        const size_t W = e0 <= hmax ? e0 : hmax + ((e0 - hmax) & 15);
+        const size_t vn = W + (c1 - c0);
+        if (vn + 64 > sec_buf) { sec_buf = vn + 64 + (vn >> 3); rc = dev_buf(c, 36, sec_buf, &p); if (rc) return rc; d_v = (uint8_t *)p; }
+        if (W) RSN_HIP(hipMemcpyAsync(d_v, d_esc + (e0 - W), W, hipMemcpyDeviceToDevice, s));
+        if (c1 > c0) RSN_HIP(hipMemcpyAsync(d_v + W, d_in + c0, c1 - c0, hipMemcpyDeviceToDevice, s));
+        RSN_HIP(hipMemsetAsync(d_v + vn, 0, 64, s));
+        size_t got = 0;
+        if (vn) {
+            rc = lzss_decode_impl(c, s, d_v, vn, nullptr, 0, &got, d_esc + (e0 - W)); if (rc) return rc;
+            if (got != W + (e1 - e0)) return c.fail(RSN_ERR_DEVICE, "lzss: a slice expands to %zu bytes, its counting pass says %zu", got, W + (e1 - e0));
+        }
+        if (e1 > e0) {
+            const unsigned long long units = (((unsigned long long)e1 + 15) >> 4) - (e0 >> 4);
+            RSN_LAUNCH("lzss_dec_map", k_lzd_map_ff, dim3((uint32_t)ceil_div((size_t)units, (size_t)256)), dim3(256), 0, s, (const uint8_t *)d_esc, d_out, (unsigned long long)e0, (unsigned long long)e1);
+            RSN_HIP(hipStreamSynchronize(s));
+            if (!st.have_out(e0, e1 - e0)) return c.fail(RSN_ERR_DEVICE, "lzss: the download of a sliced call failed");
+        }
+        b0 = b1; c0 = c1; e0 = e1;
+    }
+    *out_n = e0;
+    return RSN_OK;
 }
 
 }  // namespace rsn

@@ -748,6 +748,43 @@ static int rsn_lzss_decompress_impl(const uint8_t *in, size_t n, uint8_t **out, 
         const int rc = small_result(c, lzss_small_decompress(c, in, n, &p, &got), p, got, out, out_n);
         if (rc != 1) return rc;
     }
+    // From 64 MiB up: the pipeline (piped_call + lzss_decode_sliced, r06) -- the stream is decoded slice by slice as its pieces land, every
+    // slice's bytes on their way down while the next ones come up.  The result block must exist before the first byte is decoded and the
+    // stream does not say how long it is (lzss.go:323-364 appends as it goes): the first 256 KiB are parsed HERE, on the host (4 MiB took 4 ms of a 27 ms call), and the
+    // expansion they show + 15 % + 32 MiB is what is allocated; a stream that outgrows that, or holds a 5C, or whose sample has a token the
+    // parser does not take, is decoded by the serial call below (which also words the errors).
+    static const bool serial = getenv("RSN_HOST_SERIAL") != nullptr;
+    if (!serial && in && out && out_n && n >= ((size_t)64 << 20)) {
+        const size_t sample = std::min(n, (size_t)256 << 10);
+        unsigned long long esc = 0; size_t i = 0; bool ok = true;
+        while (i < sample && ok) {
+            const uint8_t b = in[i];
+            if (b == 0x5C) ok = false;
+            else if (b != '<') { esc++; i++; }
+            else {
+                size_t q = i + 1; unsigned long long ptr = 0, len = 0; int nd = 0;
+                while (q < n && nd < 10 && in[q] >= '0' && in[q] <= '9') { ptr = ptr * 10 + (in[q] - '0'); q++; nd++; }
+                ok = nd && q < n && in[q] == ','; q++; nd = 0;
+                while (ok && q < n && nd < 10 && in[q] >= '0' && in[q] <= '9') { len = len * 10 + (in[q] - '0'); q++; nd++; }
+                ok = ok && nd && q < n && in[q] == '>' && len <= ptr;
+                esc += len; i = q + 1;
+            }
+        }
+        if (ok && i > 0) {
+            const double ratio = (double)esc / (double)i;
+            const size_t cap = (size_t)((double)n * ratio * 1.15) + ((size_t)32 << 20);
+            if (cap < ((size_t)1 << 32) - ((size_t)1 << 20)) {
+                const size_t slice = (size_t)64 << 20;
+                const int rc = piped_call(in, n, cap, cap + 10 * (size_t)((double)slice * ratio) + ((size_t)64 << 20), out, out_n,
+                                          [n](Ctx &c, hipStream_t s, const uint8_t *di, uint8_t *dout, size_t ocap, size_t *got, const SliceStream *st) {
+                                              SliceStream mine = *st;
+                                              mine.slice_bytes = slice;
+                                              return lzss_decode_sliced(c, s, di, n, dout, ocap, got, mine);
+                                          });
+                if (rc != 1) return rc;
+            }
+        }
+    }
     // (the decoder asks for 4 bytes per escaped byte from 64 MiB of them up, lzss_decode.hip: stated for an expansion of two -- text is 1.5;
     //  a stream that expands further decodes inside this admission all the same)
     return host_call(in, n, out, out_n, 8 * n + (1 << 16), n < ((size_t)32 << 20) ? 0 : 8 * n,

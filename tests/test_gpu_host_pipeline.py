@@ -105,3 +105,42 @@ def test_pipelined_lzss_compress_is_the_serial_compress(oracle):
     c = lz.CompressAsync(lt)
     assert lz.Decompress(c) == lt
     assert c[: 1 << 20] == oracle.lzss_compress(lt[: 3 << 20])[: 1 << 20]        # (and the oracle's, where it can be had in seconds)
+
+
+def test_pipelined_lzss_decompress_is_the_serial_decompress(oracle):
+    """rsn_lzss_decompress from 64 MiB up (r06): the stream decoded slice by slice as it lands (lzss_decode_sliced), the result block sized
+    from a host-side parse of the first 4 MiB.  The serial call's bytes (RSN_HOST_SERIAL=1, a process of its own) on text's stream, on a
+    stream whose expansion GROWS behind the sample (text, then a period: the slices outgrow the block -- the serial call answers), on one that
+    shrinks, on streams with a 5C early and late (escapes: the serial call), on a hand-made stream whose tokens straddle the slice cuts, and a
+    malformed token late in the stream (an error either way)."""
+    import pickle
+    import tempfile
+    import workloads as W
+    from raisin_amd import RsnError, lz
+    n = 150 << 20
+    text = bytes(W.config_input("4", n).numpy())
+    ctext = lz.CompressAsync(text)
+    per = bytes(range(33, 127)) * 44
+    grow = lz.CompressAsync(text[: 100 << 20] + (per * ((400 << 20) // len(per) + 1))[: 400 << 20])
+    shrink = lz.CompressAsync((per * ((100 << 20) // len(per) + 1))[: 100 << 20] + text)
+    esc_early = lz.CompressAsync(b"\\" + text[1:])
+    esc_late = lz.CompressAsync(text[:-5] + b"\xff" + text[-4:])
+    unit = b"0123456789abcdefghijklmnopqrstuvwxyz" * 3 + b"<108,108>" + b"<7,7>" + b"Q"          # tokens at every alignment against the 4 KiB blocks and the 64 MiB cuts
+    straddle = unit * ((70 << 20) // len(unit))
+    streams = {"text": ctext, "grow": grow, "shrink": shrink, "esc_early": esc_early, "esc_late": esc_late, "straddle": straddle}
+    assert all(len(v) >= (64 << 20) for v in streams.values()), {k: len(v) >> 20 for k, v in streams.items()}
+    got = {k: hashlib.sha256(lz.Decompress(v)).hexdigest() for k, v in streams.items()}
+    assert lz.Decompress(ctext) == text
+    code = ("import sys, hashlib, pickle; sys.path.insert(0, %r)\nfrom raisin_amd import lz\n"
+            "streams = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "print(' '.join(k + ':' + hashlib.sha256(lz.Decompress(v)).hexdigest() for k, v in sorted(streams.items())))\n" % ROOT)
+    with tempfile.NamedTemporaryFile(suffix=".pkl") as f:
+        pickle.dump(streams, f)
+        f.flush()
+        out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=900, env=dict(os.environ, RSN_HOST_SERIAL="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == " ".join(k + ":" + v for k, v in sorted(got.items()))
+    bad = ctext[: 100 << 20] + b"<12,x>" + ctext[100 << 20:]
+    with pytest.raises(RsnError) as e:
+        lz.Decompress(bad)
+    assert e.value.code == -3
