@@ -169,14 +169,18 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
 #pragma unroll
         for (int k = 0; k <= ESC_RUN; k++) v[k] = p[(k - 1) * (ESC_TILE / 16)];
         uint32_t same_bits = 0, special = 0, lt = 0;
+        // (r06: "is there a byte equal to X" as an ACCUMULATED zero-byte test -- (t - 0x01010101) & ~t has bit 7 of a byte set iff that byte
+        //  of t = w ^ XXXX is zero or lies above one that is: exact for existence, four instructions a value and dword instead of seven)
+        auto zacc = [](uint32_t w, uint32_t x4) { const uint32_t t = w ^ x4; return (t - 0x01010101u) & ~t; };
 #pragma unroll
         for (int k = 1; k <= ESC_RUN; k++) {
             const uint32_t d = (v[k].x ^ v[k - 1].x) | (v[k].y ^ v[k - 1].y) | (v[k].z ^ v[k - 1].z) | (v[k].w ^ v[k - 1].w);
             same_bits |= (d == 0 ? 1u : 0u) << (k - 1);
             const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); lt |= bytes_equal(w[j], 0x3Cu); }
+            for (int j = 0; j < 4; j++) { special |= zacc(w[j], 0x5C5C5C5Cu) | zacc(w[j], 0xFFFFFFFFu); lt |= zacc(w[j], 0x3C3C3C3Cu); }
         }
+        special &= 0x80808080u; lt &= 0x80808080u;
         __shared__ uint32_t s_and[LB / 64], s_any[LB / 64];
         uint32_t wave_and = 0;
 #pragma unroll
