@@ -75,7 +75,7 @@ TRACE_CANDIDATES = {
     "lzss_tok_emit": ["k_tok_emit"], "lzss_esc_write": ["k_esc_try", "k_esc_write"], "lzss_esc_check": ["k_esc_try"], "lzss_tile_periodic": ["k_tile_periodic"],
     "lzss_chain_tail": ["k_chain_serial", "k_chain_tail"], "lzss_dec_resolve": ["k_lzd_resolve"], "lzss_dec_emit": ["k_lzd_emit"],
     "lzss_dec_count": ["k_lzd_count2", "k_lzd_count"], "lzss_dec_compose": ["k_lzd_compose"], "lzss_dec_runs": ["k_lzd_runs"],
-    "lzss_dec_lit": ["k_lzd_lit"], "lzss_dec_patch": ["k_lzd_patch"],
+    "lzss_dec_lit": ["k_lzd_lit"], "lzss_dec_patch": ["k_lzd_patch"], "lzss_dec_run_fill": ["k_lzd_run_fill"], "lzss_periodic_tail": ["k_periodic_tail"],
 }
 PMC_LABEL = {"2b": "2b", "skewed": "skewed", "3": "config3", "4": "config4", "5": "5", "headline": "headline"}
 
@@ -304,7 +304,7 @@ def run_other_configs(torch, device, n, cores, with_cpu, names):
         if name in ("3", "4"):
             lc = sizes[0]                                   # the LZSS stream
             kalg.update({"lzss_tok_emit": n + lc, "lzss_esc_write": n, "lzss_esc_check": n, "lzss_tile_periodic": n, "lzss_dec_resolve": lc + n, "lzss_dec_emit": lc + n,
-                         "lzss_dec_count": lc, "lzss_dec_lit": lc + n, "lzss_dec_patch": n})
+                         "lzss_dec_count": lc, "lzss_dec_lit": lc + n, "lzss_dec_patch": n, "lzss_dec_run_fill": lc + n})
         launches = {**{k: v[0] for k, v in prof_e.items()}, **{k: v[0] for k, v in prof_d.items()}}
         if dom in kalg:
             # allk holds the kernel's TOTAL ms in the last timed pass; a kernel launched several times in a call (second looks over

@@ -16,7 +16,7 @@ from collections import defaultdict
 p = glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for r in csv.DictReader(open(p[0])):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rsn::", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rsn::", "")
     a = acc[k][r["Counter_Name"]]
     a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, d in acc.items():

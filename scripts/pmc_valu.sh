@@ -14,7 +14,7 @@ from collections import defaultdict
 p = glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)
 best = {}
 for r in csv.DictReader(open(p[0])):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rsn::", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rsn::", "")
     key = (k, r["Dispatch_Id"])
     best.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
 big = {}

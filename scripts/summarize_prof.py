@@ -24,7 +24,7 @@ def find(d, pat):
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("void ", "").replace("rsn::", "")
     return n.strip()
 
