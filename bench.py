@@ -462,31 +462,35 @@ def config1_and_host_api(torch, device, n, with_host_gib):
                 "gpu_faster_than_one_cpu_core": bool(enc + dec < oe + od),
                 "note": "median of 25 calls; the small-input path (huff_small.hip): compress = 2 launches, decompress = 1, no copy command, "
                         "the host polls flags in pinned memory instead of waiting for the stream (r04: ~10 launches, 0.087 / 0.128 ms)"}
-    # the same regime for `lzss`: the reference's own table is files of 13-25 bytes (README.md:153-167) -- its two strings, and 2 KiB of
-    # samiam.txt: the small-input path (lzss_small.hip: one launch each way), next to the single-thread oracle
-    try:
-        rows = {}
-        for label, dat in (("README_25B", b"abcabcabcabcabcabcabcabc\n"), ("README_13B", b"Hello world!\n"), ("samiam_2KiB", sam[:2048])):
-            a = np.frombuffer(dat, dtype=np.uint8)
-            es, ds = [], []
-            for _ in range(25):
-                cc, te = _host_call(L.rsn_lzss_compress, a, 4096)
-                dd, td = _host_call(L.rsn_lzss_decompress, cc)
-                es.append(te)
-                ds.append(td)
-            oes, ods = [], []
-            for _ in range(5):
-                rcc, t = _timed(lambda: O.lzss_compress(dat, 4096))
-                oes.append(t * 1e3)
-                _, t = _timed(lambda: O.lzss_decompress(rcc))
-                ods.append(t * 1e3)
-            rows[label] = {"bytes": len(dat), "encode_ms": round(sorted(es)[12], 4), "decode_ms": round(sorted(ds)[12], 4), "compressed_bytes": int(cc.size),
-                           "lossless": bool(dd.tobytes() == dat), "bit_exact_vs_oracle": bool(cc.tobytes() == rcc),
-                           "oracle_1_thread_ms": [round(sorted(oes)[2], 4), round(sorted(ods)[2], 4)]}
-        out["1_lzss"] = {"algorithm": "lzss", "api": "host buffers (rsn_lzss_compress / _decompress), PCIe included", "files": rows,
-                         "note": "median of 25 calls each; inputs up to 2 KiB take lzss_small.hip (r05: the general path, 0.23 ms for 3.4 KB)"}
-    except Exception as e:                                  # noqa: BLE001
-        out["1_lzss"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the reference's own table is files of 13-25 bytes (README.md:153-167): its two strings, and 2 KiB of samiam.txt, through both codecs'
+    # host-buffer entry points (the small-input paths: lzss_small.hip one launch each way up to 1 KiB / 2 KiB, huff_small.hip two / one
+    # from 2 bytes up), next to the single-thread oracle
+    for alg, comp, decomp, extra, ocomp, odecomp in (
+            ("lzss", L.rsn_lzss_compress, L.rsn_lzss_decompress, (4096,), lambda d: O.lzss_compress(d, 4096), O.lzss_decompress),
+            ("huffman", L.rsn_huffman_compress, L.rsn_huffman_decompress, (), O.huffman_compress, O.huffman_decompress)):
+        try:
+            rows = {}
+            for label, dat in (("README_25B", b"abcabcabcabcabcabcabcabc\n"), ("README_13B", b"Hello world!\n"), ("samiam_2KiB", sam[:2048])):
+                a = np.frombuffer(dat, dtype=np.uint8)
+                es, ds = [], []
+                for _ in range(25):
+                    cc, te = _host_call(comp, a, *extra)
+                    dd, td = _host_call(decomp, cc)
+                    es.append(te)
+                    ds.append(td)
+                oes, ods = [], []
+                for _ in range(5):
+                    rcc, t = _timed(lambda: ocomp(dat))
+                    oes.append(t * 1e3)
+                    _, t = _timed(lambda: odecomp(rcc))
+                    ods.append(t * 1e3)
+                rows[label] = {"bytes": len(dat), "encode_ms": round(sorted(es)[12], 4), "decode_ms": round(sorted(ds)[12], 4), "compressed_bytes": int(cc.size),
+                               "lossless": bool(dd.tobytes() == dat), "bit_exact_vs_oracle": bool(cc.tobytes() == rcc),
+                               "oracle_1_thread_ms": [round(sorted(oes)[2], 4), round(sorted(ods)[2], 4)]}
+            out["1_" + alg + "_readme_files"] = {"algorithm": alg, "api": "host buffers, PCIe included", "files": rows,
+                                                 "note": "median of 25 calls each (r05: the general paths, 0.1-0.2 ms)"}
+        except Exception as e:                              # noqa: BLE001
+            out["1_" + alg + "_readme_files"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if with_host_gib:
         # Host buffer in, library-owned host buffer out (what the cgo shim binds).  The figures are a plain C++ PROCESS's (what a cgo caller
         # is like; scripts/probes/host_call_probe.cpp on the same bytes, best of three warm calls), pipelined and with RSN_HOST_SERIAL=1;

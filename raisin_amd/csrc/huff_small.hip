@@ -535,7 +535,7 @@ int wait_flags(Ctx &c, hipStream_t s, const uint32_t *f, uint32_t n) {
 
 // 1: not an input for this path (the caller takes the general one)
 int huff_small_compress(Ctx &c, const uint8_t *in, size_t n, const uint8_t **out, size_t *out_n) {
-    if (n < 64 || n > SMALL_MAX) return 1;
+    if (n < 2 || n > SMALL_MAX) return 1;                                          // (r06: from 2 bytes up -- the README's own files are 13 and 25 bytes; one distinct symbol: the general path)
     int rc = ctx_init(c); if (rc) return rc;
     hipStream_t s = c.own_stream;
     void *pp; rc = pinned_buf(c, PIN_BYTES, &pp); if (rc) return rc;

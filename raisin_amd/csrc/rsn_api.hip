@@ -187,6 +187,17 @@ void scratch_release(Ctx &c, size_t need, unsigned long long slots) {
 void scratch_forget(Ctx &c, size_t bytes) { g_arena_bytes[c.device & 63] -= bytes; }
 unsigned long long scratch_queued(int device) { ScratchGate &g = g_gate[device & 63]; std::lock_guard<std::mutex> lk(g.mu); return g.queued; }
 
+// the calling thread's scratch and staging back to the device / the host (rsn_trim; an idle helper when memory runs out)
+static void trim_own_context() {
+    Ctx &c = ctx();
+    if (c.inited && hipSetDevice(c.device) == hipSuccess) {
+        (void)hipStreamSynchronize(c.own_stream);
+        for (auto &b : c.bufs) { if (b.p) { (void)hipFree(b.p); g_arena_bytes[c.device & 63] -= b.cap; } b.p = nullptr; b.cap = 0; }
+        if (c.pinned) (void)hipHostFree(c.pinned);
+        c.pinned = nullptr; c.pinned_cap = 0;
+    }
+}
+
 int dev_buf(Ctx &c, int slot, size_t bytes, void **out) {
     Ctx::Buf &b = c.bufs[slot];
     if (bytes > b.cap) {
@@ -198,6 +209,7 @@ int dev_buf(Ctx &c, int slot, size_t bytes, void **out) {
             std::vector<Parked> victims;
             { std::lock_guard<std::mutex> lk(g_park_mu); if (g_parked) victims.swap(*g_parked); }
             for (auto &pk : victims) release_parked(pk);
+            HelperPool::on_idle(trim_own_context);                        // (r06: idle helpers of the pipelined calls keep contexts of their own for half a minute)
             (void)hipSetDevice(c.device);
             e = hipMalloc(&b.p, want);
         }
@@ -534,16 +546,6 @@ static int rsn_device_count_impl(void) {
 
 const char *rsn_last_error(void) { return ctx().err.c_str(); }
 const char *rsn_version(void) { return "librsn 0.1 (gfx950)"; }
-
-static void trim_own_context() {
-    Ctx &c = ctx();
-    if (c.inited && hipSetDevice(c.device) == hipSuccess) {
-        (void)hipStreamSynchronize(c.own_stream);
-        for (auto &b : c.bufs) { if (b.p) { (void)hipFree(b.p); g_arena_bytes[c.device & 63] -= b.cap; } b.p = nullptr; b.cap = 0; }
-        if (c.pinned) (void)hipHostFree(c.pinned);
-        c.pinned = nullptr; c.pinned_cap = 0;
-    }
-}
 
 static void rsn_trim_impl(void) {
     Ctx &c = ctx();
