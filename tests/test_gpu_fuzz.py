@@ -196,3 +196,34 @@ def test_fuzz_sharded_huffman_stream(mods, oracle, seed):
     assert huffman.Compress(data) == ref
     for G in (2, rng.randint(3, 9), rng.randint(10, 40)):
         assert huffman.CompressSharded(data, G) == ref, (seed, G, len(data))
+
+
+@pytest.mark.parametrize("seed", range(10 * MORE))
+def test_periodic_tail_fuzz(mods, oracle, seed):
+    """r06's arithmetic paths under fuzz: a random head (text, noise, nothing), then a block of random length repeated under a window
+    that is or is not its length (only W-periodic data takes the paths; the rest must not), random remainders, sometimes a changed byte
+    somewhere (the tail then begins behind it, or is too short to be taken), sometimes bytes that need an escape (the encoder's path
+    declines).  Encode == the oracle's bytes; decode == the input; and the oracle's stream + a token run a foreign encoder might append."""
+    lz, _, _ = mods
+    rng = random.Random(9000 + seed)
+    W = rng.choice((4096, 4096, 4096, 2048, 1024, 256, 4080, 16))
+    period = rng.choice((W, W, W, W // 2 if W >= 32 else W, W + 16, 3 * W // 4 if W >= 64 else W))
+    alphabet = bytes(b for b in range(256) if b not in (0x5C, 0xFF)) if rng.random() < 0.8 else bytes(range(256))
+    blk = bytes(rng.choice(alphabet) for _ in range(period))
+    head = rng.choice((b"", bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 30000))),
+                       b" ".join(rng.choice((b"the", b"quick", b"<b>", b"fox", b"lazy")) for _ in range(rng.randint(10, 20000)))))
+    reps = rng.randint(40, 1600000 // max(period, 1) + 40)                          # (up to 1.6 MB: the decoder takes a token run from 1 MiB of output up)
+    body = bytearray(blk * reps + blk[: rng.choice((0, 0, 1, 3, 9, 10, 11, period // 2, period - 1))])
+    if rng.random() < 0.3:
+        body[rng.randrange(len(body))] ^= 0x20
+    data = head + bytes(body)
+    want = oracle.lzss_compress(data, W)
+    got = lz.CompressAsync(data, False, W)
+    assert got == want, (seed, W, period, len(head), len(data))
+    assert lz.Decompress(got) == data
+    # a foreign tail: the oracle's stream + one token repeated (P = any distance inside the data) + sometimes a last item
+    P = rng.choice((1, 5, 255, 256, 4096, 8192, min(len(data), 6000)))
+    if P <= len(data):
+        extra = b"<%d,%d>" % (P, P) * rng.randint(2, 1300000 // (P + 1) + 2) + rng.choice((b"", b"<%d,%d>" % (P, rng.randint(0, P)), b"end\xff."))
+        stream = want + extra
+        assert lz.Decompress(stream) == oracle.lzss_decompress(stream), (seed, P, len(extra))
