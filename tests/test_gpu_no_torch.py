@@ -22,6 +22,7 @@ def test_this_process_runs_librsn_on_torchs_runtime_and_says_so():
     from raisin_amd import _lib
     if _lib.NO_TORCH:
         pytest.skip("the torch-free leg: see test_no_torch_sentinel")
+    _lib.lib()                                                          # (imports torch first, in this mode)
     assert "torch" in sys.modules
     ver, paths = _lib.runtime_info()
     assert any("/torch/" in p for p in paths), paths          # torch's bundled copy is what serves the SONAME here
