@@ -329,3 +329,55 @@ def test_lzss_check_by_segments_is_an_equality_test(oracle):
     pos = len(oracle.lzss_escape(raw))
     lit = c[:k] + esc[pos:pos + ln] + c[j + 1:]                       # the token's bytes written out raw: still decodes to data
     assert oracle.lzss_decompress(lit) == data and not oracle.lzss_check(data, lit, seg=1 << 12)[0]
+
+
+def test_c_oracle_against_the_literal_python_restatement():
+    """oracle/literal.py restates huffman.go / lzss.go a second time, independently and the way the Go reads (bit strings, a list-backed
+    container/heap, bytes.Index, the per-position recursion); the C oracle must agree with it byte for byte -- on tie-heavy alphabets
+    (equal frequencies: only the heap's sift order decides the tree), invalid UTF-8, the escape bytes, windows 4096 / 100 / 16 / unbounded,
+    and on what both reject.  Neither is reference output (no Go toolchain here): two restatements that agree pin each other, not the reference."""
+    import random
+    from oracle import literal as L
+    from oracle import oracle as O
+    O.build()
+    rng = random.Random(20261004)
+    alphabets = [b"ab", b"abc", b"abcdefgh", bytes(range(97, 123)) + b" \n", bytes(range(256)), b"a\n\\|0123456789", b"<\\\xff>,0123",
+                 "äöü€𝄞 ab".encode(), bytes(range(0x80, 0x100)), b"\xe2\x82\xac\xe2\x82", b"\xf0\x9f\x98\x80\xf0\x9f", b"xy\xc3"]
+    n_h = n_l = 0
+    for it in range(420):
+        alph = alphabets[it % len(alphabets)]
+        n = rng.choice((1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 300))
+        if it % 5 == 0:                                           # equal frequencies: every symbol k times, shuffled
+            syms = list(dict.fromkeys(alph))[: rng.randint(2, 40)]
+            k = rng.randint(1, 4)
+            data = bytearray(bytes(syms) * k)
+            rng.shuffle(data)
+            data = bytes(data)
+        else:
+            data = bytes(rng.choice(alph) for _ in range(n))
+        # ---- Huffman (more than one distinct rune: a single one is the bare-leaf special case, below)
+        if len({r for _, r in L.go_runes(data)}) > 1:
+            want = L.huffman_compress(data)
+            assert O.huffman_compress(data) == want, (it, data[:40])
+            assert O.huffman_decompress(want) == L.huffman_decompress(want), (it, data[:40])
+            n_h += 1
+        # ---- LZSS
+        for w in (4096, 100, 16, 0):
+            want = L.lzss_compress(data, w)
+            assert O.lzss_compress(data, w) == want, (it, w, data[:40])
+        assert O.lzss_decompress(want) == L.lzss_decompress(want) == data
+        n_l += 1
+    assert n_h > 300 and n_l == 420
+    # the special cases of the Huffman format (SURVEY 8c): one distinct symbol, the newline's two-byte header entry, '\\' last in Go's order
+    assert L.huffman_compress(b"aaaa") == O.huffman_compress(b"aaaa") == b"4|a\\\n\x00"
+    assert L.huffman_decompress(b"4|a\\\n\x00") == O.huffman_decompress(b"4|a\\\n\x00") == b"a"
+    assert L.huffman_compress(b"ab") == b"1|a1|b\\\n\x06\x01"
+    assert L.huffman_compress(b"a\nb\\")[-2:] == b"\x00\x87"
+    # hand-written LZSS streams: tokens that copy tokens, odd but legal spellings, what both reject
+    for stream in (b"abc<3,3><6,6>x<1,1>", b"ab<0,0>c<2,0>", b"x<1,1><2,2><4,4>", b"lit>,1<2,1>>", b"\\\\\\a<1,1>", b"a\\", b"q<01,1>"):
+        assert O.lzss_decompress(stream) == L.lzss_decompress(stream), stream
+    for bad in (b"ab<9,2>", b"<1,1>", b"abc<2,3>"):
+        with pytest.raises(Exception):
+            L.lzss_decompress(bad)
+        with pytest.raises(Exception):
+            O.lzss_decompress(bad)
