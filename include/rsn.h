@@ -67,8 +67,10 @@ RSN_API void rsn_free(void *p);           /* releases buffers returned through `
                                      library header; large ones are recycled for the next result) */
 
 /* ---- host-buffer entry points (what the cgo shim binds) ----------------
- * Input is borrowed for the duration of the call and never modified.  Output
- * is allocated by the library and released with rsn_free().                */
+ * Input is borrowed for the duration of the call and never modified -- the same
+ * bytes may be handed to several calls at once (the pipelined calls pin them in
+ * place under a shared, reference-counted table).  Output is allocated by the
+ * library and released with rsn_free().                                     */
 
 /* replaces huffman.Compress([]byte) []byte            huffman.go:299 */
 RSN_API int rsn_huffman_compress(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);

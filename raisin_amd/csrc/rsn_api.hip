@@ -304,6 +304,58 @@ void result_free(void *p) {
     free(base);
 }
 
+// ---- the caller's INPUT memory, registered in place for the pipelined calls, under a process-wide table (r06).  The input is borrowed and
+// read-only (rsn.h), so two goroutines may hand the SAME bytes to two calls at once -- decompressing one blob twice is legal -- and r05's
+// per-call hipHostRegister / hipHostUnregister then failed in a way found by tests/test_gpu_host_pipeline.py::test_four_pipelined_calls_at_once:
+// the second call's registration is refused (already registered), its copies run from memory the FIRST call has pinned, and the first call
+// unregisters it under them ("pointer does not correspond to a registered memory region"; once an abort inside the runtime).  Here a range
+// is registered once and counted: an identical range is shared, a call whose bytes merely OVERLAP registered ranges (a serial call's
+// upload, another slicing of the same buffer) holds them for as long as it copies, and the last one out unregisters.
+namespace {
+struct PinRange { uintptr_t lo, hi; int refs; };
+std::mutex g_pin_mu;
+std::vector<PinRange> *g_pins = nullptr;                                 // (never destroyed: helpers may release at exit)
+struct PinHold { std::vector<std::pair<uintptr_t, uintptr_t>> held; bool registered = false; };   // what one acquire took: release() gives it back
+
+// [p, p + len): registers it (true in h.registered) unless something overlapping is registered already -- an identical range is shared
+// (registered stays true: it IS pinned), any other overlap is held as it is (registered false: the copy takes what it finds)
+void pin_acquire(const void *p, size_t len, bool want_register, PinHold &h) {
+    if (!len) return;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + len;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_pins) g_pins = new std::vector<PinRange>();
+    bool overlap = false;
+    for (PinRange &r : *g_pins)
+        if (r.lo < hi && lo < r.hi) {
+            overlap = true;
+            r.refs++;
+            h.held.emplace_back(r.lo, r.hi);
+            if (r.lo == lo && r.hi == hi) h.registered = true;
+        }
+    if (overlap || !want_register) return;
+    if (hipHostRegister((void *)p, len, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }   // (memory some other library has registered, a mapping that cannot be pinned: copied as it is)
+    g_pins->push_back(PinRange{lo, hi, 1});
+    h.held.emplace_back(lo, hi);
+    h.registered = true;
+}
+void pin_release(PinHold &h) {
+    std::vector<uintptr_t> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_pins)
+            for (auto &pr : h.held)
+                for (size_t i = 0; i < g_pins->size(); i++)
+                    if ((*g_pins)[i].lo == pr.first && (*g_pins)[i].hi == pr.second) {
+                        if (--(*g_pins)[i].refs == 0) { gone.push_back(pr.first); g_pins->erase(g_pins->begin() + (long)i); }
+                        break;
+                    }
+    }
+    h.held.clear(); h.registered = false;
+    for (uintptr_t a : gone) if (hipHostUnregister((void *)a) != hipSuccess) (void)hipGetLastError();
+}
+struct PinGuard { PinHold h; ~PinGuard() { pin_release(h); } };         // a serial upload: holds what overlaps for as long as it copies
+}  // namespace
+
 // Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a library-owned result.
 // codec_need: what the codec itself will ask the gate for (its scratch besides the two staging buffers): stated HERE, before the
 // staging is allocated -- a call that waited behind the gate inside the codec already held n + 1.125 x bound bytes of staging, uncounted
@@ -327,7 +379,12 @@ int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t 
     void *d_in, *d_out;
     rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
     RSN_HIP(hipMemsetAsync((uint8_t *)d_in + (n & ~(size_t)15), 0, 64, s));
-    if (n) RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+    {
+        PinGuard g;                                                       // (another call may have these bytes registered: not released under this copy)
+        pin_acquire(in, n, false, g.h);
+        if (n) RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+        if (n && !g.h.held.empty()) RSN_HIP(hipStreamSynchronize(s));
+    }
     if (timing) RSN_HIP(hipStreamSynchronize(s));
     const double t_up = timing ? stamp() : 0;
     size_t cap = bound, got = 0;
@@ -399,14 +456,14 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
     static const bool timing = getenv("RSN_HOST_TIMING") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    std::vector<char> in_pinned((n + PIECE - 1) / PIECE + 2, 0);         // the input's pieces that are registered (released below)
+    std::vector<PinHold> in_pinned((n + PIECE - 1) / PIECE + 2);         // the input's pieces: registered or shared through the table above (released below)
     // Both helpers come from the pool (rsn_helpers.h): no thread and no stream is created once a first call has run, and "no thread to be
     // had" is an answer, not an exception -- the caller then takes the serial call.
     HelperPool::Handle uploader = HelperPool::run(device, stage([&] {
         if (rsn_device_set(device) != RSN_OK) { P.fail(rsn_last_error()); return; }
         hipStream_t su = ctx().own_stream;
-        std::vector<char> &pinned = in_pinned;
-        auto pin = [&](size_t k) { const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1); if (hi > lo) pinned[k] = hipHostRegister((void *)(in + lo), hi - lo, hipHostRegisterDefault) == hipSuccess; if (hi > lo && !pinned[k]) (void)hipGetLastError(); };
+        std::vector<PinHold> &pinned = in_pinned;
+        auto pin = [&](size_t k) { const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1); if (hi > lo) pin_acquire(in + lo, hi - lo, true, pinned[k]); };
         pin(0);
         for (size_t k = 0; cut(in, n, k) < n; k++) {
             const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1);
@@ -417,7 +474,7 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
             { std::lock_guard<std::mutex> lk(P.mu); if (P.failed) return; P.uploaded = hi; }
             P.cv.notify_all();
         }
-        if (timing) { size_t np_ = 0; for (char x : pinned) np_ += x != 0; fprintf(stderr, "piped call: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
+        if (timing) { size_t np_ = 0; for (const PinHold &x : pinned) np_ += x.registered; fprintf(stderr, "piped call: %zu B up by +%.2f ms (%zu pieces registered)\n", n, since(), np_); }
     }));
     if (!uploader) { result_free(res); return 1; }
     HelperPool::Handle downloader = HelperPool::run(device, stage([&] {
@@ -464,7 +521,7 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
         P.fail("no helper thread for the downloads");
         HelperPool::wait(uploader);
         (void)hipSetDevice(c.device);
-        for (size_t k = 0; k < in_pinned.size(); k++) if (in_pinned[k]) (void)hipHostUnregister((void *)(in + cut(in, n, k)));
+        for (PinHold &x : in_pinned) pin_release(x);
         result_free(res);
         return 1;
     }
@@ -488,7 +545,7 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
     HelperPool::wait(uploader);
     HelperPool::wait(downloader);
     (void)hipSetDevice(c.device);
-    for (size_t k = 0; k < in_pinned.size(); k++) if (in_pinned[k]) (void)hipHostUnregister((void *)(in + cut(in, n, k)));
+    for (PinHold &x : in_pinned) pin_release(x);
     if (timing) fprintf(stderr, "piped call: the codec returned %d (%s) at +%.2f ms\n", rc, rc > 0 || rc == RSN_OK ? "" : c.err.c_str(), since());
     if (rc == RSN_ERR_CAPACITY || rc == 1) { result_free(res); return 1; }   // more output than the caller allowed for, or not a stream for slices: the serial call
     if (rc != RSN_OK && P.failed && P.msg != c.err) { result_free(res); return c.fail(rc, "%s (%s)", std::string(c.err).c_str(), P.msg.c_str()); }
@@ -903,6 +960,8 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
         const int r = (int)(j % BatchPipe::RING);
         hipStream_t s = c.own_stream;
         hipError_t e = hipMemsetAsync((uint8_t *)P.d_in[r] + (lens[i] & ~(size_t)15), 0, 64, s);
+        PinGuard g;                                                       // (bytes another call has registered stay registered under this copy)
+        pin_acquire(ins[i], lens[i], false, g.h);
         if (e == hipSuccess) e = hipMemcpyAsync(P.d_in[r], ins[i], lens[i], hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { P.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); break; }
@@ -1073,7 +1132,12 @@ static int rsn_huffman_compress_sharded_impl(const uint8_t *in, size_t n, int sh
         void *d_in = nullptr, *d_out = nullptr;
         int rc = dev_buf(cw, 20, round_up(n_w, 16) + 64, &d_in); if (rc) return bail(rc);
         hipError_t e = hipMemsetAsync((uint8_t *)d_in + (n_w & ~(size_t)15), 0, 64, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_in, in + cut[w], n_w, hipMemcpyHostToDevice, s);
+        {
+            PinGuard g;
+            pin_acquire(in + cut[w], n_w, false, g.h);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_in, in + cut[w], n_w, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && !g.h.held.empty()) e = hipStreamSynchronize(s);
+        }
         if (e != hipSuccess) { sync.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); return; }
         rc = huff_slice_hist(cw, s, (const uint8_t *)d_in, n_w, sl[w].hs); if (rc) return bail(rc);
         if (!sync.meet(plan)) return;
@@ -1150,7 +1214,12 @@ static int64_t rsn_huffman_table_impl(const uint8_t *in, size_t n, uint32_t *run
     hipStream_t s = c.own_stream;
     void *d_in;
     rc = dev_buf(c, 20, round_up(n, 16) + 64, &d_in); if (rc) return rc;
-    RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+    {
+        PinGuard g;
+        pin_acquire(in, n, false, g.h);
+        RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+        if (!g.h.held.empty()) RSN_HIP(hipStreamSynchronize(s));
+    }
     HuffTree t; HuffCodes hc; size_t dummy = 0;
     rc = huff_encode_dev(c, s, (const uint8_t *)d_in, n, nullptr, 0, &dummy, &t, &hc);
     if (rc) return rc;

@@ -144,3 +144,35 @@ def test_pipelined_lzss_decompress_is_the_serial_decompress(oracle):
     with pytest.raises(RsnError) as e:
         lz.Decompress(bad)
     assert e.value.code == -3
+
+
+def test_four_pipelined_calls_at_once():
+    """Four threads, each a pipelined host call at the same moment (LZSS decode and Huffman decode, 70 MiB streams): every call draws its
+    two helpers from the library's pool (eight at once), and a second round finds them there -- the results are the single calls'."""
+    import threading
+    from raisin_amd import huffman, lz
+    unit = b"0123456789abcdefghijklmnopqrstuvwxyz" * 3 + b"<108,108>" + b"<7,7>" + b"Q"
+    lzs = unit * ((70 << 20) // len(unit))
+    rng = np.random.default_rng(77)
+    hin = rng.integers(0, 128, size=80 << 20, dtype=np.uint8).tobytes()
+    hs = huffman.Compress(hin)
+    want_l = hashlib.sha256(lz.Decompress(lzs)).hexdigest()
+    assert huffman.Decompress(hs) == hin
+    errors = []
+
+    def work(t):
+        try:
+            for r in range(2):
+                if (t + r) % 2:
+                    if hashlib.sha256(lz.Decompress(lzs)).hexdigest() != want_l:
+                        errors.append(("lzss", t, r))
+                elif huffman.Decompress(hs) != hin:
+                    errors.append(("huffman", t, r))
+        except Exception as e:          # noqa: BLE001
+            errors.append((t, repr(e)))
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
