@@ -354,6 +354,22 @@ void pin_release(PinHold &h) {
     for (uintptr_t a : gone) if (hipHostUnregister((void *)a) != hipSuccess) (void)hipGetLastError();
 }
 struct PinGuard { PinHold h; ~PinGuard() { pin_release(h); } };         // a serial upload: holds what overlaps for as long as it copies
+// host -> device of [src, src + len) whose pages may be PARTLY inside ranges other calls have registered (h.held, h.registered false): one
+// copy command per stretch that lies wholly inside one registered range or wholly outside all of them -- a single command over memory of
+// two kinds is decided by how its first byte is mapped
+hipError_t copy_up(void *dst, const void *src, size_t len, hipStream_t st, const PinHold &h) {
+    if (h.registered || h.held.empty()) return len ? hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, st) : hipSuccess;
+    const uintptr_t a = (uintptr_t)src, b = a + len;
+    std::vector<uintptr_t> cuts{a, b};
+    for (const auto &pr : h.held) { if (pr.first > a && pr.first < b) cuts.push_back(pr.first); if (pr.second > a && pr.second < b) cuts.push_back(pr.second); }
+    std::sort(cuts.begin(), cuts.end());
+    for (size_t i = 0; i + 1 < cuts.size(); i++) {
+        if (cuts[i + 1] == cuts[i]) continue;
+        const hipError_t e = hipMemcpyAsync((uint8_t *)dst + (cuts[i] - a), (const void *)cuts[i], cuts[i + 1] - cuts[i], hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 }  // namespace
 
 // Host-buffer wrapper: H2D, run `fn` on device buffers, D2H into a library-owned result.
@@ -382,7 +398,7 @@ int host_call(const uint8_t *in, size_t n, uint8_t **out, size_t *out_n, size_t 
     {
         PinGuard g;                                                       // (another call may have these bytes registered: not released under this copy)
         pin_acquire(in, n, false, g.h);
-        if (n) RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+        RSN_HIP(copy_up(d_in, in, n, s, g.h));
         if (n && !g.h.held.empty()) RSN_HIP(hipStreamSynchronize(s));
     }
     if (timing) RSN_HIP(hipStreamSynchronize(s));
@@ -467,7 +483,7 @@ static int piped_call(const uint8_t *in, size_t n, size_t out_cap, size_t codec_
         pin(0);
         for (size_t k = 0; cut(in, n, k) < n; k++) {
             const size_t lo = cut(in, n, k), hi = cut(in, n, k + 1);
-            hipError_t e = hipMemcpyAsync((uint8_t *)d_in + lo, in + lo, hi - lo, hipMemcpyHostToDevice, su);
+            hipError_t e = copy_up((uint8_t *)d_in + lo, in + lo, hi - lo, su, pinned[k]);
             if (e == hipSuccess && hi < n) pin(k + 1);                        // (under this piece's copy)
             if (e == hipSuccess) e = hipStreamSynchronize(su);
             if (e != hipSuccess) { P.fail(hipGetErrorString(e)); return; }
@@ -962,7 +978,7 @@ static int batch_on_device(Ctx &c, const std::vector<size_t> &idx, const uint8_t
         hipError_t e = hipMemsetAsync((uint8_t *)P.d_in[r] + (lens[i] & ~(size_t)15), 0, 64, s);
         PinGuard g;                                                       // (bytes another call has registered stay registered under this copy)
         pin_acquire(ins[i], lens[i], false, g.h);
-        if (e == hipSuccess) e = hipMemcpyAsync(P.d_in[r], ins[i], lens[i], hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = copy_up(P.d_in[r], ins[i], lens[i], s, g.h);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { P.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); break; }
         if (timing) fprintf(stderr, "batch dev %d chunk %zu up at %.2f ms\n", device, i, stamp());
@@ -1135,7 +1151,7 @@ static int rsn_huffman_compress_sharded_impl(const uint8_t *in, size_t n, int sh
         {
             PinGuard g;
             pin_acquire(in + cut[w], n_w, false, g.h);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_in, in + cut[w], n_w, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = copy_up(d_in, in + cut[w], n_w, s, g.h);
             if (e == hipSuccess && !g.h.held.empty()) e = hipStreamSynchronize(s);
         }
         if (e != hipSuccess) { sync.fail(RSN_ERR_DEVICE, hipGetErrorString(e)); return; }
@@ -1217,7 +1233,7 @@ static int64_t rsn_huffman_table_impl(const uint8_t *in, size_t n, uint32_t *run
     {
         PinGuard g;
         pin_acquire(in, n, false, g.h);
-        RSN_HIP(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+        RSN_HIP(copy_up(d_in, in, n, s, g.h));
         if (!g.h.held.empty()) RSN_HIP(hipStreamSynchronize(s));
     }
     HuffTree t; HuffCodes hc; size_t dummy = 0;

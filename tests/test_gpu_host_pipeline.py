@@ -176,3 +176,40 @@ def test_four_pipelined_calls_at_once():
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_two_pipelined_calls_on_overlapping_views_of_one_buffer():
+    """Two goroutines may compress overlapping slices of ONE buffer at the same moment (the input is borrowed and read-only): the second
+    call's pieces overlap what the first has registered without being the same ranges -- held, not registered again, copied stretch by
+    stretch; nobody's registration is pulled away under the other's copies (r06, the table in rsn_api.hip)."""
+    import ctypes
+    import threading
+    import workloads as W
+    from raisin_amd import _lib
+    L = _lib.lib()
+    buf = W.config_input("4", 150 << 20).numpy()
+    views = [buf, buf[(3 << 20) + 17:], buf[: 140 << 20]]
+
+    def call(a):
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        got = ctypes.c_size_t(0)
+        _lib.check(L.rsn_lzss_compress(a.ctypes.data_as(ctypes.c_char_p), a.size, 4096, ctypes.byref(out), ctypes.byref(got)))
+        h = hashlib.sha256(ctypes.string_at(out, got.value)).hexdigest()
+        L.rsn_free(out)
+        return h
+    want = [call(v) for v in views]
+    errors = []
+
+    def work(t):
+        try:
+            for r in range(2):
+                if call(views[t]) != want[t]:
+                    errors.append((t, r))
+        except Exception as e:          # noqa: BLE001
+            errors.append((t, repr(e)))
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
