@@ -1492,11 +1492,7 @@ int lzss_decode_impl(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8
         ResolveArgs ra{d_in, n, d_tinfo, n_tiles, E, TL, d_desc, d_fallback, d_rt_cnt, d_rt_runs};
         if (d_rt_cnt) RSN_LAUNCH("lzss_dec_runs", k_lzd_runs, dim3(n_tiles), dim3(64), 0, s, d_in, n, (const uint2 *)d_tinfo, n_tiles, E, TL, d_rt_cnt, d_rt_runs);
         RSN_LAUNCH("lzss_dec_resolve", k_lzd_resolve, dim3(n_tiles), dim3(DTH), 0, s, ra);
-        static thread_local size_t attr_tl = 0;
-        if ((size_t)TL * 4 > attr_tl) {
-            RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lzd_compose), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TL * 4)));
-            attr_tl = (size_t)TL * 4;
-        }
+        rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_lzd_compose), (size_t)TL * 4); if (rc) return rc;
         if (n_groups > 1) {
             RSN_LAUNCH("lzss_dec_compose", k_lzd_compose, dim3(n_groups - 1), dim3(DTH), (size_t)TL * 4, s, d_desc, TL, dgrp, d_comp, (const uint32_t *)d_rt_cnt, (const uint32_t *)d_rt_runs);
             const uint32_t n_links = n_groups - 1;

@@ -2080,8 +2080,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     uint32_t *d_super = (uint32_t *)q;
     unsigned long long *d_gentry = (unsigned long long *)(d_super + (size_t)n_groups * PT);
     const size_t mark_sh = std::max<size_t>((size_t)PT + 2 * (size_t)W + 48, (size_t)PT * 2);
-    static thread_local size_t mark_attr = 0;
-    if (mark_sh > mark_attr) { RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_parse_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mark_sh)); mark_attr = mark_sh; }
+    rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_parse_mark), mark_sh); if (rc) return rc;
     for (uint32_t round = 0; !parsed; round++) {
         RSN_HIP(hipMemsetAsync(d_ttot + 1, 0, 8, s));
         RSN_LAUNCH("lzss_parse_exit", k_parse_exit, dim3(n_pt), dim3(LB), 0, s, d_keys, E, d_exit);

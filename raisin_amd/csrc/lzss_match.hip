@@ -346,11 +346,7 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
 }
 
 int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2) {
-    static thread_local size_t attr2_set = 0;
-    if (shmem2 > attr2_set) {
-        RSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_match2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-        attr2_set = shmem2;
-    }
+    { const int rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_match2), shmem2); if (rc) return rc; }
     RSN_LAUNCH("lzss_match", k_match2, dim3(n_blocks), dim3(MW2 * 64), shmem2, s, m2);
     return RSN_OK;
 }

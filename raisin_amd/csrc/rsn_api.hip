@@ -234,6 +234,22 @@ int pinned_buf(Ctx &c, size_t bytes, void **out) {
     return RSN_OK;
 }
 
+int func_dyn_lds(Ctx &c, const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void *, int>, size_t>> *seen = new std::vector<std::pair<std::pair<const void *, int>, size_t>>();
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : *seen)
+        if (e.first.first == fn && e.first.second == c.device) {
+            if (bytes <= e.second) return RSN_OK;
+            RSN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            e.second = bytes;
+            return RSN_OK;
+        }
+    RSN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    seen->push_back({{fn, c.device}, bytes});
+    return RSN_OK;
+}
+
 void prof_collect(Ctx &c) {
     for (auto &sl : c.slots) {
         for (auto &pr : sl.pending) {

@@ -61,6 +61,10 @@ void scratch_release(Ctx &c, size_t held, unsigned long long slots);         // 
 void scratch_forget(Ctx &c, size_t bytes);
 unsigned long long scratch_queued(int device);                               // calls that have had to wait so far (tests)
 void prof_collect(Ctx &c);
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the FUNCTION on a device, not to the calling thread: raised only, under a lock (r06:
+// every thread kept its own "largest so far" and set the attribute whenever its own grew -- a thread with a small need lowered what another's
+// next launch relied on)
+int func_dyn_lds(Ctx &c, const void *fn, size_t bytes);
 
 #define RSN_HIP(call)                                                                              \
     do {                                                                                           \

@@ -838,3 +838,36 @@ def test_periodic_tail_switches_give_the_same_bytes(oracle):
             out = subprocess.run([sys.executable, "-c", code, f.name], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
             assert out.returncode == 0, out.stderr[-2000:]
             assert out.stdout.strip().splitlines()[-1].split("|") == want, (env, out.stdout[-600:])
+
+
+def test_threads_with_different_tail_lengths_and_windows(lz, oracle):
+    """The kernels that take dynamic LDS (k_lzd_compose: four bytes per position of the longest back-pointer's tail; k_match2: by window)
+    have that maximum set per FUNCTION, for all threads: one thread decoding streams with 16 000-byte pointers beside one with 100-byte
+    pointers, one encoding under window 8192 beside one under 5000 -- each must keep getting its own answer (r06: the attribute was
+    tracked per thread and could be lowered under another thread's next launch)."""
+    import threading
+    rng = np.random.default_rng(8)
+    lit = rng.integers(97, 123, size=40000, dtype=np.uint8).tobytes()
+    big = lit + b"<16000,16000>" * 40 + b"<15000,900>" * 300
+    small = lit[:3000] + b"<100,100>" * 20000 + b"<37,30>" * 9000
+    want_big, want_small = oracle.lzss_decompress(big), oracle.lzss_decompress(small)
+    data = text(77, 90000) + b"ab" * 3000 + text(78, 20000)
+    want_w = {w: oracle.lzss_compress(data, w) for w in (8192, 5000)}
+    errors = []
+
+    def dec(stream, want, tag):
+        for r in range(12):
+            if lz.Decompress(stream) != want:
+                errors.append((tag, r))
+
+    def enc(w):
+        for r in range(3):
+            if lz.CompressAsync(data, False, w) != want_w[w]:
+                errors.append(("window", w, r))
+    ts = [threading.Thread(target=dec, args=(big, want_big, "big")), threading.Thread(target=dec, args=(small, want_small, "small")),
+          threading.Thread(target=enc, args=(8192,)), threading.Thread(target=enc, args=(5000,))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
