@@ -13,7 +13,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = ["test_gpu_fuzz.py", "test_gpu_huffman_small.py", "test_gpu_host_pipeline.py", "test_gpu_shapes.py"]
+SUITES = ["test_gpu_fuzz.py", "test_gpu_huffman_small.py", "test_gpu_host_pipeline.py", "test_gpu_shapes.py", "test_gpu_lzss_small.py", "test_gpu_literal.py"]
 
 
 @pytest.mark.gpu
