@@ -198,16 +198,26 @@ def test_two_pipelined_calls_on_overlapping_views_of_one_buffer():
         L.rsn_free(out)
         return h
     want = [call(v) for v in views]
+
+    def hcall(a):                                                   # the engine's other goroutine: ANOTHER codec on the same bytes (engine.go:235-244), a serial upload
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        got = ctypes.c_size_t(0)
+        _lib.check(L.rsn_huffman_compress(a.ctypes.data_as(ctypes.c_char_p), a.size, ctypes.byref(out), ctypes.byref(got)))
+        h = hashlib.sha256(ctypes.string_at(out, got.value)).hexdigest()
+        L.rsn_free(out)
+        return h
+    views.append(buf)
+    want.append(hcall(buf))
     errors = []
 
     def work(t):
         try:
             for r in range(2):
-                if call(views[t]) != want[t]:
+                if (hcall(views[t]) if t == 3 else call(views[t])) != want[t]:
                     errors.append((t, r))
         except Exception as e:          # noqa: BLE001
             errors.append((t, repr(e)))
-    ts = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
     for t in ts:
         t.start()
     for t in ts:
