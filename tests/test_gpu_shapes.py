@@ -26,6 +26,10 @@ def _shapes():
     for p in (1, 2, 3, 7, 37, 100, 256, 1000, 3461, 4095, 4096, 4097, 5000, 20000):
         unit = "".join(rng.choices("abcdefghijklmnopqrstuvwxyz ,.\n<>\\", k=p)).encode()
         yield "period %d" % p, (unit * (N // p + 1))[:N]
+    blk = "".join(rng.choices("abcdefghijklmnopqrstuvwxyz ,.\n<", k=4096)).encode()    # r06: what the arithmetic paths take (nothing to escape), and what they must leave alone
+    yield "period 4096, nothing to escape", (blk * (2 * N // 4096))[: 2 * N - 1234]
+    yield "text, then period 4096", text[: N // 4] + blk * 300
+    yield "period 4096, then text", blk * 200 + text[: N // 4]
     for p in (37, 256, 1000):
         unit = "".join(rng.choices("abcdefghijklmnopqrstuvwxyz ,.\n", k=p)).encode()
         b = bytearray((unit * (N // p + 1))[:N])
