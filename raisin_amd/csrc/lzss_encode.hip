@@ -168,7 +168,7 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
         uint4 v[ESC_RUN + 1];
 #pragma unroll
         for (int k = 0; k <= ESC_RUN; k++) v[k] = p[(k - 1) * (ESC_TILE / 16)];
-        uint32_t same_bits = 0, special = 0, lt = 0;
+        uint32_t same_bits = 0, special = 0, lt = 0, unlike = ~0u;                 // unlike: zero once a 16-byte unit began with eight bytes alike (see `seen` below)
         // (r06: "is there a byte equal to X" as an ACCUMULATED zero-byte test -- (t - 0x01010101) & ~t has bit 7 of a byte set iff that byte
         //  of t = w ^ XXXX is zero or lies above one that is: exact for existence, four instructions a value and dword instead of seven)
         auto zacc = [](uint32_t w, uint32_t x4) { const uint32_t t = w ^ x4; return (t - 0x01010101u) & ~t; };
@@ -179,13 +179,14 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
             for (int j = 0; j < 4; j++) { special |= zacc(w[j], 0x5C5C5C5Cu) | zacc(w[j], 0xFFFFFFFFu); lt |= zacc(w[j], 0x3C3C3C3Cu); }
+            unlike = min(unlike, (w[0] ^ w[1]) | (w[0] ^ (uint32_t)__builtin_amdgcn_alignbit(w[0], w[0], 8u)));
         }
         special &= 0x80808080u; lt &= 0x80808080u;
         __shared__ uint32_t s_and[LB / 64], s_any[LB / 64];
         uint32_t wave_and = 0;
 #pragma unroll
         for (int k = 0; k < ESC_RUN; k++) wave_and |= (__ballot((same_bits >> k) & 1u) == ~0ull ? 1u : 0u) << k;
-        const uint32_t wave_any = (__ballot(special != 0) ? 1u : 0u) | (__ballot(lt != 0) ? 2u : 0u);
+        const uint32_t wave_any = (__ballot(special != 0) ? 1u : 0u) | (__ballot(lt != 0) ? 2u : 0u) | (__ballot(unlike == 0) ? 4u : 0u);
         if ((threadIdx.x & 63) == 0) { s_and[threadIdx.x >> 6] = wave_and; s_any[threadIdx.x >> 6] = wave_any; }
         __syncthreads();
         uint32_t all = ~0u, any = 0;
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
     }
     uint32_t prev[4] = {0, 0, 0, 0};
     int prev_cnt = -1;                                                     // -1: nothing in `prev` (the run's first chunk, or Wp is not a chunk)
-    uint32_t seen = 0;                                                     // bit 0: a 5C / FF, bit 1: a '<' -- one look at the flag per BLOCK, at the end (r05: a stream with a '<' in
+    uint32_t seen = 0;                                                     // bit 2 (r06): a 16-byte unit that begins with eight bytes alike -- the stream holds runs of a byte: k_match_chain<RUNS> is its walk
+                                                                           // bit 0: a 5C / FF, bit 1: a '<' -- one look at the flag per BLOCK, at the end (r05: a stream with a '<' in
                                                                            // every wavefront's 1 KiB -- config 3 -- had sixteen million wavefronts read the one flag word: 0.44 ms against 0.25)
     for (uint32_t k = 0; k < (uint32_t)ESC_RUN; k++) {
         const uint32_t chunk = blockIdx.x * ESC_RUN + k;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             prev[0] = w[0]; prev[1] = w[1]; prev[2] = w[2]; prev[3] = w[3]; prev_cnt = cnt;   // (the INPUT bytes: before '<' becomes FF below)
         }
         uint32_t special = 0, lt = 0;
+        if (cnt >= 8 && ((w[0] ^ w[1]) | (w[0] ^ (uint32_t)__builtin_amdgcn_alignbit(w[0], w[0], 8u))) == 0) seen |= 4u;
 #pragma unroll
         for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); const uint32_t m = bytes_equal(w[j], 0x3Cu); lt |= m; w[j] |= m; }
         seen |= (special != 0 ? 1u : 0u) | (lt != 0 ? 2u : 0u);
@@ -231,9 +234,9 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             if (threadIdx.x == 0) same_blk[chunk] = (uint8_t)all;
         }
     }
-    const int any1 = __syncthreads_or(seen & 1u), any2 = __syncthreads_or(seen & 2u);
+    const int any1 = __syncthreads_or(seen & 1u), any2 = __syncthreads_or(seen & 2u), any4 = __syncthreads_or(seen & 4u);
     if (threadIdx.x == 0) {
-        const unsigned long long want = (any1 ? 1ull : 0ull) | (any2 ? 2ull : 0ull);
+        const unsigned long long want = (any1 ? 1ull : 0ull) | (any2 ? 2ull : 0ull) | (any4 ? 4ull : 0ull);
         if (want & ~__atomic_load_n(flag, __ATOMIC_RELAXED)) atomicOr(flag, want);
     }
 }
@@ -288,9 +291,10 @@ __device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len);
 // KEY_UNKNOWN; if the true chain ever lands on one (k_parse_mark notices), that strip is redone for
 // all positions by k_match_hash and the parse is repeated -- correctness never rests on the merge,
 // only the speed does.
-template <int CT_, int CTH_, int CS_>
+template <int CT_, int CTH_, int CS_, bool RUNS_ = false>
 struct ChainCfg {
     static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
+    static constexpr bool RUNS = RUNS_;         // heavy visits inside a run of one byte are resolved from the window's runs (chain_run_visit): the kernel for streams that hold such runs
     static constexpr int CSH = 9;               // a bucket's entries are ordered by staged offset >> CSH
     static constexpr int CH = 128;                          // warm-up positions before the tile
     static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
@@ -392,6 +396,75 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
         } else ok = false;
     }
     if (tid == 0) { tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0}; step[blockIdx.x] = 0; }
+}
+
+// (r06) k_match_chain's heavy visit of a position in a run of one byte z.  Its candidates -- every one begins with z z -- are the positions
+// of the window's runs of z.  With r bytes of the run left at the position (capped at min(W, E - p)) and R left at a candidate at distance d
+// the match is min(r, R, d) long unless R == r: then both runs end together and it goes on behind them.  Inside one run [a, b) of the
+// window R and d both fall with the candidate's offset: its first byte is its best (and farthest) candidate, the one with R == r the only
+// other that can count; in the position's own run R > r, so its first byte inside the window.  The wavefront reads the window once out of the
+// stage, 512 bytes a trip, and every lane that finds a byte other than z closes the run in front of it: some forty runs' keys instead of
+// four thousand candidates compared eight bytes at a time, most of them further than the stage reaches (a buffer with a byte in a hundred
+// set: 1.9 ms a tile, seventeen times a tile of text -- and the tiles whose farthest long candidate did not decide went to the sweep at
+// 0.5 GB/s).  Runs inside a lane's eight bytes are not seen: the result stands if it is eight bytes or longer -- else 0, and the rounds
+// find it.  Returns L << 16 | distance.  sw: the stage; c_irel: the position's staged offset; c_ipos: its stream position; zrel: the
+// staged offset of stream position 0.  All arguments are the same in the 64 lanes.
+__device__ __forceinline__ uint32_t chain_run_visit(const uint32_t *sw, const uint8_t *fc, uint32_t c_irel, uint32_t c_capE, uint32_t c_ipos, uint32_t W, uint32_t zrel, int lane) {
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
+    const unsigned long long zz = 0x0101010101010101ull * sb[c_irel];
+    uint32_t fr = 0xFFFFFFFFu;
+    if (lane < HLMAX / 8) { const unsigned long long x = lds_load8(sw, c_irel + 8u * (uint32_t)lane) ^ zz; if (x) fr = 8u * (uint32_t)lane + ((uint32_t)__builtin_ctzll(x) >> 3); }
+    fr = ~wave_max_u32(~fr);                                              // bytes of the run from the position on that the stage shows
+    if (fr < 8u) return 0u;
+    const uint32_t lim0 = min(W, c_capE);
+    auto wave_first_diff = [&](uint32_t d, uint32_t from, uint32_t lim) -> uint32_t {   // the first q in [from, lim) with fc[p + q] != fc[p - d + q], or lim
+        const uint8_t *pa = fc + (size_t)c_ipos, *pb = pa - d;
+        uint32_t res = lim;
+        for (uint32_t base = from; base < lim && res == lim; base += 512u) {
+            const uint32_t q = base + 8u * (uint32_t)lane;
+            uint32_t mm = lim;
+            if (q + 8 <= lim) {
+                unsigned long long u, v;
+                __builtin_memcpy(&u, pa + q, 8); __builtin_memcpy(&v, pb + q, 8);
+                if (u != v) mm = q + ((uint32_t)__builtin_ctzll(u ^ v) >> 3);
+            } else for (uint32_t k = q; k < lim && mm == lim; k++) if (pa[k] != pb[k]) mm = k;
+            res = ~wave_max_u32(~mm);
+        }
+        return res;
+    };
+    const uint32_t r = fr == 0xFFFFFFFFu ? wave_first_diff(1u, (uint32_t)HLMAX, lim0) : min(fr, lim0);
+    const uint32_t after = r < (uint32_t)HLMAX ? sb[c_irel + r] : 0x100u;  // the byte behind the position's run, if the stage shows it
+    uint32_t carry = max(c_irel - W, zrel), kb = 0;                        // the offset behind the last byte so far that is not z; the lane's best key
+    for (uint32_t cb = carry; cb < c_irel; cb += 512u) {
+        const uint32_t o = cb + 8u * (uint32_t)lane;
+        unsigned long long x = o < c_irel ? lds_load8(sw, o) ^ zz : 0ull;
+        if (o < c_irel && o + 8u > c_irel) x &= ~0ull >> (8u * (o + 8u - c_irel));   // the position's own bytes are z
+        const uint32_t first = o + ((uint32_t)__builtin_ctzll(x | (1ull << 63)) >> 3);
+        uint32_t pe = x ? o + 8u - ((uint32_t)__builtin_clzll(x) >> 3) : 0u;       // the offset behind the lane's last byte that is not z
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x111, 0xF, 0xF, true));   // a running maximum over the lanes (as the sum in k_match_chain's 2b.)
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x112, 0xF, 0xF, true));
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x114, 0xF, 0xF, true));
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x118, 0xF, 0xF, true));
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false));
+        pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false));
+        uint32_t a0 = __shfl_up(pe, 1);
+        a0 = max(lane ? a0 : 0u, carry);                                  // where the run that this lane's first such byte ends began
+        carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)pe, 63));
+        uint32_t ds = 0;                                                  // the candidate whose run ends with the position's, if it is to be followed
+        if (x) {
+            const uint32_t rq = first - a0, dmax = c_irel - a0;
+            if (rq >= 2u) kb = max(kb, (min(min(r, rq), dmax) << 16) | dmax);   // (rq == r: at least that; followed below if the bytes behind the runs agree)
+            if (rq >= r && r < lim0 && (after == 0x100u || after == sb[first])) ds = c_irel - first + r;
+        }
+        for (unsigned long long am = __ballot(ds != 0); am; am &= am - 1) {
+            const int l = __builtin_ctzll(am);
+            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)ds, l), L1 = wave_first_diff(d1, r, min(d1, c_capE));
+            if (lane == l) kb = max(kb, (L1 << 16) | d1);
+        }
+    }
+    uint32_t wb = wave_max_u32(kb);
+    if (carry < c_irel) wb = max(wb, (min(r, c_irel - carry) << 16) | (c_irel - carry));   // the position's own run
+    return (wb >> 16) < 8u ? 0u : wb;
 }
 
 template <class C>
@@ -662,6 +735,20 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 *reinterpret_cast<uint4 *>(&ws.par[slot][0]) = uint4{irel, cand_q(irel, tag), (uint32_t)pat0, (uint32_t)(pat0 >> 32)};
                 *reinterpret_cast<uint4 *>(&ws.par[slot][4]) = uint4{lo, hi, capE, 0u};
             }
+            if constexpr (C::RUNS) {
+                // (r06) a heavy visit whose position stands in a run of one byte: resolved from the window's runs (chain_run_visit).  In the
+                //  kernel for streams that hold such runs only: never entered, the code still costs text 0.7 of 27.7 ms (registers), and
+                //  its gate -- the four bytes behind the position's first alike, two instructions a wavefront-iteration -- another 0.4.
+                for (unsigned long long hr = hm & __ballot((uint32_t)pat0 == (uint32_t)__builtin_amdgcn_alignbit((uint32_t)pat0, (uint32_t)pat0, 8u)); hr; hr &= hr - 1) {
+                    const int hl = __builtin_ctzll(hr);
+                    const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl);
+                    const uint32_t wb = chain_run_visit(sw, a.fc, c_irel, (uint32_t)__builtin_amdgcn_readlane((int)capE, hl), (uint32_t)(t0 - CH) + (c_irel - HWMAX), W, zrel, lane);
+                    if (wb) {                                             // (exact; as long as a candidate followed through memory: 3. counts it as one)
+                        if (lane == 0) { ws.best[(uint32_t)hl / LW] = wb; if ((wb >> 16) >= (uint32_t)HLMAX) ws.lcnt[(uint32_t)hl / LW] = 0x80000000u; }
+                        hm &= ~(1ull << hl);
+                    }
+                }
+            }
             while (hm) {
                 const int hl = __builtin_ctzll(hm);
                 hm &= hm - 1;
@@ -747,6 +834,12 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                     }
                     return ~row_max_u32<LW>(~mm);
                 };
+                auto in_byte_run = [&]() {                                   // the HLMAX bytes from the position on: one byte repeated?
+                    const unsigned long long zz = 0x0101010101010101ull * sb[irel];
+                    bool same = true;
+                    for (uint32_t q = 8u * (uint32_t)rl; q < (uint32_t)HLMAX; q += 8u * LW) same = same && lds_load8(sw, irel + q) == zz;
+                    return row_ballot<LW>(!same, lane) == 0;
+                };
                 auto commit = [&](uint32_t key) {
                     a.keys[ipos] = key;
                     next = kp + max(1u, key >> 16);                           // lzss.go:139-142: a reference skips size-1 positions
@@ -756,7 +849,8 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 else {
                     bool giveup_heavy = false, giveup_dense = false;
                     if (longm) {
-                        if (lcnt <= LCAP) {                                   // every long candidate is followed to its end: the maximum is exact
+                        if (lcnt >> 31) {}                                    // resolved by the wavefront from the window's runs (2a., chain_run_visit)
+                        else if (lcnt <= LCAP) {                                   // every long candidate is followed to its end: the maximum is exact
                             // (farthest first: a candidate at distance d matches d bytes at most, so once the best reaches further than the
                             //  farthest one left, the rest cannot win -- a 1000-periodic stream follows one candidate over 4000 bytes, not four)
                             uint32_t done = 0;
@@ -770,6 +864,33 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                 if ((best >> 16) > dj) break;
                                 best = max(best, (first_diff(dj, ws.llist[slot][pick][1], ws.llist[slot][pick][0] >> 16) << 16) | dj);
                             }
+                        } else if (in_byte_run()) {
+                            // (r06) The position stands in a run of one byte z, HLMAX of it and more ahead: zero-filled and sparse buffers, runs.
+                            // Every candidate that agrees for HLMAX bytes lies in a run of z too; chain_run_visit's argument, by the row: the
+                            // window's runs of z out of the stage, 64 bytes a trip -- a dozen candidates with exact lengths instead of
+                            // thousands that all agree further than the stage reaches (the farthest of which decided, or the strip went to
+                            // the sweep: a buffer with a byte in a hundred set took 0.5 GB/s).  Runs of fewer than HLMAX - 16 bytes are left
+                            // out: their candidates have their exact keys from the rounds.
+                            const uint32_t lim0 = min(W, capE), r = first_diff(1u, 1u, lim0);
+                            const unsigned long long zz = 0x0101010101010101ull * sb[irel];
+                            uint32_t run_a = max(irel - W, zrel);
+                            for (uint32_t cb = run_a; cb < irel; cb += 8u * LW) {
+                                const uint32_t o = cb + 8u * (uint32_t)rl;
+                                unsigned long long x = o < irel ? lds_load8(sw, o) ^ zz : 0ull;
+                                if (o < irel && o + 8u > irel) x &= ~0ull >> (8u * (o + 8u - irel));   // the position's own bytes are z
+                                uint32_t first = 0xFFFFFFFFu, last = 0;                      // the trip's first byte that is not z, and the offset behind its last
+                                if (x) { first = o + ((uint32_t)__builtin_ctzll(x) >> 3); last = o + 8u - ((uint32_t)__builtin_clzll(x) >> 3); }
+                                first = ~row_max_u32<LW>(~first); last = row_max_u32<LW>(last);
+                                if (first != 0xFFFFFFFFu) {
+                                    const uint32_t rq = first - run_a, dmax = irel - run_a;   // the run [run_a, first) ends here
+                                    if (rq + 16u >= HLMAX) {
+                                        best = max(best, (min(min(r, rq), dmax) << 16) | dmax);   // (rq == r: at least that)
+                                        if (rq >= r && r < lim0) { const uint32_t ds = irel - first + r; best = max(best, (first_diff(ds, r, min(ds, capE)) << 16) | ds); }
+                                    }
+                                    run_a = last;
+                                }
+                            }
+                            if (run_a < irel) best = max(best, (min(r, irel - run_a) << 16) | (irel - run_a));
                         } else {                                              // (the wave version explains why the farthest long candidate decides)
                             const uint32_t Lp = min(long_far, capE);
                             const uint32_t mm = first_diff(long_far, 0, Lp);
@@ -1915,8 +2036,12 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
     using CC = ChainCfg<8192, 1024, 64>;                           // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 64 positions
+    using CCR = ChainCfg<8192, 1024, 64, true>;                     // the same walk for a stream that holds runs of a byte (k_esc_try's flag, Ctx::lz_runs; RSN_LZSS_RUNS=0 / 1: never / always -- the tests)
+    static const int runs_env = [] { const char *e = getenv("RSN_LZSS_RUNS"); return e ? atoi(e) : -1; }();
+    const bool runs = runs_env < 0 ? c.lz_runs : runs_env != 0;
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
-        RSN_LAUNCH(name, (k_match_chain<CC>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        if (runs) RSN_LAUNCH(name, (k_match_chain<CCR>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
+        else RSN_LAUNCH(name, (k_match_chain<CC>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         return RSN_OK;
     };
     uint8_t *d_dump = nullptr;
@@ -2219,6 +2344,7 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 16, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     copied = (h64[0] & 1ull) == 0;
+    c.lz_runs = (h64[0] & 4ull) != 0;                                 // (lzss_encode_stream's choice of walk)
     const size_t unlike_end = tail_cand ? (size_t)h64[1] * ESC_TILE : n;   // every 4 KiB chunk from this byte on repeats the W bytes before it
     h64[0] = 0;
     if (!copied) {
@@ -2361,6 +2487,7 @@ int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int
     unsigned long long *h64 = (unsigned long long *)hp;
     RSN_HIP(hipMemsetAsync(d_flag, 0, 8, s));
     size_t entry = 0, written = 0, checked = 0;
+    c.lz_runs = false;                                                // (set by the slices' checks as they come)
     void *sp = nullptr;
     while (entry < n) {
         const bool halo = entry >= halo_len;
@@ -2379,6 +2506,7 @@ int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int
             RSN_HIP(hipMemcpyAsync(h64, d_flag, 8, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
             if (h64[0] & 1ull) { if (dbg) fprintf(stderr, "lzss sliced: a byte that needs an escape below position %zu: encoded whole instead\n", upto); return 1; }
+            if (h64[0] & 4ull) c.lz_runs = true;
             checked = upto;
             if (!announce(checked == n)) return c.fail(RSN_ERR_DEVICE, "lzss: the download of a sliced call failed");
         }

@@ -39,6 +39,7 @@ struct Ctx {
     enum { N_BUFS = 39 };   // 28..33: the batch pipeline's ring; 34: the one-pass Huffman decoder's tile words; 35: k_esc_try's block flags; 36: an LZSS section's stream (encoder: the aligned copy; decoder: the escaped bytes in front + the section's tokens); 37, 38: the small-input Huffman path's device copy / its decoder's block maps
     Buf bufs[N_BUFS];
     void *pinned = nullptr; size_t pinned_cap = 0;
+    bool lz_runs = false;           // the LZSS input in hand holds runs of a byte (k_esc_try's flag): lzss_encode_stream walks it with k_match_chain<RUNS>
     size_t gate_held = 0;           // scratch this thread's call in progress has been admitted with (rsn_api.hip: a nested admission is covered by it)
 
     ~Ctx();     // parks the device resources for the next thread (rsn_api.hip); makes no HIP call

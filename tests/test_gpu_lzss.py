@@ -871,3 +871,44 @@ def test_threads_with_different_tail_lengths_and_windows(lz, oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def _sparse(seed, n, every, hi=128):
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n, dtype=np.uint8)
+    idx = rng.integers(0, n, size=max(1, n // every))
+    a[idx] = rng.integers(1, hi, size=idx.size, dtype=np.uint8)
+    return a.tobytes()
+
+
+def _byte_runs(seed, n, longest, alphabet=b"abcdefgh<\\ \n"):
+    rng = random.Random(seed)
+    out, size = [], 0
+    while size < n:
+        k = rng.randint(1, longest)
+        out.append(bytes([rng.choice(alphabet)]) * k)
+        size += k
+    return b"".join(out)[:n]
+
+
+@pytest.mark.parametrize("name,data", [
+    ("a byte in 100 set", _sparse(1, 1 << 20, 100)),
+    ("a byte in 300 set", _sparse(2, 600000, 300)),
+    ("a byte in 3000 set", _sparse(3, 1 << 20, 3000)),
+    ("a byte in 3000 set, of two values", _sparse(4, 1 << 20, 3000, hi=3)),          # runs that end alike: the candidate whose run ends with the position's goes on behind it
+    ("a byte in 700 set, of two values", _sparse(5, 700001, 700, hi=3)),
+    ("runs up to 1000", _byte_runs(6, 1 << 20, 1000)),
+    ("runs up to 5000", _byte_runs(7, 1 << 20, 5000)),
+    ("runs up to 600 of two bytes", _byte_runs(8, 500000, 600, b"ab")),
+    ("runs up to 3000 of two bytes", _byte_runs(9, 800000, 3000, b"a<")),
+    ("text, zeros, text", text(10, 100000) + bytes(300000) + text(11, 50000) + bytes(5000) + text(12, 30000)),
+    ("zeros with a word now and then", b"".join(bytes(n) + w for n, w in zip(np.random.default_rng(13).integers(1, 2500, size=600).tolist(), [b"word", b"zero", b"\0x\0", b"longer words here"] * 150))),
+    ("a run that ends the stream", text(14, 20000) + b"z" * 9000),
+    ("a run that begins it", b"z" * 9000 + text(15, 20000)),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_byte_runs_are_resolved_in_the_walk(lz, oracle, name, data):
+    """r06: a position in a run of one byte with HLMAX of it ahead has thousands of candidates that agree further than the stage reaches;
+    the walk resolves them from the window's runs instead of handing the strip to the sweep.  The oracle's bytes."""
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
