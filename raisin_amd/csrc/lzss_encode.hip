@@ -1984,6 +1984,12 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
 // ======================================================================= host side
 size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
 
+__global__ __launch_bounds__(256) void k_count_flags(const uint32_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ out) {   // how many of the flags are set
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && flags[i] != 0);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(out, (unsigned long long)__builtin_popcountll(m));
+}
+
 // One pass over one escaped stream of E < 2^31 positions: match search, greedy chain, token emit.  halo: the stream is a SECTION of a
 // longer one -- its first HALO_TILES tiles are window only and the chain enters at the first position behind them; stop_tile (0: none):
 // the section ends in front of that tile -- *out_n is then the bytes of the items that begin before it, *exit_pos where the chain first
@@ -2018,15 +2024,6 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     if ((halo || stop_tile) && !hashed) return c.fail(RSN_ERR_LIMIT, "lzss: a stream of 2 GiB and more is encoded in sections only for windows up to %d", HWMAX);
     bool chain_mode = hashed && !allpos;                             // (a sample of tiles may still send the whole stream to the bucket search, below)
     if (!chain_mode) { rc = need_copy(); if (rc) return rc; }
-    auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 on every strip, or on the flagged ones
-        // (r05: a block's time is its (strip + W) / 64 position blocks in a row -- 8 ms for 16384 positions under the engine's window -- so a
-        //  short stream is swept in shorter strips: 1 MiB of a period broken every 100 KB 15.7 -> 4 ms, scripts/probes/periodic_lzss.py)
-        const uint32_t strip = n_strips <= 64 ? 2048u : n_strips <= 1024 ? 4096u : (uint32_t)MATCH_STRIP;
-        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only, strip};
-        const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
-        const size_t shmem2 = (size_t)((strip + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
-        return lzss_launch_match2(c, s, m2, (uint32_t)ceil_div(E, strip), shmem2);
-    };
     // E3 buffers (the chain walk fills flags and tile bytes itself when its per-tile chains join up)
     const uint32_t n_pt = (uint32_t)ceil_div(E, PT);
     rc = dev_buf(c, 12, (size_t)n_pt * 8 + (size_t)n_pt * (PT / 32) * 4 + ((size_t)n_pt * 2 + 4) * 8 + (size_t)n_pt * sizeof(TileChain) + 64, &p); if (rc) return rc;
@@ -2035,6 +2032,30 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     uint32_t *d_flags = d_entry + n_pt;
     TileChain *d_tchain = (TileChain *)(d_flags + (size_t)n_pt * (PT / 32));
     bool parsed = false;                                              // flags + tile offsets + total are final
+    auto sweep = [&](const uint32_t *only) -> int {                   // k_match2 on every strip, or on the flagged ones
+        // (r05: a block's time is its (strip + W) / 64 position blocks in a row -- 8 ms for 16384 positions under the engine's window -- so a
+        //  short stream is swept in shorter strips: 1 MiB of a period broken every 100 KB 15.7 -> 4 ms, scripts/probes/periodic_lzss.py)
+        uint32_t strip = n_strips <= 64 ? 2048u : n_strips <= 1024 ? 4096u : (uint32_t)MATCH_STRIP;
+        if (only) {
+            // (r06) ... and what counts is how many strips are flagged, not how long the stream is: 16 MiB of 256-byte records with a
+            // counter had three heavy strips of 2081 tiles and waited 7.9 ms of its 10.2 for three blocks.  Shorter strips while the
+            // flagged ones make no more than 128 blocks (a block of 512 positions: 72 position blocks in a row instead of 320 -- 7.9 ->
+            // 2.4 ms; at 272 blocks of 1024 instead of 136 of 2048 a period broken every 100 KB lost: 4.8 -> 5.6 ms a MiB).
+            RSN_HIP(hipMemsetAsync(d_ttot + 3, 0, 8, s));
+            RSN_LAUNCH("lzss_scan", k_count_flags, dim3((uint32_t)ceil_div(n_strips, 256)), dim3(256), 0, s, only, n_strips, (unsigned long long *)(d_ttot + 3));
+            RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            const uint64_t flagged = h64[3];
+            if (flagged == 0) return RSN_OK;
+            uint32_t fine = 512u;
+            while (fine < (uint32_t)MATCH_STRIP && flagged * ((uint64_t)MATCH_STRIP / fine) > 128) fine *= 2;
+            strip = std::min(strip, fine);
+        }
+        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only, strip};
+        const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
+        const size_t shmem2 = (size_t)((strip + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
+        return lzss_launch_match2(c, s, m2, (uint32_t)ceil_div(E, strip), shmem2);
+    };
     using CC = ChainCfg<8192, 1024, 64>;                           // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 64 positions
     using CCR = ChainCfg<8192, 1024, 64, true>;                     // the same walk for a stream that holds runs of a byte (k_esc_try's flag, Ctx::lz_runs; RSN_LZSS_RUNS=0 / 1: never / always -- the tests)
     static const int runs_env = [] { const char *e = getenv("RSN_LZSS_RUNS"); return e ? atoi(e) : -1; }();
@@ -2145,6 +2166,15 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
+        if (dbg && (uint32_t)h64[1]) {                                    // which strips, and why (heavy: the long candidates of a visit did not decide; dense: steps of one and two bytes)
+            std::vector<uint32_t> fl((size_t)n_strips * 3);
+            RSN_HIP(hipMemcpyAsync(fl.data(), d_heavy, fl.size() * 4, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            std::string line;
+            for (uint32_t k = 0, shown = 0; k < n_strips && shown < 12; k++)
+                if (fl[k] || fl[(size_t)2 * n_strips + k]) { line += " " + std::to_string(k) + (fl[k] ? "h" : "d"); shown++; }
+            fprintf(stderr, "lzss chain walk: strips of %d positions with a tile that gave up (h: heavy, d: dense):%s\n", MATCH_STRIP, line.c_str());
+        }
         // A few tiles gave up (a stretch of one- and two-byte steps looked "dense"), or entered on a chain that had not merged with the
         // true one yet: walk just those -- without that test / from the true entry, the tile before's exit -- and check again.  A joint
         // next to a tile that gave up can only be judged once that tile is resolved, hence up to three looks (each costs a few tiles).
