@@ -899,14 +899,33 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                 const uint32_t want = a.fc[(size_t)ipos + mm];
                                 const uint32_t b1 = sb[irel + 1], h = ((uint32_t)sb[irel] << 5) | (b1 & 31u), tag = (b1 >> 5) & TAGM;
                                 const uint32_t blo = h ? (uint32_t)ends[h - 1] : 0u, bhi = ends[h];
-                                bool other = false;
-                                for (uint32_t idx = blo + rl; idx < bhi; idx += LW) {
-                                    const uint32_t e = s_list[idx], rot = cand_rot(cand_q(irel, tag), e), dn = rot + 1u;
-                                    const bool ok = rot < W;
-                                    if (ok && dn > mm && dn <= ipos && a.fc[(size_t)ipos - dn + mm] == want) other = true;
+                                // Who can outlast the farthest: a candidate further back than mm bytes that has the position's byte at offset mm --
+                                // and, r06, its first eight bytes and the stage's last eight, which every candidate that agrees for HLMAX bytes
+                                // has (sorted lines: "aba\n" repeated after "ab\n" repeated -- a third of the earlier stretch's positions
+                                // have the right byte at offset mm and agree with the position for three bytes; the byte alone sent 125 of
+                                // 8192 tiles to the sweep, 12 of the call's 24 ms).  Up to eight of them are followed to their ends: exact.
+                                // (counted first: a period broken now and then has every multiple of the period beyond mm among them, and
+                                //  following eight of sixteen before giving up cost more than giving up at once)
+                                best = max(best, (mm << 16) | long_far);
+                                auto contender = [&](uint32_t idx, uint32_t &dn) {
+                                    dn = cand_rot(cand_q(irel, tag), s_list[idx]) + 1u;
+                                    return dn <= W && dn > mm && dn <= ipos && a.fc[(size_t)ipos - dn + mm] == want &&
+                                           lds_load8(sw, irel - dn) == lds_load8(sw, irel) && lds_load8(sw, irel - dn + HLMAX - 8) == lds_load8(sw, irel + HLMAX - 8);
+                                };
+                                uint32_t n_cont = 0;
+                                for (uint32_t idx0 = blo; idx0 < bhi && n_cont <= 8u; idx0 += LW) {
+                                    uint32_t dn;
+                                    n_cont += (uint32_t)__builtin_popcount(row_ballot<LW>(idx0 + (uint32_t)rl < bhi && contender(idx0 + (uint32_t)rl, dn), lane));
                                 }
-                                if (row_ballot<LW>(other, lane)) giveup_heavy = true;
-                                else best = max(best, (mm << 16) | long_far);
+                                if (n_cont > 8u) giveup_heavy = true;
+                                else if (n_cont) for (uint32_t idx0 = blo; idx0 < bhi; idx0 += LW) {
+                                    uint32_t dn = 0;
+                                    const bool cand = idx0 + (uint32_t)rl < bhi && contender(idx0 + (uint32_t)rl, dn);
+                                    for (uint32_t cm = row_ballot<LW>(cand, lane); cm; cm &= cm - 1) {
+                                        const uint32_t d1 = row_read<LW>(dn, (uint32_t)__builtin_ctz(cm), lane);
+                                        best = max(best, (first_diff(d1, 0, min(d1, capE)) << 16) | d1);
+                                    }
+                                }
                             }
                         }
                     }
@@ -1984,6 +2003,10 @@ __global__ __launch_bounds__(LB) void k_tok_emit(const uint8_t *__restrict__ fc,
 // ======================================================================= host side
 size_t lzss_compress_bound(size_t n) { return 2 * n + 64; }
 
+__global__ __launch_bounds__(256) void k_flag_listed(const uint32_t *__restrict__ list, uint32_t n, uint32_t *__restrict__ flags, uint32_t tiles_per_strip) {   // flags[strip of tile] = 1 for the listed tiles (bits 31, 30 of an entry: k_chain_verify's marks)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[(list[i] & 0x3FFFFFFFu) / tiles_per_strip] = 1u;
+}
 __global__ __launch_bounds__(256) void k_count_flags(const uint32_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ out) {   // how many of the flags are set
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const unsigned long long m = __ballot(i < n && flags[i] != 0);
@@ -2214,6 +2237,15 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         if (!parsed) {                                                // some tile was periodic / dense / heavy, or two chains did not join: the general parse decides
             rc = need_copy(); if (rc) return rc;                      // (the bucket search, the sweep and the general parse read the escaped stream itself)
             RSN_LAUNCH("lzss_chain_unknown", k_chain_unknown<CC>, dim3(n_pt), dim3(256), 0, s, d_dump, d_tchain, n_pt, E, W, d_keys);
+            // (r06) The tiles still on the looks' list -- entered on a chain that is not the true one, or given up -- are where the parse
+            // will land on positions nobody evaluated: their strips are searched now, with the dense ones, instead of in a second and a
+            // third round of bucket search + sweep + parse each (a period broken every 100 KB, 8 MiB: three sweeps of 5.4 ms).
+            {
+                static const bool no_preflag = getenv("RSN_LZSS_NO_PREFLAG") != nullptr;   // A/B switch (the tests' way to the parse's redo rounds)
+                const uint32_t n_list = (uint32_t)(h64[2] >> 32);
+                if (n_list && n_list <= redo_cap && !no_preflag)
+                    RSN_LAUNCH("lzss_chain_unknown", k_flag_listed, dim3((uint32_t)ceil_div(n_list, 256)), dim3(256), 0, s, (const uint32_t *)d_redo_list, n_list, d_dense, (uint32_t)(MATCH_STRIP / CC::CT));
+            }
             HashArgs hd{d_fc, E, W, d_keys, d_heavy, d_dense};
             rc = lzss_launch_match_hash(c, s, hd); if (rc) return rc;   // the strips the chain walk found dense
             rc = sweep(d_heavy); if (rc) return rc;

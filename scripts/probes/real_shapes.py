@@ -14,6 +14,7 @@ from raisin_amd import huffman, lz
 
 N = (int(sys.argv[1]) if len(sys.argv) > 1 else 16) << 20
 only = sys.argv[2] if len(sys.argv) > 2 else None
+dev = len(sys.argv) > 3 and sys.argv[3] == "dev"          # device tensors in and out (no PCIe): what the kernels make of the shape
 trace = len(sys.argv) > 3 and sys.argv[3] == "trace"      # with RSN_DEBUG=1 in the environment: the encoder's stages and per-kernel times of one LZSS call
 rng = random.Random(11)
 nrng = np.random.default_rng(11)
@@ -138,6 +139,23 @@ for name, gen in kinds.items():
         continue
     data = gen(N)
     n = len(data)
+    if dev:
+        import torch
+        src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+
+        def tmed(fn, *a):
+            fn(*a); torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); r = fn(*a); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            return r, sorted(ts)[1]
+        c, he = tmed(huffman.compress_tensor, src)
+        d, hd = tmed(huffman.decompress_tensor, c)
+        z, le = tmed(lz.compress_tensor, src)
+        u, ld = tmed(lz.decompress_tensor, z)
+        note = "" if torch.equal(u, src) else " LZSS MISMATCH"
+        print("%-36s | %8.2f %8.2f %5.1f%% | %8.2f %8.2f %5.1f%%%s" % (name, n / he / 1e9, n / hd / 1e9, 100.0 * c.numel() / n, n / le / 1e9, n / ld / 1e9, 100.0 * z.numel() / n, note), flush=True)
+        continue
     if trace:
         from raisin_amd import _lib
         lz.CompressAsync(data)

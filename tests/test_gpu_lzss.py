@@ -485,7 +485,7 @@ def test_chain_redo_round(lz, oracle):
             "    c = lz.CompressAsync(data, False, w)\n"
             "    p = _lib.prof_get(); _lib.prof_enable(False)\n"
             "    print(hashlib.sha256(c).hexdigest(), p.get('lzss_parse_exit', (0, 0))[0])\n" % (root, blk.hex(), cases))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, RSN_LZSS_NO_FUSED_PARSE="1"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, RSN_LZSS_NO_FUSED_PARSE="1", RSN_LZSS_NO_PREFLAG="1"))   # (r06: without the second switch the listed tiles' strips are searched before the first parse)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [x.split() for x in out.stdout.strip().splitlines()[-3:]]
     assert [r[0] for r in rows] == want
@@ -909,6 +909,35 @@ def _byte_runs(seed, n, longest, alphabet=b"abcdefgh<\\ \n"):
 def test_byte_runs_are_resolved_in_the_walk(lz, oracle, name, data):
     """r06: a position in a run of one byte with HLMAX of it ahead has thousands of candidates that agree further than the stage reaches;
     the walk resolves them from the window's runs instead of handing the strip to the sweep.  The oracle's bytes."""
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
+
+
+def _sorted_lines(seed, n, n_words, longest):
+    rng = random.Random(seed)
+    words = ["".join(rng.choice("abcdefghij") for _ in range(rng.randint(1, longest))) for _ in range(n_words)]
+    lines = sorted(rng.choice(words) + rng.choice(words) for _ in range(n // 4))
+    return "\n".join(lines).encode()[:n]
+
+
+@pytest.mark.parametrize("name,data", [
+    ("sorted lines, many alike", _sorted_lines(1, 1 << 20, 300, 3)),
+    ("sorted lines, fewer alike", _sorted_lines(2, 1 << 20, 3000, 9)),
+    ("sorted lines of one and two letters", _sorted_lines(3, 700000, 40, 2)),
+    ("a line repeated, then one a byte longer", (b"ab\n" * 400 + b"aba\n" * 300 + b"abab\n" * 250 + b"abb\n" * 500) * 40),
+    ("period 256 broken now and then", bytes(bytearray((bytes(range(32, 127)) * 3)[:256] * 4096)[:1 << 20])),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_contenders_of_the_farthest_long_candidate_are_followed(lz, oracle, name, data):
+    """r06: more long candidates than a visit lists, and the farthest does not run to its limit: the candidates that can outlast it
+    (its byte at the mismatch, the first eight bytes, the stage's last eight) are followed to their ends, up to eight of them."""
+    if name.startswith("period 256"):
+        b = bytearray(data)
+        rng = random.Random(4)
+        at = 30000
+        while at < len(b):
+            b[at] = ord(rng.choice("ABCDEFG")); at += rng.randint(20000, 200000)
+        data = bytes(b)
     c = lz.CompressAsync(data)
     assert c == oracle.lzss_compress(data)
     assert lz.Decompress(c) == data
