@@ -587,6 +587,12 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
     // advanced less than two positions per visit hands the strip to k_match_hash.
     // (64 visits: at 32, a few text tiles in every ten thousand -- two or three rare words in a row are a few dozen one-byte steps --
     //  gave up, and each such tile costs the stream a second look; noise gives up at 64 as surely as at 32)
+        // (r06: HALF the walkers, not a quarter -- 100-byte records with 20 random bytes each have a fifth of the starts inside the random bytes:
+    //  54 % of the tiles gave up and the bucket search did them at 2.7 GB/s; with the half 23 GB/s.  Noise, where every walker says so
+    //  after its eighth visit, gives up at the same moment either way: 16 MiB 1.97 ms, 1 GiB 41.7 ms before and after.)
+#ifndef RSN_DENSE_DIV
+#define RSN_DENSE_DIV 2
+#endif
     constexpr uint32_t DENSE_EVALS = 64, DENSE_VOTE = 8;
     constexpr uint32_t LONG_CAP = 8;                                      // candidates with a common prefix of HLMAX bytes and more that a visit follows through memory
     // (Structured control flow on purpose -- no break / continue out of the walk: with them the compiler turns the loop into a
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                                 voted = true;
                                 uint32_t v = 0;
                                 if (leader) v = atomicAdd(&s_votes, 1u) + 1u;
-                                giveup_dense = row_read<LW>(v, 0, lane) >= (uint32_t)(CTH / LW / 4);
+                                giveup_dense = row_read<LW>(v, 0, lane) >= (uint32_t)(CTH / LW / RSN_DENSE_DIV);
                             }
                         }
                         if (!giveup_dense) {
@@ -2073,6 +2079,8 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             uint32_t fine = 512u;
             while (fine < (uint32_t)MATCH_STRIP && flagged * ((uint64_t)MATCH_STRIP / fine) > 128) fine *= 2;
             strip = std::min(strip, fine);
+            static const bool dbg_sweep = getenv("RSN_DEBUG") != nullptr;
+            if (dbg_sweep) fprintf(stderr, "lzss sweep: %llu of %u strips flagged, blocks of %u positions\n", (unsigned long long)flagged, n_strips, strip);
         }
         MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only, strip};
         const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
