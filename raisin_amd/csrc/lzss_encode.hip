@@ -241,6 +241,33 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
     }
 }
 
+// (r06) Does the input hold stretches of a short period -- a line or a record repeated?  k_esc_try's third flag only sees eight bytes alike
+// (a period of one); a walk by the lean instance of k_match_chain that ends in "heavy" tiles is done again by the other, but what it
+// walked before giving up is lost (sparse CSV, 16 MiB: 3 of 6 ms).  A sample instead: up to 64 chunks of 4 KiB spread over the input, every
+// eighth position asks whether its 24 bytes come again within 64; a chunk where one in fifty does raises the flag.  Text: none.
+constexpr uint32_t PSAMPLE_CHUNK = 4096, PSAMPLE_MAX_P = 64;
+__global__ __launch_bounds__(256) void k_period_sample(const uint8_t *__restrict__ in, size_t n, uint32_t n_samples, unsigned long long *__restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[(PSAMPLE_CHUNK + PSAMPLE_MAX_P + 32 + 16) / 4];
+    __shared__ uint32_t s_hits;
+    const size_t span = PSAMPLE_CHUNK + PSAMPLE_MAX_P + 32;
+    if (n < span) return;
+    const size_t at = n_samples > 1 ? (size_t)((unsigned __int128)(n - span) * blockIdx.x / (n_samples - 1)) & ~(size_t)15 : 0;
+    for (uint32_t v = threadIdx.x; v < span / 16; v += 256) reinterpret_cast<uint4 *>(s_w)[v] = *reinterpret_cast<const uint4 *>(in + at + 16 * (size_t)v);
+    if (threadIdx.x == 0) s_hits = 0;
+    __syncthreads();
+    uint32_t hits = 0;
+    for (uint32_t i = 8u * threadIdx.x; i < PSAMPLE_CHUNK; i += 8u * 256u) {
+        const unsigned long long a0 = lds_load8(s_w, i), a1 = lds_load8(s_w, i + 8), a2 = lds_load8(s_w, i + 16);
+        bool hit = false;
+        for (uint32_t P = 1; P <= PSAMPLE_MAX_P && !hit; P++)
+            hit = lds_load8(s_w, i + P) == a0 && lds_load8(s_w, i + P + 8) == a1 && lds_load8(s_w, i + P + 16) == a2;
+        hits += hit ? 1u : 0u;
+    }
+    if (hits) atomicAdd(&s_hits, hits);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits * 50u >= PSAMPLE_CHUNK / 8u && !(__atomic_load_n(flag, __ATOMIC_RELAXED) & 4ull)) atomicOr(flag, 4ull);
+}
+
 // k_tile_periodic's records from k_esc_try's block flags: a tile is W-periodic iff every block that overlaps [t0, t0 + tile + W - 1) repeats
 // the bytes W before it (block granularity: a stretch that ends inside the last block is walked like any other tile)
 constexpr uint32_t PREV_BLK = 8192;                                  // tiles per block of k_prev_walked
@@ -294,7 +321,7 @@ __device__ __forceinline__ uint32_t enc_len(uint32_t off, uint32_t len);
 template <int CT_, int CTH_, int CS_, bool RUNS_ = false>
 struct ChainCfg {
     static constexpr int CT = CT_, CTH = CTH_, CS = CS_;
-    static constexpr bool RUNS = RUNS_;         // heavy visits inside a run of one byte are resolved from the window's runs (chain_run_visit): the kernel for streams that hold such runs
+    static constexpr bool RUNS = RUNS_;         // visits inside a stretch of a short period -- a run of a byte, a line repeated -- are resolved from the window's stretches (chain_period_visit): the kernel for streams that hold such
     static constexpr int CSH = 9;               // a bucket's entries are ordered by staged offset >> CSH
     static constexpr int CH = 128;                          // warm-up positions before the tile
     static constexpr int NS = HWMAX + CH + CT;              // staged positions that can be candidates
@@ -398,25 +425,43 @@ __global__ __launch_bounds__(256) void k_tile_periodic(const uint8_t *__restrict
     if (tid == 0) { tchain[blockIdx.x] = TileChain{0, 0, ok ? 2u : 0u, 0}; step[blockIdx.x] = 0; }
 }
 
-// (r06) k_match_chain's heavy visit of a position in a run of one byte z.  Its candidates -- every one begins with z z -- are the positions
-// of the window's runs of z.  With r bytes of the run left at the position (capped at min(W, E - p)) and R left at a candidate at distance d
-// the match is min(r, R, d) long unless R == r: then both runs end together and it goes on behind them.  Inside one run [a, b) of the
-// window R and d both fall with the candidate's offset: its first byte is its best (and farthest) candidate, the one with R == r the only
-// other that can count; in the position's own run R > r, so its first byte inside the window.  The wavefront reads the window once out of the
-// stage, 512 bytes a trip, and every lane that finds a byte other than z closes the run in front of it: some forty runs' keys instead of
-// four thousand candidates compared eight bytes at a time, most of them further than the stage reaches (a buffer with a byte in a hundred
-// set: 1.9 ms a tile, seventeen times a tile of text -- and the tiles whose farthest long candidate did not decide went to the sweep at
-// 0.5 GB/s).  Runs inside a lane's eight bytes are not seen: the result stands if it is eight bytes or longer -- else 0, and the rounds
-// find it.  Returns L << 16 | distance.  sw: the stage; c_irel: the position's staged offset; c_ipos: its stream position; zrel: the
-// staged offset of stream position 0.  All arguments are the same in the 64 lanes.
-__device__ __forceinline__ uint32_t chain_run_visit(const uint32_t *sw, const uint8_t *fc, uint32_t c_irel, uint32_t c_capE, uint32_t c_ipos, uint32_t W, uint32_t zrel, int lane) {
+// (r06) k_match_chain's visit of a position p that stands in a stretch of period P <= PMAX: b[i + P] == b[i] for the 64 bytes from p on
+// and more -- a run of one byte (P = 1: zero-filled and sparse buffers), a line or a record repeated (sparse CSV, a log line over and
+// over).  Such a visit has hundreds or thousands of candidates that agree further than the stage's 256 bytes; the rounds compare them
+// eight bytes at a time, and the rule for more long candidates than a visit lists -- the farthest decides unless another has the
+// position's byte where it stops -- gave nearly every tile up as "heavy": the sweep did the stream at 4096 compares a position, 0.4-0.6 GB/s.
+//
+// With r = the bytes from p on that keep the period (capped at min(W, E - p)), a candidate q at distance d that begins with p's unit U =
+// b[p .. p + P) and keeps the period for R bytes matches min(r, R, d) bytes unless R == r -- then both stretches end together and the match
+// goes on behind them.  The window's stretches are what lies between its MARKS, the positions i with b[i] != b[i - P]: marks absent on
+// [a, b) make [a - P, b) one stretch.  Inside a stretch the candidates are the positions that begin with U, P apart; R and d both fall
+// with the offset, so the first of them is the stretch's best and farthest candidate and the one with R == r the only other that can
+// count.  In p's own stretch R > r: the farthest position a multiple of P back.  So: find P (lane j tries j + 1), r through memory, then
+// the wavefront reads the window once, 512 bytes a trip, and every lane that finds a mark closes the stretch in front of it -- finds the
+// first position that begins with U, evaluates its key, follows the R == r candidate if the bytes behind the two stretches agree.
+//
+// What it does not see: gaps between two marks inside one lane's eight bytes (six bytes at most).  A candidate that matches l >= P + 7 bytes has
+// no mark on [q + P, q + l), so it lies in a stretch that is seen, at or behind that stretch's first position that begins with U: the
+// maximum over the keys above is exact as soon as it is P + 7 or more -- else 0 is returned and the rounds decide.
+// Returns L << 16 | distance.  sw: the stage; c_irel: p's staged offset; c_ipos: its stream position; zrel: the staged offset of stream
+// position 0.  All arguments are the same in the 64 lanes.
+template <int PMAX>
+__device__ __forceinline__ uint32_t chain_period_visit(const uint32_t *sw, const uint8_t *fc, uint32_t c_irel, uint32_t c_capE, uint32_t c_ipos, uint32_t W, uint32_t zrel, int lane) {
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
-    const unsigned long long zz = 0x0101010101010101ull * sb[c_irel];
-    uint32_t fr = 0xFFFFFFFFu;
-    if (lane < HLMAX / 8) { const unsigned long long x = lds_load8(sw, c_irel + 8u * (uint32_t)lane) ^ zz; if (x) fr = 8u * (uint32_t)lane + ((uint32_t)__builtin_ctzll(x) >> 3); }
-    fr = ~wave_max_u32(~fr);                                              // bytes of the run from the position on that the stage shows
-    if (fr < 8u) return 0u;
-    const uint32_t lim0 = min(W, c_capE);
+    const uint32_t wlo = max(c_irel - W, zrel);
+    uint32_t P = 0;
+    static_assert(PMAX + 24 + 8 <= HLMAX + 32, "the period is found in the bytes the stage holds behind a position");
+    for (uint32_t p0 = 0; p0 < (uint32_t)PMAX && !P; p0 += 64) {          // the least period of the bytes from p on (what lies BEFORE p may be anything: the first of a row of equal lines)
+        const uint32_t Pj = p0 + (uint32_t)lane + 1u;
+        // (24 bytes that repeat at distance Pj -- eight for a run of one byte: a buffer with a byte in a hundred set has runs of a dozen
+        //  zeros everywhere, and each visit of one that goes to the rounds instead compares four thousand candidates)
+        bool ok = Pj <= (uint32_t)PMAX && lds_load8(sw, c_irel) == lds_load8(sw, c_irel + Pj);
+        if (Pj > 1u) ok = ok && lds_load8(sw, c_irel + 8u) == lds_load8(sw, c_irel + 8u + Pj) && lds_load8(sw, c_irel + 16u) == lds_load8(sw, c_irel + 16u + Pj);
+        const unsigned long long m = __ballot(ok);
+        if (m) P = p0 + (uint32_t)__builtin_ctzll(m) + 1u;
+    }
+    if (!P) return 0u;
+    const uint32_t lim0 = min(W, c_capE), T = P + 7u;
     auto wave_first_diff = [&](uint32_t d, uint32_t from, uint32_t lim) -> uint32_t {   // the first q in [from, lim) with fc[p + q] != fc[p - d + q], or lim
         const uint8_t *pa = fc + (size_t)c_ipos, *pb = pa - d;
         uint32_t res = lim;
@@ -432,15 +477,32 @@ __device__ __forceinline__ uint32_t chain_run_visit(const uint32_t *sw, const ui
         }
         return res;
     };
-    const uint32_t r = fr == 0xFFFFFFFFu ? wave_first_diff(1u, (uint32_t)HLMAX, lim0) : min(fr, lim0);
-    const uint32_t after = r < (uint32_t)HLMAX ? sb[c_irel + r] : 0x100u;  // the byte behind the position's run, if the stage shows it
-    uint32_t carry = max(c_irel - W, zrel), kb = 0;                        // the offset behind the last byte so far that is not z; the lane's best key
-    for (uint32_t cb = carry; cb < c_irel; cb += 512u) {
+    // r: p's unit, then the bytes that repeat the byte P before them -- out of the stage as far as it shows them (a load from memory is a
+    // microsecond or two, and a buffer with a byte in a hundred set has 160 such visits a tile), through memory behind that; capped at
+    // lim0 (the stage is zero behind the stream's end)
+    uint32_t r = 0xFFFFFFFFu;
+    {
+        const uint32_t k = P + 8u * (uint32_t)lane;
+        if (k + 8u <= (uint32_t)HLMAX + 24u) { const unsigned long long x = lds_load8(sw, c_irel + k) ^ lds_load8(sw, c_irel + k - P); if (x) r = k + ((uint32_t)__builtin_ctzll(x) >> 3); }
+        r = ~wave_max_u32(~r);
+        if (r == 0xFFFFFFFFu) r = wave_first_diff(P, min(P + 512u, (uint32_t)HLMAX + 24u) / 8u * 8u - 8u, lim0);   // (from a multiple of eight the stage has shown alike)
+        r = min(r, lim0);
+    }
+    if (r < T || (P > 1u && r < 2u * P + 16u)) return 0u;                  // (a unit that comes again once and a bit -- table rows that share their mark-up -- is the rounds' business: the window's scan costs a thousand instructions)
+    auto begins_with_unit = [&](uint32_t q) {                              // b[q .. q + P) == U  (eight bytes at a time: up to seven bytes past the unit, which both sides repeat -- q + T and p + T lie inside their stretches)
+        bool eq = true;
+        for (uint32_t k = 0; k < P && eq; k += 8) eq = lds_load8(sw, q + k) == lds_load8(sw, c_irel + k);
+        return eq;
+    };
+    const uint32_t after = r < (uint32_t)HLMAX ? sb[c_irel + r] : 0x100u;  // the byte behind p's stretch, if the stage shows it
+    uint32_t carry = wlo + P, kb = 0;                                      // the offset behind the last mark so far ([wlo, wlo + P) counts as marked: no unit in front of it inside the window); the lane's best key
+    const uint32_t scan_end = c_irel + P;                                  // (the marks of p's own unit too: is it the first of its stretch?)
+    for (uint32_t cb = carry; cb < scan_end; cb += 512u) {
         const uint32_t o = cb + 8u * (uint32_t)lane;
-        unsigned long long x = o < c_irel ? lds_load8(sw, o) ^ zz : 0ull;
-        if (o < c_irel && o + 8u > c_irel) x &= ~0ull >> (8u * (o + 8u - c_irel));   // the position's own bytes are z
+        unsigned long long x = o < scan_end ? lds_load8(sw, o) ^ lds_load8(sw, o - P) : 0ull;
+        if (o < scan_end && o + 8u > scan_end) x &= ~0ull >> (8u * (o + 8u - scan_end));   // from p + P on there is no mark for r bytes
         const uint32_t first = o + ((uint32_t)__builtin_ctzll(x | (1ull << 63)) >> 3);
-        uint32_t pe = x ? o + 8u - ((uint32_t)__builtin_clzll(x) >> 3) : 0u;       // the offset behind the lane's last byte that is not z
+        uint32_t pe = x ? o + 8u - ((uint32_t)__builtin_clzll(x) >> 3) : 0u;       // the offset behind the lane's last mark
         pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x111, 0xF, 0xF, true));   // a running maximum over the lanes (as the sum in k_match_chain's 2b.)
         pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x112, 0xF, 0xF, true));
         pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, 0x114, 0xF, 0xF, true));
@@ -448,23 +510,42 @@ __device__ __forceinline__ uint32_t chain_run_visit(const uint32_t *sw, const ui
         pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, RSN_DPP_ROW_BCAST15, 0xA, 0xF, false));
         pe = max(pe, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pe, RSN_DPP_ROW_BCAST31, 0xC, 0xF, false));
         uint32_t a0 = __shfl_up(pe, 1);
-        a0 = max(lane ? a0 : 0u, carry);                                  // where the run that this lane's first such byte ends began
+        a0 = max(lane ? a0 : 0u, carry);                                  // the marks are absent on [a0, first): the stretch [a0 - P, first)
         carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)pe, 63));
-        uint32_t ds = 0;                                                  // the candidate whose run ends with the position's, if it is to be followed
-        if (x) {
-            const uint32_t rq = first - a0, dmax = c_irel - a0;
-            if (rq >= 2u) kb = max(kb, (min(min(r, rq), dmax) << 16) | dmax);   // (rq == r: at least that; followed below if the bytes behind the runs agree)
-            if (rq >= r && r < lim0 && (after == 0x100u || after == sb[first])) ds = c_irel - first + r;
+        uint32_t ds = 0;                                                  // the candidate whose stretch ends with p's, if it is to be followed
+        if (x && first >= a0 - P + T) {
+            uint32_t qf = 0xFFFFFFFFu;                                    // the stretch's first position that begins with U and has T bytes of the stretch in front of it
+            for (uint32_t q = a0 - P; q < a0 && q + T <= first && q < c_irel && qf == 0xFFFFFFFFu; q++) if (begins_with_unit(q)) qf = q;
+            if (qf != 0xFFFFFFFFu) {
+                const uint32_t R = first - qf, d = c_irel - qf;
+                kb = max(kb, (min(min(r, R), d) << 16) | d);              // (R == r: at least that; followed below if the bytes behind the stretches agree)
+                if (R >= r && r < lim0 && first - r < c_irel && (after == 0x100u || after == sb[first]) && begins_with_unit(first - r)) ds = c_irel - (first - r);
+            }
         }
-        for (unsigned long long am = __ballot(ds != 0); am; am &= am - 1) {
+        if (ds) {
+            // ... out of the stage as far as it shows p's bytes, every lane for itself (sparse CSV: half a dozen of a visit's forty stretches
+            // end like p's does, and each would be a load from memory the wavefront waits a microsecond or two for)
+            const uint32_t lim1 = min(ds, c_capE);
+            uint32_t off = r;
+            bool open = true;
+            while (open && off < lim1 && off + 8u <= (uint32_t)HLMAX + 24u) {
+                const unsigned long long y = lds_load8(sw, c_irel + off) ^ lds_load8(sw, c_irel - ds + off);
+                if (y) { off += (uint32_t)__builtin_ctzll(y) >> 3; open = false; } else off += 8u;
+            }
+            if (!open || off >= lim1) { kb = max(kb, (min(off, lim1) << 16) | ds); ds = 0; }
+        }
+        for (unsigned long long am = __ballot(ds != 0); am; am &= am - 1) {   // what goes on behind the stage: through memory, by the wavefront
             const int l = __builtin_ctzll(am);
             const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)ds, l), L1 = wave_first_diff(d1, r, min(d1, c_capE));
             if (lane == l) kb = max(kb, (L1 << 16) | d1);
         }
     }
     uint32_t wb = wave_max_u32(kb);
-    if (carry < c_irel) wb = max(wb, (min(r, c_irel - carry) << 16) | (c_irel - carry));   // the position's own run
-    return (wb >> 16) < 8u ? 0u : wb;
+    if (carry <= c_irel) {   // no mark in p's own unit: its stretch is [carry - P, p + r), the farthest candidate a multiple of P back
+        const uint32_t d = (c_irel - (carry - P)) / P * P;
+        if (d) wb = max(wb, (min(r, d) << 16) | d);
+    }
+    return (wb >> 16) < T ? 0u : wb;
 }
 
 template <class C>
@@ -742,13 +823,16 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 *reinterpret_cast<uint4 *>(&ws.par[slot][4]) = uint4{lo, hi, capE, 0u};
             }
             if constexpr (C::RUNS) {
-                // (r06) a heavy visit whose position stands in a run of one byte: resolved from the window's runs (chain_run_visit).  In the
-                //  kernel for streams that hold such runs only: never entered, the code still costs text 0.7 of 27.7 ms (registers), and
-                //  its gate -- the four bytes behind the position's first alike, two instructions a wavefront-iteration -- another 0.4.
-                for (unsigned long long hr = hm & __ballot((uint32_t)pat0 == (uint32_t)__builtin_amdgcn_alignbit((uint32_t)pat0, (uint32_t)pat0, 8u)); hr; hr &= hr - 1) {
+                // (r06) a heavy visit of a position in a stretch of period <= 64 -- a run of a byte, a short line repeated: resolved from the
+                //  window's stretches (chain_period_visit) before any candidate round.  In the kernel instance for such streams only:
+                //  never entered, the code still costs text 0.7 of 27.7 ms (registers of a kernel at its limits, LEDGER.md).
+                //  (Rows of a table that share 24 bytes with the row before -- "</td></tr>\n<tr><td>" -- have a period and no stretch to
+                //  speak of: resolving them this way took such data from 27 to 11 GB/s, hence the function's second gate -- two units and
+                //  more behind the first -- which a row like that fails after a hundred instructions: 26.)
+                for (unsigned long long hr = hm; hr; hr &= hr - 1) {
                     const int hl = __builtin_ctzll(hr);
                     const uint32_t c_irel = (uint32_t)__builtin_amdgcn_readlane((int)irel, hl);
-                    const uint32_t wb = chain_run_visit(sw, a.fc, c_irel, (uint32_t)__builtin_amdgcn_readlane((int)capE, hl), (uint32_t)(t0 - CH) + (c_irel - HWMAX), W, zrel, lane);
+                    const uint32_t wb = chain_period_visit<64>(sw, a.fc, c_irel, (uint32_t)__builtin_amdgcn_readlane((int)capE, hl), (uint32_t)(t0 - CH) + (c_irel - HWMAX), W, zrel, lane);
                     if (wb) {                                             // (exact; as long as a candidate followed through memory: 3. counts it as one)
                         if (lane == 0) { ws.best[(uint32_t)hl / LW] = wb; if ((wb >> 16) >= (uint32_t)HLMAX) ws.lcnt[(uint32_t)hl / LW] = 0x80000000u; }
                         hm &= ~(1ull << hl);
@@ -820,6 +904,18 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (C::RUNS) {
+                // (r06) ... and a visit the rounds leave with more long candidates than it lists -- a longer line repeated, a bucket of fewer
+                //  than 128 -- the same way, periods up to 192, before the home row would let the farthest decide or give the tile up
+                for (unsigned long long lm = __ballot(mine && leader && ws.lcnt[slot] > LCAP && !(ws.lcnt[slot] >> 31)); lm; lm &= lm - 1) {
+                    const int hl = __builtin_ctzll(lm);
+                    const uint32_t c_kp = (uint32_t)__builtin_amdgcn_readlane((int)kp, hl), c_ipos = (uint32_t)(t0 - CH) + c_kp;
+                    const uint32_t wb = chain_period_visit<192>(sw, a.fc, HWMAX + c_kp, E - c_ipos, c_ipos, W, zrel, lane);
+                    if (wb && lane == 0) { ws.best[(uint32_t)hl / LW] = max(ws.best[(uint32_t)hl / LW], wb); ws.lcnt[(uint32_t)hl / LW] = 0x80000000u; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             // ---- 3. home rows: commit
             if (mine) {
                 const uint32_t ipos = (uint32_t)(t0 - CH) + kp, irel = HWMAX + kp, capE = E - ipos;
@@ -855,7 +951,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                 else {
                     bool giveup_heavy = false, giveup_dense = false;
                     if (longm) {
-                        if (lcnt >> 31) {}                                    // resolved by the wavefront from the window's runs (2a., chain_run_visit)
+                        if (lcnt >> 31) {}                                    // resolved by the wavefront from the window's stretches (chain_period_visit)
                         else if (lcnt <= LCAP) {                                   // every long candidate is followed to its end: the maximum is exact
                             // (farthest first: a candidate at distance d matches d bytes at most, so once the best reaches further than the
                             //  farthest one left, the rest cannot win -- a 1000-periodic stream follows one candidate over 4000 bytes, not four)
@@ -872,7 +968,7 @@ __global__ __launch_bounds__(C::CTH) __attribute__((amdgpu_num_sgpr(80), amdgpu_
                             }
                         } else if (in_byte_run()) {
                             // (r06) The position stands in a run of one byte z, HLMAX of it and more ahead: zero-filled and sparse buffers, runs.
-                            // Every candidate that agrees for HLMAX bytes lies in a run of z too; chain_run_visit's argument, by the row: the
+                            // Every candidate that agrees for HLMAX bytes lies in a run of z too; chain_period_visit's argument for P = 1, by the row: the
                             // window's runs of z out of the stage, 64 bytes a trip -- a dozen candidates with exact lengths instead of
                             // thousands that all agree further than the stage reaches (the farthest of which decided, or the strip went to
                             // the sweep: a buffer with a byte in a hundred set took 0.5 GB/s).  Runs of fewer than HLMAX - 16 bytes are left
@@ -2090,7 +2186,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
     using CC = ChainCfg<8192, 1024, 64>;                           // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 64 positions
     using CCR = ChainCfg<8192, 1024, 64, true>;                     // the same walk for a stream that holds runs of a byte (k_esc_try's flag, Ctx::lz_runs; RSN_LZSS_RUNS=0 / 1: never / always -- the tests)
     static const int runs_env = [] { const char *e = getenv("RSN_LZSS_RUNS"); return e ? atoi(e) : -1; }();
-    const bool runs = runs_env < 0 ? c.lz_runs : runs_env != 0;
+    bool runs = runs_env < 0 ? c.lz_runs : runs_env != 0;
     auto launch_chain = [&](const char *name, uint32_t blocks, const ChainArgs &ca) -> int {
         if (runs) RSN_LAUNCH(name, (k_match_chain<CCR>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
         else RSN_LAUNCH(name, (k_match_chain<CC>), dim3(blocks), dim3(CC::CTH), 0, s, ca);
@@ -2194,8 +2290,25 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             return RSN_OK;
         };
         rc = resolve(false, false); if (rc) return rc;
-        parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         static const bool dbg = getenv("RSN_DEBUG") != nullptr;
+        if (!runs && runs_env < 0 && (uint32_t)h64[1]) {
+            // (r06) Some tile gave up.  If as "heavy" -- a visit's long candidates did not decide: what a line or a record repeated does to
+            // the lean instance, whose input showed the check no eight bytes alike -- the walk is done again by the instance that resolves
+            // such visits from the window's stretches.  (A heavy tile gives up at its first such visit: the first walk was short.)
+            RSN_HIP(hipMemsetAsync(d_ttot + 3, 0, 8, s));
+            RSN_LAUNCH("lzss_scan", k_count_flags, dim3((uint32_t)ceil_div(n_strips, 256)), dim3(256), 0, s, (const uint32_t *)d_heavy, n_strips, (unsigned long long *)(d_ttot + 3));
+            RSN_HIP(hipMemcpyAsync(h64 + 3, d_ttot + 3, 8, hipMemcpyDeviceToHost, s));
+            RSN_HIP(hipStreamSynchronize(s));
+            if (h64[3]) {
+                if (dbg) fprintf(stderr, "lzss chain walk: %u tiles gave up, heavy ones in %llu strips: once more with the instance for repeated stretches\n", (uint32_t)h64[1], (unsigned long long)h64[3]);
+                runs = true;
+                RSN_HIP(hipMemsetAsync(d_heavy, 0, (size_t)n_strips * 12, s));
+                RSN_HIP(hipMemsetAsync(d_ccnt, 0xFF, (size_t)n_pt * 8, s));
+                rc = launch_chain("lzss_match_chain", (uint32_t)ceil_div(E, CC::CT), ha); if (rc) return rc;
+                rc = resolve(false, false); if (rc) return rc;
+            }
+        }
+        parsed = h64[1] == 0 && (uint32_t)h64[2] == 0 && !no_fused;
         if (dbg) fprintf(stderr, "lzss chain walk: %u tiles, %u gave up, %u chains that do not join, %u periodic tiles not placed\n", n_pt, (uint32_t)h64[1], (uint32_t)(h64[1] >> 32), (uint32_t)h64[2]);
         if (dbg && (uint32_t)h64[1]) {                                    // which strips, and why (heavy: the long candidates of a visit did not decide; dense: steps of one and two bytes)
             std::vector<uint32_t> fl((size_t)n_strips * 3);
@@ -2232,7 +2345,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         for (int look = 2; look <= (use_pred ? 7 : 4) && !parsed && !no_fused; look++) {   // (a stretch is placed in the look after the one that mends the tile before it)
             const uint32_t n_list = (uint32_t)(h64[2] >> 32), n_gave = (uint32_t)h64[1], n_arith = use_pred ? (uint32_t)h64[3] : 0u;
             const uint32_t n_plain = n_list - std::min(n_list, n_arith);         // entries that are not placed by arithmetic: tiles that gave up, joints to mend
-            if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || n_plain > n_pt / 2 + 64) break;
+            if (n_list == 0 || n_list > redo_cap || (n_gave > gave_cap && !use_pred) || (n_plain > 64 && n_plain > prev_plain / 2) || (n_plain > n_pt / 2 + 64 && !(runs && look == 2))) break;   // (r06: lines repeated for longer than a tile -- the chains of a tile inside one stretch keep their phase, but every chain lands on the stretch's end: one look from the true entries mends them all, 16 MiB of log lines 38 -> ? ms)
             prev_plain = n_plain;
             ha.redo = 3u | halo_bit | (raw ? 8u : 0u); ha.tail.redo_list = d_redo_list;
             ha.tail.ckeys = nullptr; ha.tail.ckn = nullptr;                   // (a look's tiles are resolved by k_chain_tail, from the key array)
@@ -2408,6 +2521,7 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
     RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 16, s));
     RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)nullptr, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
+    RSN_LAUNCH("lzss_esc_check", k_period_sample, dim3((uint32_t)std::min<size_t>(64, std::max<size_t>(1, n / (4 * PSAMPLE_CHUNK)))), dim3(256), 0, s, d_in, n, (uint32_t)std::min<size_t>(64, std::max<size_t>(1, n / (4 * PSAMPLE_CHUNK))), d_etot + 1);
     static const bool no_tail = getenv("RSN_LZSS_NO_PERIODIC_TAIL") != nullptr;   // A/B switch (tests): a W-periodic stream through the whole pipeline
     const bool tail_cand = d_same && !no_tail && (uint64_t)window == Wp && n >= ((size_t)PERIODIC_TAIL_MIN_TILES + 2) * PT;
     if (tail_cand) RSN_LAUNCH("lzss_last_unlike", k_last_unlike, dim3((uint32_t)ceil_div(n_eb, 4096)), dim3(256), 0, s, (const uint8_t *)d_same, n_eb, d_etot + 2);
@@ -2573,6 +2687,7 @@ int lzss_encode_sliced(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, int
             const size_t upto = upto_chk, m = upto - checked;
             const uint32_t n_eb = (uint32_t)ceil_div(m, ESC_TILE);
             RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in + checked, m, (uint8_t *)nullptr, d_flag, 0u, (uint8_t *)nullptr, n_eb);
+            { const uint32_t ns = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, m / (4 * PSAMPLE_CHUNK))); RSN_LAUNCH("lzss_esc_check", k_period_sample, dim3(ns), dim3(256), 0, s, d_in + checked, m, ns, d_flag); }
             RSN_HIP(hipMemcpyAsync(h64, d_flag, 8, hipMemcpyDeviceToHost, s));
             RSN_HIP(hipStreamSynchronize(s));
             if (h64[0] & 1ull) { if (dbg) fprintf(stderr, "lzss sliced: a byte that needs an escape below position %zu: encoded whole instead\n", upto); return 1; }

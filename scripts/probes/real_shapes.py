@@ -121,6 +121,12 @@ kinds = {
     "runs up to 1000": runs,
     "runs up to 20": lambda n: runs(n, 20),
     "a document edited and repeated": edited_document,
+    "csv, nine rows in ten the same": lambda n: lines(lambda i: "0,0,0,0.0,\n" if rng.random() < 0.9 else "%d,%d,%d,%0.1f,x\n" % (rng.randint(0, 99), rng.randint(0, 9), i % 7, rng.random()), n),
+    "csv, 99 rows in 100 the same": lambda n: lines(lambda i: "0,0,0,0.0,\n" if rng.random() < 0.99 else "%d,%d,%d,%0.1f,x\n" % (rng.randint(0, 99), rng.randint(0, 9), i % 7, rng.random()), n),
+    "a log line repeated 1-300 times": lambda n: lines(lambda i: (rng.choice(["worker idle\n", "heartbeat ok 200\n", "retrying connection to 10.0.0.%d\n" % rng.randint(1, 9)])) * rng.randint(1, 300), n),
+    "utf-16 text": lambda n: text(n // 2).decode().encode("utf-16-le")[:n],
+    "32-bit integers, small": lambda n: nrng.integers(0, 1000, size=n // 4 + 1, dtype="<u4").tobytes()[:n],
+    "32-bit floats near 1": lambda n: (1.0 + nrng.random(n // 4 + 1, dtype=np.float32) * 1e-3).astype("<f4").tobytes()[:n],
     "html-like, many <": lambda n: lines(lambda i: "<tr><td>%d</td><td>%s</td></tr>\n" % (i, rng.choice(words)), n),
 }
 

@@ -941,3 +941,53 @@ def test_contenders_of_the_farthest_long_candidate_are_followed(lz, oracle, name
     c = lz.CompressAsync(data)
     assert c == oracle.lzss_compress(data)
     assert lz.Decompress(c) == data
+
+
+def _lines_mostly_alike(seed, n, common, share, alphabet="0123456789,.x"):
+    rng = random.Random(seed)
+    out, size = [], 0
+    while size < n:
+        if rng.random() < share:
+            ln = common
+        else:
+            ln = "".join(rng.choice(alphabet) for _ in range(rng.randint(1, 2 * len(common)))) + "\n"
+        out.append(ln); size += len(ln)
+    return "".join(out).encode()[:n]
+
+
+def _line_repeated(seed, n, lines, longest):
+    rng = random.Random(seed)
+    out, size = [], 0
+    while size < n:
+        k = rng.randint(1, longest)
+        ln = rng.choice(lines)
+        out.append(ln * k); size += len(ln) * k
+    return "".join(out).encode()[:n]
+
+
+_LOG = ["worker idle\n", "heartbeat ok 200\n", "retrying connection to 10.0.0.7\n", "a" * 63 + "\n", "x\n", "ab\n",
+        "GET /index.html HTTP/1.1 200 5120 \"-\" \"Mozilla/5.0 (X11; Linux x86_64) AppleWebKit/537.36\"\n"]
+
+
+@pytest.mark.parametrize("name,data", [
+    ("csv, nine rows in ten the same", _lines_mostly_alike(1, 1 << 20, "0,0,0,0.0,\n", 0.9)),
+    ("csv, 99 rows in 100 the same", _lines_mostly_alike(2, 1 << 20, "0,0,0,0.0,\n", 0.99)),
+    ("csv, half the rows the same", _lines_mostly_alike(3, 700000, "1,2,3\n", 0.5)),
+    ("a two-byte line, nine in ten", _lines_mostly_alike(4, 600000, "0\n", 0.9, "01")),
+    ("a 64-byte row, 19 in 20", _lines_mostly_alike(5, 1 << 20, "0123456789abcdef" * 3 + "0123456789abcde\n", 0.95)),
+    ("log lines repeated up to 300 times", _line_repeated(6, 1 << 20, _LOG, 300)),
+    ("log lines repeated up to 20 times", _line_repeated(7, 1 << 20, _LOG, 20)),
+    ("log lines repeated up to 3000 times", _line_repeated(8, 1 << 20, _LOG[:4], 3000)),
+    ("the same line with < and a backslash in it", _line_repeated(9, 500000, ["<a href=\\x>\n", "<b>\n", "\\\\\n"], 200)),
+    ("short period, then text, then the period again", (b"abcabd" * 3000 + text(20, 30000) + b"abcabd" * 2000 + text(21, 5000)) * 6),
+    ("periods 2, 3, 5, 7, 11, 13 in turn", b"".join((bytes(range(97, 97 + p)) * (9000 // p + i)) for i in range(40) for p in (2, 3, 5, 7, 11, 13))),
+    ("a period of 64 and one of 65", (bytes(range(48, 112)) * 300 + bytes(range(48, 113)) * 300) * 10),
+    ("utf-16 zeros between letters, lines repeated", _line_repeated(10, 600000, ["ok\n", "fail\n"], 500).decode().encode("utf-16-le")),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_repeated_lines_are_resolved_in_the_walk(lz, oracle, name, data):
+    """r06: a position in a stretch of a short period -- a line or a record repeated -- is resolved from the window's stretches
+    (chain_period_visit); the lean instance of the walk gives such tiles up and the walk is done again by the other.
+    The oracle's bytes."""
+    c = lz.CompressAsync(data)
+    assert c == oracle.lzss_compress(data)
+    assert lz.Decompress(c) == data
