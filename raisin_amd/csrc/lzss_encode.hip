@@ -246,12 +246,14 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
 // walked before giving up is lost (sparse CSV, 16 MiB: 3 of 6 ms).  A sample instead: up to 64 chunks of 4 KiB spread over the input, every
 // eighth position asks whether its 24 bytes come again within 64; a chunk where one in fifty does raises the flag.  Text: none.
 constexpr uint32_t PSAMPLE_CHUNK = 4096, PSAMPLE_MAX_P = 64;
-__global__ __launch_bounds__(256) void k_period_sample(const uint8_t *__restrict__ in, size_t n, uint32_t n_samples, unsigned long long *__restrict__ flag) {
+// (the block's threads all call it; which: the sample's index, < n_samples.  As a function: a large input's sample rides on k_last_unlike's
+//  launch -- config 3's 0.54 ms call has no 0.02 ms for a launch of its own)
+__device__ __forceinline__ void period_sample_block(const uint8_t *__restrict__ in, size_t n, uint32_t n_samples, uint32_t which, unsigned long long *__restrict__ flag) {
     __shared__ __attribute__((aligned(16))) uint32_t s_w[(PSAMPLE_CHUNK + PSAMPLE_MAX_P + 32 + 16) / 4];
     __shared__ uint32_t s_hits;
     const size_t span = PSAMPLE_CHUNK + PSAMPLE_MAX_P + 32;
-    if (n < span) return;
-    const size_t at = n_samples > 1 ? (size_t)((unsigned __int128)(n - span) * blockIdx.x / (n_samples - 1)) & ~(size_t)15 : 0;
+    if (n < span || which >= n_samples) return;
+    const size_t at = n_samples > 1 ? (size_t)((unsigned __int128)(n - span) * which / (n_samples - 1)) & ~(size_t)15 : 0;
     for (uint32_t v = threadIdx.x; v < span / 16; v += 256) reinterpret_cast<uint4 *>(s_w)[v] = *reinterpret_cast<const uint4 *>(in + at + 16 * (size_t)v);
     if (threadIdx.x == 0) s_hits = 0;
     __syncthreads();
@@ -266,6 +268,9 @@ __global__ __launch_bounds__(256) void k_period_sample(const uint8_t *__restrict
     if (hits) atomicAdd(&s_hits, hits);
     __syncthreads();
     if (threadIdx.x == 0 && s_hits * 50u >= PSAMPLE_CHUNK / 8u && !(__atomic_load_n(flag, __ATOMIC_RELAXED) & 4ull)) atomicOr(flag, 4ull);
+}
+__global__ __launch_bounds__(256) void k_period_sample(const uint8_t *__restrict__ in, size_t n, uint32_t n_samples, unsigned long long *__restrict__ flag) {
+    period_sample_block(in, n, n_samples, blockIdx.x, flag);
 }
 
 // k_tile_periodic's records from k_esc_try's block flags: a tile is W-periodic iff every block that overlaps [t0, t0 + tile + W - 1) repeats
@@ -2440,7 +2445,9 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
 // emit kernel per tile: 0.94 ms of which the one pass that has to read the input (the check) is 0.25.  Now: the check, the ordinary
 // encoder on the head [0, S + W) stopped in front of tile S / 8192 (the sections' mechanism: what the items before that tile emit, and
 // where the chain goes on), and one kernel that writes the rest.
-__global__ __launch_bounds__(256) void k_last_unlike(const uint8_t *__restrict__ same_blk, uint32_t n_chunks, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_last_unlike(const uint8_t *__restrict__ same_blk, uint32_t n_chunks, unsigned long long *__restrict__ out,
+                                                     const uint8_t *__restrict__ in, size_t n, uint32_t n_samples, unsigned long long *__restrict__ flag) {
+    period_sample_block(in, n, n_samples, blockIdx.x, flag);             // (r06: the sample for short periods rides along, see k_period_sample)
     // 1 + the index of the last chunk that does not repeat (chunk 0 never does): sixteen flags per thread, one atomic per wavefront that
     // has anything to say (a periodic stream: block 0's first; text: every one of them -- 256 atomics per MiB of flags = per 4 GiB of input)
     const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
@@ -2521,10 +2528,11 @@ static int lzss_encode_admitted(Ctx &c, hipStream_t s, const uint8_t *d_in, size
     if (Wp) { void *sp; rc = dev_buf(c, 35, (size_t)n_eb + 64, &sp); if (rc) return rc; d_same = (uint8_t *)sp; }
     RSN_HIP(hipMemsetAsync(d_etot + 1, 0, 16, s));
     RSN_LAUNCH("lzss_esc_check", k_esc_try, dim3((uint32_t)ceil_div(n_eb, ESC_RUN)), dim3(LB), 0, s, d_in, n, (uint8_t *)nullptr, d_etot + 1, d_same ? Wp : 0u, d_same, n_eb);
-    RSN_LAUNCH("lzss_esc_check", k_period_sample, dim3((uint32_t)std::min<size_t>(64, std::max<size_t>(1, n / (4 * PSAMPLE_CHUNK)))), dim3(256), 0, s, d_in, n, (uint32_t)std::min<size_t>(64, std::max<size_t>(1, n / (4 * PSAMPLE_CHUNK))), d_etot + 1);
     static const bool no_tail = getenv("RSN_LZSS_NO_PERIODIC_TAIL") != nullptr;   // A/B switch (tests): a W-periodic stream through the whole pipeline
     const bool tail_cand = d_same && !no_tail && (uint64_t)window == Wp && n >= ((size_t)PERIODIC_TAIL_MIN_TILES + 2) * PT;
-    if (tail_cand) RSN_LAUNCH("lzss_last_unlike", k_last_unlike, dim3((uint32_t)ceil_div(n_eb, 4096)), dim3(256), 0, s, (const uint8_t *)d_same, n_eb, d_etot + 2);
+    const uint32_t n_psamp = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, n / (4 * PSAMPLE_CHUNK)));
+    if (tail_cand) RSN_LAUNCH("lzss_last_unlike", k_last_unlike, dim3(std::max((uint32_t)ceil_div(n_eb, 4096), n_psamp)), dim3(256), 0, s, (const uint8_t *)d_same, n_eb, d_etot + 2, d_in, n, n_psamp, d_etot + 1);
+    else RSN_LAUNCH("lzss_esc_check", k_period_sample, dim3(n_psamp), dim3(256), 0, s, d_in, n, n_psamp, d_etot + 1);
     RSN_HIP(hipMemcpyAsync(h64, d_etot + 1, 16, hipMemcpyDeviceToHost, s));
     RSN_HIP(hipStreamSynchronize(s));
     copied = (h64[0] & 1ull) == 0;
