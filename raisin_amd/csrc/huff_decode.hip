@@ -1093,6 +1093,8 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
     // ---- the phase solver (k_dec_phase): RSN_OK = the arrays hold the true path; 1 = it gave up (the passes go on)
     auto phase_solve = [&]() -> int {
         static const bool dbg2 = getenv("RSN_DEBUG") != nullptr;
+        const auto ph_t0 = std::chrono::steady_clock::now();
+        auto ph_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ph_t0).count(); };
         const size_t nbk = n_blk;
         void *pp2; int r2 = dev_buf(c, 34, nbk * (PH_CAND * 8 + 1) + 256, &pp2); if (r2) return r2;
         PhaseArgs ph{};
@@ -1118,10 +1120,14 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
         r2 = launch_phase(0); if (r2) return r2;
         RSN_HIP(hipMemcpyAsync(hmap, ph.blk_map, nbk * PH_CAND * 8, hipMemcpyDeviceToHost, s));
         RSN_HIP(hipStreamSynchronize(s));
+        if (dbg2) fprintf(stderr, "huffman decode, phases: +%.3f ms: every entry of every lane walked, the blocks' maps on the host\n", ph_ms());
         // the blocks chained: block 0 is entered at the stream's first code bit (bit 0 of its table), block b + 1 at the bit b left at
         std::vector<uint8_t> tc(nbk, 0xFF);
         uint32_t e = 0;
         for (size_t b = 0; b < nbk; b++) {
+            // (the maps have just come in by DMA: every block's two lines are misses, and which entry is read depends on the block before --
+            //  6802 blocks took 0.8-1.0 ms of a 2.5 ms decode; fetched sixteen blocks ahead: 0.03)
+            if (b + 16 < nbk) for (uint32_t k = 0; k < ph.cand; k += 8) __builtin_prefetch(&hmap[(b + 16) * PH_CAND + k]);
             if (e == BAD_REL) break;                                          // (the stream ran off its payload: the rest stays 0xFF)
             if (e >= ph.cand) { if (dbg2) fprintf(stderr, "huffman decode, phases: block %zu is entered at bit %u\n", b, e); return 1; }
             const uint2 m = hmap[b * PH_CAND + e];
@@ -1129,9 +1135,11 @@ int huff_decode_dev(Ctx &c, hipStream_t s, const uint8_t *d_in, size_t n, uint8_
             tc[b] = (uint8_t)e;
             e = m.x;
         }
+        if (dbg2) fprintf(stderr, "huffman decode, phases: +%.3f ms: the blocks chained\n", ph_ms());
         RSN_HIP(hipMemcpyAsync(d_true, tc.data(), nbk, hipMemcpyHostToDevice, s));
         r2 = launch_phase(2); if (r2) return r2;
         RSN_HIP(hipStreamSynchronize(s));                                     // (tc is host memory: the copy has left it)
+        if (dbg2) fprintf(stderr, "huffman decode, phases: +%.3f ms: the true path written\n", ph_ms());
         if (dbg2) fprintf(stderr, "huffman decode: settled by every entry of every lane (%u blocks, %u entries a lane)\n", n_blk, ph.cand);
         return RSN_OK;
     };
