@@ -227,3 +227,47 @@ def test_periodic_tail_fuzz(mods, oracle, seed):
         extra = b"<%d,%d>" % (P, P) * rng.randint(2, 1300000 // (P + 1) + 2) + rng.choice((b"", b"<%d,%d>" % (P, rng.randint(0, P)), b"end\xff."))
         stream = want + extra
         assert lz.Decompress(stream) == oracle.lzss_decompress(stream), (seed, P, len(extra))
+
+
+def _stretches(rng, n):
+    """Units of 1 to 200 bytes repeated 1 to 400 times, between them now and then a few bytes of anything, a stretch of text, a copy of an
+    earlier stretch's unit shifted by a byte or cut short -- what chain_period_visit's keys are worked out from (r06)."""
+    alphabets = [b"ab", b"0,.\n", b"abcdefghijklmnopqrstuvwxyz \n", bytes(range(32, 127)), b"\x00\x01\x02\xfe", b"<>\\a"]
+    out = bytearray()
+    units = []
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.6 or not units:
+            al = rng.choice(alphabets)
+            p = rng.choice((1, 1, 2, 3, 4, 5, 7, 8, 11, 12, 16, 17, 31, 33, 63, 64, 65, 100, 191, 192, 193, 200))
+            u = bytes(rng.choice(al) for _ in range(p))
+            units.append(u)
+        elif r < 0.8:
+            u = rng.choice(units)                                    # the same unit again: a stretch further back that ends differently
+        else:
+            u = rng.choice(units)
+            k = rng.randrange(len(u))
+            u = u[k:] + u[:k] if rng.random() < 0.5 else u[: max(1, len(u) - 1)]   # a rotation of it, or the unit a byte shorter
+        reps = rng.choice((1, 2, 3, 5, 9, 30, 100, 400))
+        body = u * reps
+        cut = rng.randrange(len(u)) if rng.random() < 0.5 else 0  # the stretch ends inside a unit
+        out += body[: len(body) - cut]
+        r2 = rng.random()
+        if r2 < 0.3:
+            out += bytes(rng.choice(rng.choice(alphabets)) for _ in range(rng.randint(1, 9)))
+        elif r2 < 0.4:
+            out += bytes(rng.choice(alphabets[2]) for _ in range(rng.randint(50, 3000)))
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(16 * MORE))
+def test_stretches_of_short_periods_fuzz(mods, oracle, seed):
+    """r06: the walk's arithmetic for positions inside a stretch of a short period against the oracle's search, on streams made of such
+    stretches -- windows 4096, 1024 and 300, so that stretches begin before the window, inside it and at its edge."""
+    lz, _, _ = mods
+    rng = random.Random(9000 + seed)
+    data = _stretches(rng, rng.choice((40000, 150000, 400000)))
+    for w in ((4096,) if seed % 4 else (4096, 1024, 300)):
+        c = lz.CompressAsync(data, False, w)
+        assert c == oracle.lzss_compress(data, w), "seed %d, window %d" % (seed, w)
+    assert lz.Decompress(c) == data
