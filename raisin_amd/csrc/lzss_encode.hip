@@ -168,7 +168,7 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
         uint4 v[ESC_RUN + 1];
 #pragma unroll
         for (int k = 0; k <= ESC_RUN; k++) v[k] = p[(k - 1) * (ESC_TILE / 16)];
-        uint32_t same_bits = 0, special = 0, lt = 0, unlike = ~0u;                 // unlike: zero once a 16-byte unit began with eight bytes alike (see `seen` below)
+        uint32_t same_bits = 0, special = 0, lt = 0;
         // (r06: "is there a byte equal to X" as an ACCUMULATED zero-byte test -- (t - 0x01010101) & ~t has bit 7 of a byte set iff that byte
         //  of t = w ^ XXXX is zero or lies above one that is: exact for existence, four instructions a value and dword instead of seven)
         auto zacc = [](uint32_t w, uint32_t x4) { const uint32_t t = w ^ x4; return (t - 0x01010101u) & ~t; };
@@ -179,14 +179,13 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
             for (int j = 0; j < 4; j++) { special |= zacc(w[j], 0x5C5C5C5Cu) | zacc(w[j], 0xFFFFFFFFu); lt |= zacc(w[j], 0x3C3C3C3Cu); }
-            unlike = min(unlike, (w[0] ^ w[1]) | (w[0] ^ (uint32_t)__builtin_amdgcn_alignbit(w[0], w[0], 8u)));
         }
         special &= 0x80808080u; lt &= 0x80808080u;
         __shared__ uint32_t s_and[LB / 64], s_any[LB / 64];
         uint32_t wave_and = 0;
 #pragma unroll
         for (int k = 0; k < ESC_RUN; k++) wave_and |= (__ballot((same_bits >> k) & 1u) == ~0ull ? 1u : 0u) << k;
-        const uint32_t wave_any = (__ballot(special != 0) ? 1u : 0u) | (__ballot(lt != 0) ? 2u : 0u) | (__ballot(unlike == 0) ? 4u : 0u);
+        const uint32_t wave_any = (__ballot(special != 0) ? 1u : 0u) | (__ballot(lt != 0) ? 2u : 0u);   // (bit 2, "holds runs of a byte or stretches of a short period", is the sample's: period_sample_block -- measured here as five more instructions per 16 bytes it cost config 3's check 0.24 -> 0.26 ms)
         if ((threadIdx.x & 63) == 0) { s_and[threadIdx.x >> 6] = wave_and; s_any[threadIdx.x >> 6] = wave_any; }
         __syncthreads();
         uint32_t all = ~0u, any = 0;
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
     }
     uint32_t prev[4] = {0, 0, 0, 0};
     int prev_cnt = -1;                                                     // -1: nothing in `prev` (the run's first chunk, or Wp is not a chunk)
-    uint32_t seen = 0;                                                     // bit 2 (r06): a 16-byte unit that begins with eight bytes alike -- the stream holds runs of a byte: k_match_chain<RUNS> is its walk
+    uint32_t seen = 0;                                                     // (bit 2 of the flag word, r06: the stream holds runs of a byte or stretches of a short period -- k_match_chain<RUNS> is its walk; set by period_sample_block)
                                                                            // bit 0: a 5C / FF, bit 1: a '<' -- one look at the flag per BLOCK, at the end (r05: a stream with a '<' in
                                                                            // every wavefront's 1 KiB -- config 3 -- had sixteen million wavefronts read the one flag word: 0.44 ms against 0.25)
     for (uint32_t k = 0; k < (uint32_t)ESC_RUN; k++) {
@@ -220,7 +219,6 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             prev[0] = w[0]; prev[1] = w[1]; prev[2] = w[2]; prev[3] = w[3]; prev_cnt = cnt;   // (the INPUT bytes: before '<' becomes FF below)
         }
         uint32_t special = 0, lt = 0;
-        if (cnt >= 8 && ((w[0] ^ w[1]) | (w[0] ^ (uint32_t)__builtin_amdgcn_alignbit(w[0], w[0], 8u))) == 0) seen |= 4u;
 #pragma unroll
         for (int j = 0; j < 4; j++) { special |= bytes_equal(w[j], 0x5Cu) | bytes_equal(w[j], 0xFFu); const uint32_t m = bytes_equal(w[j], 0x3Cu); lt |= m; w[j] |= m; }
         seen |= (special != 0 ? 1u : 0u) | (lt != 0 ? 2u : 0u);
@@ -234,17 +232,19 @@ __global__ __launch_bounds__(LB) void k_esc_try(const uint8_t *__restrict__ in, 
             if (threadIdx.x == 0) same_blk[chunk] = (uint8_t)all;
         }
     }
-    const int any1 = __syncthreads_or(seen & 1u), any2 = __syncthreads_or(seen & 2u), any4 = __syncthreads_or(seen & 4u);
+    const int any1 = __syncthreads_or(seen & 1u), any2 = __syncthreads_or(seen & 2u);
     if (threadIdx.x == 0) {
-        const unsigned long long want = (any1 ? 1ull : 0ull) | (any2 ? 2ull : 0ull) | (any4 ? 4ull : 0ull);
+        const unsigned long long want = (any1 ? 1ull : 0ull) | (any2 ? 2ull : 0ull);
         if (want & ~__atomic_load_n(flag, __ATOMIC_RELAXED)) atomicOr(flag, want);
     }
 }
 
-// (r06) Does the input hold stretches of a short period -- a line or a record repeated?  k_esc_try's third flag only sees eight bytes alike
-// (a period of one); a walk by the lean instance of k_match_chain that ends in "heavy" tiles is done again by the other, but what it
-// walked before giving up is lost (sparse CSV, 16 MiB: 3 of 6 ms).  A sample instead: up to 64 chunks of 4 KiB spread over the input, every
-// eighth position asks whether its 24 bytes come again within 64; a chunk where one in fifty does raises the flag.  Text: none.
+// (r06) Does the input hold runs of a byte or stretches of a short period -- a zero-filled buffer, a line or a record repeated?  Then the
+// walk is k_match_chain<RUNS>'s.  A walk by the lean instance that ends in "heavy" tiles is done again by the other, but what it walked
+// before giving up is lost (sparse CSV, 16 MiB: 3 of 6 ms).  A sample instead, into bit 2 of the check's flag word: up to 64 chunks of
+// 4 KiB spread over the input, every eighth position asks whether its 24 bytes come again within 64; a chunk where one in fifty does
+// raises the flag.  Text: none.  (Eight bytes alike at a 16-byte boundary, tested by k_esc_try on all of the input, was the first form:
+// five instructions per 16 bytes that cost config 3's check 0.24 -> 0.26 ms.)
 constexpr uint32_t PSAMPLE_CHUNK = 4096, PSAMPLE_MAX_P = 64;
 // (the block's threads all call it; which: the sample's index, < n_samples.  As a function: a large input's sample rides on k_last_unlike's
 //  launch -- config 3's 0.54 ms call has no 0.02 ms for a launch of its own)
@@ -2302,7 +2302,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         static const bool dbg = getenv("RSN_DEBUG") != nullptr;
         if (!runs && runs_env < 0 && (uint32_t)h64[1]) {
             // (r06) Some tile gave up.  If as "heavy" -- a visit's long candidates did not decide: what a line or a record repeated does to
-            // the lean instance, whose input showed the check no eight bytes alike -- the walk is done again by the instance that resolves
+            // the lean instance, whose input showed the sample nothing -- the walk is done again by the instance that resolves
             // such visits from the window's stretches.  (A heavy tile gives up at its first such visit: the first walk was short.)
             RSN_HIP(hipMemsetAsync(d_ttot + 3, 0, 8, s));
             RSN_LAUNCH("lzss_scan", k_count_flags, dim3((uint32_t)ceil_div(n_strips, 256)), dim3(256), 0, s, (const uint32_t *)d_heavy, n_strips, (unsigned long long *)(d_ttot + 3));
