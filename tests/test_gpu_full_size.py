@@ -399,3 +399,31 @@ def test_lzss_windows_other_than_the_engines_at_size(oracle, w, mib):
     assert ok, "window %d: differs from the oracle's CompressAsync output in the segment at compressed offset %d" % (w, bad)
     back = lz.decompress_tensor(got)
     assert back.numel() == src.numel() and torch.equal(back, src)
+
+
+def test_lzss_runs_and_repeated_rows_at_size(oracle):
+    """r06: about 512 MiB made of a sparse buffer, byte runs and rows repeated -- the chain walk's instance for stretches of short periods with
+    65536 tiles and the serial in-tile parse (from 256 MiB).  Properties: the round trip; the stream of the first 1 MiB encoded alone is
+    the oracle's; the whole stream BEGINS with the bytes of the oracle's stream for that megabyte up to its last item (the chain of a
+    prefix does not depend on what follows it beyond the last match's reach)."""
+    import torch
+    from raisin_amd import lz
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    n = 128 << 20
+    sparse = torch.where(torch.rand(n, device="cuda", generator=g) < 0.01, torch.randint(1, 128, (n,), device="cuda", generator=g, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8, device="cuda"))
+    runs = torch.repeat_interleave(torch.randint(97, 123, (n // 300 + 1,), device="cuda", generator=g, dtype=torch.uint8), torch.randint(1, 600, (n // 300 + 1,), device="cuda", generator=g))[:n]
+    row = torch.tensor(list(b"0,0,0,0.0,\n"), dtype=torch.uint8, device="cuda")
+    rows = row.repeat(n // 11 + 1)[:n].clone()
+    idx = torch.randint(0, n // 11, (n // 110,), device="cuda", generator=g) * 11          # a row in ten begins with another digit
+    rows[idx] = torch.randint(49, 58, (idx.numel(),), device="cuda", generator=g, dtype=torch.uint8)
+    line = torch.tensor(list(b"worker idle\n"), dtype=torch.uint8, device="cuda").repeat(n // 12 + 1)[:n].clone()
+    line[torch.randint(0, n, (n // 5000,), device="cuda", generator=g)] = 88                # the line broken every five thousand bytes or so
+    src = torch.cat([sparse, runs, rows, line]).contiguous()
+    c = lz.compress_tensor(src)
+    d = lz.decompress_tensor(c)
+    assert d.numel() == src.numel() and torch.equal(d, src)
+    head = bytes(src[: 1 << 20].cpu().numpy())
+    want = oracle.lzss_compress(head)
+    assert lz.CompressAsync(head) == want
+    k = max(want.rfind(b"<", 0, len(want) - 64), 0)                                          # up to the last token that begins well before the prefix's end
+    assert bytes(c[:k].cpu().numpy()) == want[:k]
