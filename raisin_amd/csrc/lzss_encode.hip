@@ -2170,6 +2170,7 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
         // (r05: a block's time is its (strip + W) / 64 position blocks in a row -- 8 ms for 16384 positions under the engine's window -- so a
         //  short stream is swept in shorter strips: 1 MiB of a period broken every 100 KB 15.7 -> 4 ms, scripts/probes/periodic_lzss.py)
         uint32_t strip = n_strips <= 64 ? 2048u : n_strips <= 1024 ? 4096u : (uint32_t)MATCH_STRIP;
+        bool wide = false;                                            // sixteen wavefronts a block instead of four (see k_match2)
         if (only) {
             // (r06) ... and what counts is how many strips are flagged, not how long the stream is: 16 MiB of 256-byte records with a
             // counter had three heavy strips of 2081 tiles and waited 7.9 ms of its 10.2 for three blocks.  Shorter strips while the
@@ -2184,13 +2185,16 @@ static int lzss_encode_stream(Ctx &c, hipStream_t s, const uint8_t *d_fc, uint32
             uint32_t fine = 512u;
             while (fine < (uint32_t)MATCH_STRIP && flagged * ((uint64_t)MATCH_STRIP / fine) > 128) fine *= 2;
             strip = std::min(strip, fine);
+            static const int wide_env = [] { const char *e = getenv("RSN_LZSS_SWEEP_WIDE"); return e ? atoi(e) : -1; }();   // A/B switch: 0 never, 1 whenever the window allows
+            wide = wide_env != 0 && W >= 1024;                        // (a sweep of flagged strips: 4.8 -> 4.05 ms on a period of 256 broken every 100 KB, 1 MiB; 9.1 -> 8.7 at 8 MiB; the mixed 96 MiB stream's 15 strips 4.3 -> 4.1)
             static const bool dbg_sweep = getenv("RSN_DEBUG") != nullptr;
             if (dbg_sweep) fprintf(stderr, "lzss sweep: %llu of %u strips flagged, blocks of %u positions\n", (unsigned long long)flagged, n_strips, strip);
         }
-        MatchArgs m2{d_fc, E, W, (W + MW2 - 1) / MW2, d_keys, only, strip};
-        const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * MW2 + 16;
-        const size_t shmem2 = (size_t)((strip + WUB + W4b + 15) & ~15u) + (size_t)MW2 * ((m2.DW + 1) / 2) * 4 + 2 * MW2 * 64 * 4 + 16;
-        return lzss_launch_match2(c, s, m2, (uint32_t)ceil_div(E, strip), shmem2);
+        const uint32_t mw = wide ? (uint32_t)MW2_WIDE : (uint32_t)MW2;
+        MatchArgs m2{d_fc, E, W, (W + mw - 1) / mw, d_keys, only, strip};
+        const uint32_t WUB = (W + 63) / 64 * 64, W4b = m2.DW * mw + 16;
+        const size_t shmem2 = (size_t)((strip + WUB + W4b + 15) & ~15u) + (size_t)mw * ((m2.DW + 1) / 2) * 4 + 2 * mw * 64 * 4 + 16;
+        return lzss_launch_match2(c, s, m2, (uint32_t)ceil_div(E, strip), shmem2, wide);
     };
     using CC = ChainCfg<8192, 1024, 64>;                           // 8192-position tiles (= parse tiles), 16 wavefronts, a start every 64 positions
     using CCR = ChainCfg<8192, 1024, 64, true>;                     // the same walk for a stream that holds runs of a byte (k_esc_try's flag, Ctx::lz_runs; RSN_LZSS_RUNS=0 / 1: never / always -- the tests)

@@ -16,6 +16,7 @@ struct MatchArgs {
     const uint32_t *only;                                      // non-null: sweep only the strips flagged here (k_match_hash's hand-backs), a flag per MATCH_STRIP positions
     uint32_t strip;                                            // positions per block: MATCH_STRIP, or a smaller multiple of 64 that divides it
 };
+constexpr int MW2_WIDE = 16;            // ... and where only a handful of strips are swept: a strip's latency is what the call waits for
 constexpr int MW2 = 4;                  // wavefronts per block of the packed sweep: fewer, longer diagonal ranges (less pipeline fill)
 
 constexpr int HT = 4096;                 // positions per block
@@ -44,7 +45,7 @@ __device__ __forceinline__ unsigned long long lds_load8(const uint32_t *sw, uint
 #endif
 
 // the launches (lzss_match.hip); shmem2: k_match2's dynamic LDS for this window
-int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2);
+int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2, bool wide = false);   // wide: MW2_WIDE wavefronts a block (m2.DW and shmem2 worked out for it)
 int lzss_launch_match_hash(Ctx &c, hipStream_t s, const HashArgs &h);
 
 }  // namespace rsn

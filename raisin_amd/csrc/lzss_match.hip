@@ -57,37 +57,40 @@ __device__ __forceinline__ void match2_chunk(const uint8_t *ybase, long long y0,
     }
 }
 
-__global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
+// (MW: wavefronts per block.  MW = 4 where the flagged strips fill the chip -- fewer, longer diagonal ranges, less pipeline fill; 16 for a
+//  handful of strips, r06: a block's time is its position blocks in a row times the steps of a wavefront's diagonal range, 575 or 191)
+template <int MW>
+__global__ __launch_bounds__(MW * 64) void k_match2(MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t W4 = a.DW * MW2 + 16;                      // lead-in of the staged region (+16: the high half of an odd DW reads one byte further)
+    const uint32_t W4 = a.DW * MW + 16;                      // lead-in of the staged region (+16: the high half of an odd DW reads one byte further)
     const uint32_t WUB = (a.W + 63) / 64 * 64;
     const uint32_t STRIP = a.strip;                                   // positions of this block (r05: MATCH_STRIP, or less where the strips are few -- a block's
                                                                       // time is (STRIP + W) / 64 position blocks in a row, and 64 blocks leave three CUs in four idle)
     const uint32_t RLEN = (STRIP + WUB + W4 + 15) & ~15u;
     const uint32_t H = (a.DW + 1) / 2;                                // diagonals per half
     uint8_t *s_b = smem;
-    uint32_t *s_carry = reinterpret_cast<uint32_t *>(smem + RLEN);    // [MW2][H] packed runs entering from the block above
-    uint32_t *s_comb = s_carry + MW2 * H;                     // [2][MW2][64]
+    uint32_t *s_carry = reinterpret_cast<uint32_t *>(smem + RLEN);    // [MW][H] packed runs entering from the block above
+    uint32_t *s_comb = s_carry + MW * H;                     // [2][MW][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.only && !a.only[(size_t)blockIdx.x * STRIP / MATCH_STRIP]) return;   // (the flags are per MATCH_STRIP positions)
     const long long b0 = (long long)blockIdx.x * STRIP;
     const long long r0 = b0 - (long long)W4;
-    for (uint32_t i = tid; i < RLEN; i += MW2 * 64) {
+    for (uint32_t i = tid; i < RLEN; i += MW * 64) {
         const long long p = r0 + i;
         s_b[i] = (p >= 0 && p < (long long)a.E) ? a.fc[p] : 0;
     }
-    for (uint32_t i = tid; i < MW2 * H; i += MW2 * 64) s_carry[i] = 0;
+    for (uint32_t i = tid; i < MW * H; i += MW * 64) s_carry[i] = 0;
     __syncthreads();
     {   // Shortcut for W-periodic stretches: a match on diagonal W that fills the whole window (or reaches the end of the stream)
         // cannot be beaten -- L <= W, and W is the largest distance, i.e. the leftmost occurrence.  If that holds for every position
         // of the strip (no mismatch fc[q] != fc[q-W] anywhere in [b0, b0+STRIP+W)), the search is skipped.
         const long long q_end = min(b0 + (long long)STRIP + (long long)a.W - 1, (long long)a.E);
         bool ok = b0 >= (long long)a.W;
-        if (ok) for (long long q = b0 + tid; q < q_end; q += MW2 * 64) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
+        if (ok) for (long long q = b0 + tid; q < q_end; q += MW * 64) ok = ok && (s_b[q - r0] == s_b[q - (long long)a.W - r0]);
         if (__syncthreads_and(ok)) {
-            for (long long p = b0 + tid; p < min(b0 + (long long)STRIP, (long long)a.E); p += MW2 * 64) {
+            for (long long p = b0 + tid; p < min(b0 + (long long)STRIP, (long long)a.E); p += MW * 64) {
                 const uint32_t L = (uint32_t)min((long long)a.W, (long long)a.E - p);
                 a.keys[p] = (L << 16) | a.W;
             }
@@ -124,13 +127,13 @@ __global__ __launch_bounds__(MW2 * 64) void k_match2(MatchArgs a) {
             const uint32_t co = t0 - (uint32_t)lane;                  // value of step k sits in lane 63-k
             if (co < Hk_lo) carry[co] = vCout;
         }
-        uint32_t *comb = s_comb + (pb & 1) * (MW2 * 64);
+        uint32_t *comb = s_comb + (pb & 1) * (MW * 64);
         comb[wv * 64 + lane] = max(best2 & 0xFFFFu, best2 >> 16);
         __syncthreads();
         if (wv == 0 && pb < (int)(STRIP / 64) && p < (long long)a.E) {
             uint32_t L = comb[lane];
 #pragma unroll
-            for (int w = 1; w < MW2; w++) L = max(L, comb[w * 64 + lane]);
+            for (int w = 1; w < MW; w++) L = max(L, comb[w * 64 + lane]);
             a.keys[p] = L << 16;                                      // distance filled in later for chain positions that need it
         }
     }
@@ -345,9 +348,14 @@ __global__ __launch_bounds__(HTH) void k_match_hash(HashArgs a) {
     if (tid == 0 && s_heavy) a.heavy[blockIdx.x / (MATCH_STRIP / HT)] = 1;
 }
 
-int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2) {
-    { const int rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_match2), shmem2); if (rc) return rc; }
-    RSN_LAUNCH("lzss_match", k_match2, dim3(n_blocks), dim3(MW2 * 64), shmem2, s, m2);
+int lzss_launch_match2(Ctx &c, hipStream_t s, const MatchArgs &m2, uint32_t n_blocks, size_t shmem2, bool wide) {
+    if (wide) {
+        { const int rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_match2<MW2_WIDE>), shmem2); if (rc) return rc; }
+        RSN_LAUNCH("lzss_match", k_match2<MW2_WIDE>, dim3(n_blocks), dim3(MW2_WIDE * 64), shmem2, s, m2);
+        return RSN_OK;
+    }
+    { const int rc = func_dyn_lds(c, reinterpret_cast<const void *>(k_match2<MW2>), shmem2); if (rc) return rc; }
+    RSN_LAUNCH("lzss_match", k_match2<MW2>, dim3(n_blocks), dim3(MW2 * 64), shmem2, s, m2);
     return RSN_OK;
 }
 
