@@ -138,6 +138,16 @@ def test_large_alphabet_tree_matches_oracle(built, oracle):
     assert huffman.parse_header(header) == sorted(counts.items())
     wide, _ = huffman.plan({r: c << 33 for r, c in counts.items()})
     assert wide == want
+    # (r06: the sifts take three levels a step, frequencies and ids in arrays of their own) a table of 2b's shape: most runes once or
+    # twice, a few thousand around sixty times, a few often -- sixteen levels of heap
+    runes = rng.sample([r for r in range(0x20, 0x10FFFF) if not 0xD800 <= r < 0xE000 and r != 0x5C], 60000)
+    counts = {r: (1 if i < 42000 else 2 if i < 48000 else 3 if i < 49000 else rng.randint(40, 90) if i < 59800 else rng.randint(5000, 9000)) for i, r in enumerate(runes)}
+    text = [r for r, c in counts.items() for _ in range(c)]
+    rng.shuffle(text)
+    data = "".join(map(chr, text)).encode("utf-8")
+    want = [(r, c, l) for r, f, c, l in oracle.huffman_table(data)]
+    assert huffman.plan(counts)[0] == want
+    assert huffman.plan({r: c << 33 for r, c in counts.items()})[0] == want
 
 
 def test_header_parse_quirks(built):
