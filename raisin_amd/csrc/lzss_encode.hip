@@ -13,6 +13,9 @@
 //                      often a bigram recurs in the window; exact, hands pathological strips back
 //        k_match2      general case / hand-backs: diagonal sweep, O(1) per (position, distance)
 //                      pair whatever the data (two diagonals per lane, lengths only: the distance is recovered where it matters)
+//        k_match_chain the fast path (r03-): the keys only where greedy chains land, eight chains a wavefront; its second instance
+//                      (ChainCfg::RUNS, r06) resolves a position inside a stretch of a short period -- a run of a byte, a line
+//                      repeated -- from the window's stretches (chain_period_visit); period_sample_block picks the instance
 //   E3 k_parse_exit / k_parse_super / k_parse_chain / k_parse_fill / k_parse_mark
 //                  the greedy chain of lzss.go:136-151 (position i is visited iff no earlier
 //                  visited reference covers it), without a serial walk over the stream
